@@ -1,0 +1,113 @@
+"""ctypes binding of libgssgcn.so (include/gssgcn.h).  No CPU fallback: if the library is missing or a
+call fails this raises -- the product path never routes around the HIP kernels."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgssgcn.so")
+CSRC = os.path.join(_HERE, "csrc")
+ABI_VERSION = 1
+
+_lib = None
+
+
+class GssError(RuntimeError):
+    pass
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("d", C.c_int32), ("num_layers", C.c_int32), ("max_batch", C.c_int32),
+                ("layer_decay", C.c_float), ("alpha", C.c_float), ("lr", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float), ("cache_layer1", C.c_int32)]
+
+
+class PlanIO(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("x", "w1", "b1", "w2", "b2", "emb", "loss", "gw1", "gb1", "gw2", "gb2")]
+
+
+_P, _I32, _I64, _F, _D, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/gssgcn.h one to one
+SIGNATURES = {
+    "gss_abi_version": (C.c_int, []),
+    "gss_last_error": (C.c_char_p, []),
+    "gss_normalize_adj": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P]),
+    "gss_csr_create": (C.c_int, [C.POINTER(_P), _I32, _I32, _I64, _P, _P, _P, _P]),
+    "gss_csr_destroy": (None, [_P]),
+    "gss_spmm": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P]),
+    "gss_spmm_bwd1": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "gss_spmm_bwd2": (C.c_int, [_P, _I32, _P, _P, _P, _F, _P, _P, _P, _P]),
+    "gss_dense_fwd": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "gss_dense_bwd_input": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "gss_wgrad_workspace_bytes": (_SZ, [_I32, _I32]),
+    "gss_dense_bwd_weight": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
+    "gss_rownorm_fwd": (C.c_int, [_I32, _I32, _P, _P, _P, _P]),
+    "gss_loss_workspace_bytes": (_SZ, [_I32, _I32]),
+    "gss_loss_fwd_bwd": (C.c_int, [_I32, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
+    "gss_rownorm_elu_bwd": (C.c_int, [_I32, _P, _P, _I32, _P, _P, _P, _F, _P, _P, _P]),
+    "gss_scatter_add_rows": (C.c_int, [_I32, _P, _P, _I32, _P, _P]),
+    "gss_adam_step": (C.c_int, [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P, _I32, _P]),
+    "gss_percentile": (C.c_int, [_I32, _I32, _P, _D, C.POINTER(_F), _P]),
+    "gss_plan_create": (C.c_int, [C.POINTER(_P), C.POINTER(PlanDesc), _P, _P, C.POINTER(PlanIO)]),
+    "gss_plan_destroy": (None, [_P]),
+    "gss_plan_forward": (C.c_int, [_P, _P]),
+    "gss_plan_loss_backward": (C.c_int, [_P, _P, _I32, _F, _P]),
+    "gss_plan_backward": (C.c_int, [_P, _P, _I32, _P, _P]),
+    "gss_plan_adam": (C.c_int, [_P, _P]),
+    "gss_plan_step": (C.c_int, [_P, _P, _I32, _F, _P]),
+    "gss_plan_activation": (_P, [_P, C.c_int, C.c_int]),
+    "gss_plan_device_bytes": (_SZ, [_P]),
+    "gss_plan_set_step": (None, [_P, _I32]),
+    "gss_plan_get_step": (_I32, [_P]),
+    "gss_memcpy_d2d": (C.c_int, [_P, _P, _SZ, _P]),
+}
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libgssgcn.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise GssError("building libgssgcn.so failed (hipcc --offload-arch=gfx950); see output above")
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library and declare every prototype.  Raises GssError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GssError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"or `make -C {CSRC}` -- there is no CPU fallback for the GSS-GCN kernels")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here means header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gss_abi_version() != ABI_VERSION:
+        raise GssError(f"libgssgcn.so ABI {lib.gss_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().gss_last_error().decode(errors="replace")
+        raise GssError(f"{what or 'libgssgcn'} failed with code {rc}: {msg}")
+
+
+def ptr(t) -> int:
+    """device pointer of a torch tensor (None -> NULL)"""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

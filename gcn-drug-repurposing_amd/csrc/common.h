@@ -1,0 +1,98 @@
+// common.h -- shared host/device helpers for libgssgcn.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gssgcn.h"
+
+namespace gss {
+
+constexpr int kWave = 64;
+
+// ---- error plumbing (thread-local last error text) ------------------------------------------
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+inline int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define GSS_HIP(call)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return ::gss::fail(GSS_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+  } while (0)
+
+#define GSS_LAUNCH_CHECK(name)                                                                \
+  do {                                                                                        \
+    hipError_t e_ = hipGetLastError();                                                        \
+    if (e_ != hipSuccess)                                                                     \
+      return ::gss::fail(GSS_EHIP, "launch %s -> %s", name, hipGetErrorString(e_));           \
+  } while (0)
+
+#define GSS_REQUIRE(cond, ...)                                                                \
+  do {                                                                                        \
+    if (!(cond)) return ::gss::fail(GSS_EINVAL, __VA_ARGS__);                                 \
+  } while (0)
+
+inline int check_d(int32_t d) {
+  if (d < 16 || d > 1024 || (d % 16) != 0)
+    return fail(GSS_EINVAL, "hidden size d=%d unsupported: need a multiple of 16 in [16, 1024]", d);
+  return GSS_OK;
+}
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers ---------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+__device__ __forceinline__ float4 fma4(float s, float4 x, float4 a) {
+  a.x = fmaf(s, x.x, a.x);
+  a.y = fmaf(s, x.y, a.y);
+  a.z = fmaf(s, x.z, a.z);
+  a.w = fmaf(s, x.w, a.w);
+  return a;
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 scale4(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+
+// F.elu (alpha = 1) and its derivative expressed through the pre-activation
+__device__ __forceinline__ float elu1(float p) { return p > 0.f ? p : expm1f(p); }
+__device__ __forceinline__ float elu1_grad(float p) { return p > 0.f ? 1.f : expf(p); }
+__device__ __forceinline__ float4 elu_grad4(float4 p) {
+  return make_float4(elu1_grad(p.x), elu1_grad(p.y), elu1_grad(p.z), elu1_grad(p.w));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id (cdna guide T1): blocks b and b+8 share an XCD, so give
+// each XCD a contiguous chunk of the logical grid.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, k = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+}  // namespace gss

@@ -1,0 +1,413 @@
+// dense.hip -- the dense half of the GSS layer on fp32 MFMA (K3/K4/K8 of SURVEY.md section 2b).
+//
+//   gemm_nt_kernel   OUT[n][j] = sum_k IN[n][k] * W[j][k]      (both operands K-contiguous)
+//       forward  : P = [AX|AM] . [W1|W2]^T + b1 + b2, O = ELU(P), x_next = P_prev + decay O
+//                  (nn.Linear x2 + add + F.elu + residual, modules/model.py:165,170-173,201-203)
+//       backward : [g_ax | g_am] = dP . [W1 ; W2]  using pre-transposed weights
+//   wgrad_tn_kernel  dW[f][k] = sum_n dP[n][f] * Z[n][k]        (reduction over the node dimension)
+//
+// MFMA: v_mfma_f32_16x16x4_f32 (exact fp32, 256 FLOP/clk/CU).  Operands are loaded as float4 per
+// lane straight from L1/L2 -- at the fp32 MFMA rate (32 cycles per instruction) one 16-B load per 4
+// MFMAs per lane is far below the L1 rate, so no LDS staging is needed.  The float4's four elements
+// feed four consecutive k-steps: a k-chunk of 16 is consumed in the order k = kc + 4*(lane>>4) + e,
+// a permutation of the reduction order that both operands share.
+// The operands are swapped (A = weights, B = node rows) so that each lane ends up with 4 consecutive
+// output features of one node row -> float4 epilogue loads/stores.
+//
+// Roofline: MFMA fp32 (157 TFLOP/s).  flops fwd = 2 N (2d) d; bwd-input = 2 N d (2d); wgrad = 2 N d (2d).
+#include "ops.h"
+
+namespace gss {
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+enum GemmEpi { EPI_FWD = 0, EPI_SPLIT = 1 };
+
+struct GemmArgs {
+  int n;              // node rows
+  int K, ksplit;      // reduction length; k < ksplit reads in0 / w[.][0], else in1 / w[.][1]
+  int J, jsplit;      // output features; j < jsplit -> out0 / w[0][.], else out1 / w[1][.]
+  const float *in0, *in1;
+  int ld_in0, ld_in1;
+  const float *w[2][2];
+  int ld_w;
+  float *out0, *out1;
+  int ld_out0, ld_out1;
+  // EPI_FWD
+  const float *b1, *b2, *p_prev;
+  float *x_next;
+  float decay;
+  // EPI_SPLIT
+  const int32_t *rows;  // scatter map for the output row (nullable)
+};
+
+template <int FT, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int node0 = (blockIdx.x * 4 + wib) * 32;
+  if (node0 >= g.n) return;
+  const int j0 = blockIdx.y * (16 * FT);
+  const int jh = j0 >= g.jsplit ? 1 : 0;
+  const int jrow0 = j0 - (jh ? g.jsplit : 0);
+
+  int node[2];
+  node[0] = min(g.n - 1, node0 + r);
+  node[1] = min(g.n - 1, node0 + 16 + r);
+
+  f32x4 acc[2][FT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < FT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int kh = 0; kh < 2; ++kh) {
+    const int kbeg = kh ? g.ksplit : 0;
+    const int kend = kh ? g.K : g.ksplit;
+    if (kbeg >= kend) continue;
+    const float *in = kh ? g.in1 : g.in0;
+    const int ld = kh ? g.ld_in1 : g.ld_in0;
+    const float *w = g.w[jh][kh];
+    const float *bp[2];
+    bp[0] = in + (size_t)node[0] * ld + 4 * q;
+    bp[1] = in + (size_t)node[1] * ld + 4 * q;
+    const float *ap[FT];
+#pragma unroll
+    for (int u = 0; u < FT; ++u) ap[u] = w + (size_t)(jrow0 + 16 * u + r) * g.ld_w + 4 * q;
+    const int klen = kend - kbeg;
+
+    for (int kc = 0; kc < klen; kc += 16) {
+      float4 b[2], a[FT];
+      b[0] = ld4(bp[0] + kc);
+      b[1] = ld4(bp[1] + kc);
+#pragma unroll
+      for (int u = 0; u < FT; ++u) a[u] = ld4(ap[u] + kc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float bv = e == 0 ? b[t].x : e == 1 ? b[t].y : e == 2 ? b[t].z : b[t].w;
+#pragma unroll
+          for (int u = 0; u < FT; ++u) {
+            const float av = e == 0 ? a[u].x : e == 1 ? a[u].y : e == 2 ? a[u].z : a[u].w;
+            acc[t][u] = mfma16(av, bv, acc[t][u]);
+          }
+        }
+      }
+    }
+  }
+
+  // epilogue: lane (r, q) holds OUT[node0 + 16 t + r][j0 + 16 u + 4 q + 0..3]
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int nd = node0 + 16 * t + r;
+    if (nd >= g.n) continue;
+#pragma unroll
+    for (int u = 0; u < FT; ++u) {
+      const int j = j0 + 16 * u + 4 * q;
+      float4 v = make_float4(acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]);
+      if (EPI == EPI_FWD) {
+        const float4 bb = add4(ld4(g.b1 + j), ld4(g.b2 + j));
+        const float4 p = add4(v, bb);
+        const size_t off = (size_t)nd * g.ld_out0 + j;
+        st4(g.out0 + off, p);
+        float4 o = make_float4(elu1(p.x), elu1(p.y), elu1(p.z), elu1(p.w));
+        if (g.p_prev) o = add4(ld4(g.p_prev + off), scale4(g.decay, o));
+        st4(g.x_next + off, o);
+      } else {
+        const int orow = g.rows ? g.rows[nd] : nd;
+        if (jh == 0)
+          st4(g.out0 + (size_t)orow * g.ld_out0 + j, v);
+        else
+          st4(g.out1 + (size_t)orow * g.ld_out1 + (j - g.jsplit), v);
+      }
+    }
+  }
+}
+
+template <int EPI>
+static int launch_gemm(const GemmArgs &g, int d, hipStream_t st) {
+  const int ft = (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
+  dim3 grid(ceil_div(g.n, 128), g.J / (16 * ft));
+  if (g.n <= 0) return GSS_OK;
+  if (ft == 4)
+    hipLaunchKernelGGL((gemm_nt_kernel<4, EPI>), grid, dim3(256), 0, st, g);
+  else if (ft == 2)
+    hipLaunchKernelGGL((gemm_nt_kernel<2, EPI>), grid, dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<1, EPI>), grid, dim3(256), 0, st, g);
+  GSS_LAUNCH_CHECK("gemm_nt_kernel");
+  return GSS_OK;
+}
+
+int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
+              const float *b2, const float *p_prev, float decay, float *p, float *x_next, void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(n >= 0 && ax && am && w1 && b1 && w2 && b2 && p && x_next, "dense_fwd: null operand");
+  GemmArgs g{};
+  g.n = n;
+  g.K = 2 * d;
+  g.ksplit = d;
+  g.J = d;
+  g.jsplit = d;
+  g.in0 = ax;
+  g.in1 = am;
+  g.ld_in0 = g.ld_in1 = d;
+  g.w[0][0] = w1;
+  g.w[0][1] = w2;
+  g.w[1][0] = g.w[1][1] = nullptr;
+  g.ld_w = d;
+  g.out0 = p;
+  g.out1 = nullptr;
+  g.ld_out0 = g.ld_out1 = d;
+  g.b1 = b1;
+  g.b2 = b2;
+  g.p_prev = p_prev;
+  g.x_next = x_next;
+  g.decay = decay;
+  g.rows = nullptr;
+  return launch_gemm<EPI_FWD>(g, d, as_stream(stream));
+}
+
+int dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t, const float *w2t, const int32_t *rows,
+                    float *g_ax, float *g_am, void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(n >= 0 && dp && w1t && w2t && g_ax && g_am, "dense_bwd_input: null operand");
+  GemmArgs g{};
+  g.n = n;
+  g.K = d;
+  g.ksplit = d;
+  g.J = 2 * d;
+  g.jsplit = d;
+  g.in0 = dp;
+  g.in1 = nullptr;
+  g.ld_in0 = g.ld_in1 = d;
+  g.w[0][0] = w1t;
+  g.w[1][0] = w2t;
+  g.w[0][1] = g.w[1][1] = nullptr;
+  g.ld_w = d;
+  g.out0 = g_ax;
+  g.out1 = g_am;
+  g.ld_out0 = g.ld_out1 = d;
+  g.rows = rows;
+  return launch_gemm<EPI_SPLIT>(g, d, as_stream(stream));
+}
+
+// ---- weight gradients -----------------------------------------------------------------------------
+//
+// dWcat[f][k] = sum_n dP[n][f] * Z[n][k],  Z = [AX | AM]  (d x 2d output, reduction over nodes).
+// One workgroup = 8 waves = one 64x64 output tile over one slice of the node range; wave w takes rows
+// 4*(8 it + w) + (lane>>4).  A lane's float4 of dP holds 4 consecutive features: element e is the A
+// operand of the MFMA whose output rows are features 64 G + 4 fi + e (fi = lane & 15) -- a row
+// permutation undone when storing.  Same for Z on the column side.  Partial tiles are tree-reduced
+// through LDS in a fixed order, written per slice and summed in slice order by wgrad_reduce_kernel.
+
+constexpr int kWgWaves = 8;
+
+struct WgradArgs {
+  int n, d;
+  const float *dp, *ax, *am;
+  const int32_t *rows;
+  float *part_w;  // [nslices][d][2d]
+  float *part_b;  // [nslices][d]
+  int rows_per_slice;
+};
+
+__global__ __launch_bounds__(64 * kWgWaves) void wgrad_tn_kernel(WgradArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *red = reinterpret_cast<float4 *>(smem);  // [4 slots][16 tiles][64 lanes] float4
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int fi = lane & 15, q = lane >> 4;
+  const int tiles_k = (2 * g.d) / 64;
+  const int G = blockIdx.x / tiles_k, H = blockIdx.x % tiles_k;
+  const int slice = blockIdx.y;
+  const int r0 = slice * g.rows_per_slice;
+  const int r1 = min(g.n, r0 + g.rows_per_slice);
+  const int dh = g.d / 64;
+  const float *z = (H < dh) ? g.ax : g.am;
+  const int zc = (H < dh ? H : H - dh) * 64 + 4 * fi;
+  const int ac = G * 64 + 4 * fi;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) acc[e][e2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+
+
+  for (int base = r0 + 4 * w; base < r1; base += 4 * kWgWaves) {
+    const int row = base + q;
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
+    if (row < r1) {
+      a4 = ld4(g.dp + (size_t)row * g.d + ac);
+      const int zr = g.rows ? g.rows[row] : row;
+      b4 = ld4(z + (size_t)zr * g.d + zc);
+    }
+    cs = add4(cs, a4);
+    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+    const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) acc[e][e2] = mfma16(av[e], bv[e2], acc[e][e2]);
+  }
+
+  // tree reduction over the 8 waves (fixed order): 4..7 -> 0..3, 2..3 -> 0..1, 1 -> 0
+  for (int half = kWgWaves / 2; half >= 1; half >>= 1) {
+    if (w >= half && w < 2 * half) {
+      float4 *dst = red + (size_t)(w - half) * 16 * 64;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2)
+          dst[(e * 4 + e2) * 64 + lane] = make_float4(acc[e][e2][0], acc[e][e2][1], acc[e][e2][2], acc[e][e2][3]);
+    }
+    __syncthreads();
+    if (w < half) {
+      const float4 *src = red + (size_t)w * 16 * 64;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          const float4 v = src[(e * 4 + e2) * 64 + lane];
+          acc[e][e2][0] += v.x;
+          acc[e][e2][1] += v.y;
+          acc[e][e2][2] += v.z;
+          acc[e][e2][3] += v.w;
+        }
+    }
+    __syncthreads();
+  }
+
+  // column sums of dP (bias gradient) from the H == 0 workgroups
+  if (H == 0) {
+    cs.x += __shfl_xor(cs.x, 16, 64); cs.y += __shfl_xor(cs.y, 16, 64); cs.z += __shfl_xor(cs.z, 16, 64); cs.w += __shfl_xor(cs.w, 16, 64);
+    cs.x += __shfl_xor(cs.x, 32, 64); cs.y += __shfl_xor(cs.y, 32, 64); cs.z += __shfl_xor(cs.z, 32, 64); cs.w += __shfl_xor(cs.w, 32, 64);
+    if (q == 0) red[w * 16 + fi] = cs;
+    __syncthreads();
+    if (w == 0 && q == 0) {
+      float4 s = red[fi];
+      for (int ww = 1; ww < kWgWaves; ++ww) s = add4(s, red[ww * 16 + fi]);
+      st4(g.part_b + (size_t)slice * g.d + ac, s);
+    }
+  }
+
+  if (w == 0) {
+    // tile (e, e2), lane (c = fi, q), reg: f = 64 G + 4 (4 q + reg) + e ; k = 64 H + 4 c + e2
+    float *pw = g.part_w + (size_t)slice * g.d * (2 * g.d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int f = 64 * G + 4 * (4 * q + reg) + e;
+        const int k = 64 * H + 4 * fi;
+        st4(pw + (size_t)f * (2 * g.d) + k, make_float4(acc[e][0][reg], acc[e][1][reg], acc[e][2][reg], acc[e][3][reg]));
+      }
+  }
+}
+
+// generic VALU fallback for d not a multiple of 64 (test sizes): one thread per output element
+__global__ __launch_bounds__(256) void wgrad_simple_kernel(WgradArgs g) {
+  const int slice = blockIdx.y;
+  const int r0 = slice * g.rows_per_slice, r1 = min(g.n, r0 + g.rows_per_slice);
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int d = g.d;
+  if (idx < d * 2 * d) {
+    const int f = idx / (2 * d), k = idx % (2 * d);
+    const float *z = k < d ? g.ax : g.am;
+    const int kk = k < d ? k : k - d;
+    float s = 0.f;
+    for (int row = r0; row < r1; ++row) {
+      const int zr = g.rows ? g.rows[row] : row;
+      s = fmaf(g.dp[(size_t)row * d + f], z[(size_t)zr * d + kk], s);
+    }
+    g.part_w[(size_t)slice * d * 2 * d + idx] = s;
+  } else if (idx < d * 2 * d + d) {
+    const int f = idx - d * 2 * d;
+    float s = 0.f;
+    for (int row = r0; row < r1; ++row) s += g.dp[(size_t)row * d + f];
+    g.part_b[(size_t)slice * d + f] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(int d, int nslices, const float *__restrict__ part_w,
+                                                            const float *__restrict__ part_b, float *__restrict__ gw1,
+                                                            float *__restrict__ gw2, float *__restrict__ gb, int accumulate) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int nw = d * 2 * d;
+  if (idx < nw) {
+    float s = 0.f;
+    for (int sl = 0; sl < nslices; ++sl) s += part_w[(size_t)sl * nw + idx];
+    const int f = idx / (2 * d), k = idx % (2 * d);
+    float *dst = k < d ? gw1 + (size_t)f * d + k : gw2 + (size_t)f * d + (k - d);
+    *dst = accumulate ? *dst + s : s;
+  } else if (idx < nw + d) {
+    const int f = idx - nw;
+    float s = 0.f;
+    for (int sl = 0; sl < nslices; ++sl) s += part_b[(size_t)sl * d + f];
+    gb[f] = accumulate ? gb[f] + s : s;
+  }
+}
+
+static void wgrad_geometry(int32_t n, int32_t d, int &nslices, int &rows_per_slice) {
+  const int tiles = (d % 64 == 0) ? (d / 64) * (2 * d / 64) : ceil_div((int64_t)d * 2 * d + d, 256);
+  int want = ceil_div(512, tiles);
+  const int max_slices = n > 0 ? ceil_div(n, 32) : 1;
+  if (want > max_slices) want = max_slices;
+  if (want < 1) want = 1;
+  rows_per_slice = ceil_div(ceil_div(n > 0 ? n : 1, want), 32) * 32;
+  nslices = ceil_div(n > 0 ? n : 1, rows_per_slice);
+}
+
+size_t wgrad_workspace_bytes(int32_t n, int32_t d) {
+  int ns, rps;
+  wgrad_geometry(n, d, ns, rps);
+  return sizeof(float) * (size_t)ns * ((size_t)d * 2 * d + d);
+}
+
+int dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, const float *am, const int32_t *rows,
+                     float *gw1, float *gw2, float *gb, int accumulate, void *ws, void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(n >= 0 && dp && ax && am && gw1 && gw2 && gb && ws, "dense_bwd_weight: null operand");
+  hipStream_t st = as_stream(stream);
+  int ns, rps;
+  wgrad_geometry(n, d, ns, rps);
+  WgradArgs g{n, d, dp, ax, am, rows, (float *)ws, (float *)ws + (size_t)ns * d * 2 * d, rps};
+  if (d % 64 == 0) {
+    const int tiles = (d / 64) * (2 * d / 64);
+    hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns), dim3(64 * kWgWaves), 4 * 16 * 64 * sizeof(float4), st, g);
+    GSS_LAUNCH_CHECK("wgrad_tn_kernel");
+  } else {
+    hipLaunchKernelGGL(wgrad_simple_kernel, dim3(ceil_div((int64_t)d * 2 * d + d, 256), ns), dim3(256), 0, st, g);
+    GSS_LAUNCH_CHECK("wgrad_simple_kernel");
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div((int64_t)d * 2 * d + d, 256)), dim3(256), 0, st, d, ns, g.part_w,
+                     g.part_b, gw1, gw2, gb, accumulate);
+  GSS_LAUNCH_CHECK("wgrad_reduce_kernel");
+  return GSS_OK;
+}
+
+}  // namespace gss
+
+using namespace gss;
+
+extern "C" {
+int gss_dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
+                  const float *b2, const float *p_prev, float decay, float *p, float *x_next, void *stream) {
+  return dense_fwd(n, d, ax, am, w1, b1, w2, b2, p_prev, decay, p, x_next, stream);
+}
+int gss_dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t, const float *w2t, const int32_t *rows,
+                        float *g_ax, float *g_am, void *stream) {
+  return dense_bwd_input(n, d, dp, w1t, w2t, rows, g_ax, g_am, stream);
+}
+size_t gss_wgrad_workspace_bytes(int32_t n, int32_t d) { return wgrad_workspace_bytes(n, d); }
+int gss_dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, const float *am, const int32_t *rows,
+                         float *gw1, float *gw2, float *gb, int accumulate, void *ws, void *stream) {
+  return dense_bwd_weight(n, d, dp, ax, am, rows, gw1, gw2, gb, accumulate, ws, stream);
+}
+}

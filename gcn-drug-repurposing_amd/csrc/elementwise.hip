@@ -1,0 +1,226 @@
+// elementwise.hip -- row normalisation (K5), its backward fused with ELU' on the batch rows,
+// row scatter-add, Adam (K10) and weight transposes.  All HBM/L2-bound streaming kernels.
+#include "ops.h"
+
+namespace gss {
+
+// ---- K5  F.normalize(x, dim=1), modules/model.py:205 -----------------------------------------------
+// A row of d floats is covered by LPR = min(64, pow2ceil(d/4)) lanes holding VPL float4 each, so one
+// wave normalises 64/LPR rows; the sum of squares is reduced with xor-shuffles inside the lane group.
+template <int VPL>
+__global__ __launch_bounds__(256) void rownorm_fwd_kernel(int n, int d4, int lpr_log2, const float *__restrict__ x,
+                                                          float *__restrict__ e, float *__restrict__ inv_den) {
+  const int lane = threadIdx.x & 63;
+  const int lpr = 1 << lpr_log2;
+  const int rpw = 64 >> lpr_log2;
+  const int li = lane & (lpr - 1);
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + (lane >> lpr_log2);
+  const bool ok = row < n;
+  float4 v[VPL];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int f4 = li + k * 64;
+    v[k] = (ok && f4 < d4) ? ld4(x + ((size_t)row * d4 + f4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+  }
+  for (int o = 1; o < lpr; o <<= 1) ss += __shfl_xor(ss, o, 64);
+  const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+  if (!ok) return;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int f4 = li + k * 64;
+    if (f4 < d4) st4(e + ((size_t)row * d4 + f4) * 4, scale4(inv, v[k]));
+  }
+  if (li == 0) inv_den[row] = inv;
+}
+
+// backward of F.normalize and of F.elu / the residual mix on the batch rows (autograd of
+// model.py:173,201-205): dx = (de - e (e . de)) * inv_den ; dp = c * dx (.) elu'(p)
+template <int VPL>
+__global__ __launch_bounds__(256) void rownorm_elu_bwd_kernel(int b, int d4, int lpr_log2, const float *__restrict__ de_b,
+                                                              const int32_t *__restrict__ idx, const float *__restrict__ e,
+                                                              const float *__restrict__ inv_den, const float *__restrict__ p,
+                                                              float c, float *__restrict__ dx_b, float *__restrict__ dp_b) {
+  const int lane = threadIdx.x & 63;
+  const int lpr = 1 << lpr_log2;
+  const int rpw = 64 >> lpr_log2;
+  const int li = lane & (lpr - 1);
+  const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + (lane >> lpr_log2);
+  const bool ok = r < b;
+  const int node = ok ? idx[r] : 0;
+  float4 g[VPL], ev[VPL];
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int f4 = li + k * 64;
+    const bool in = ok && f4 < d4;
+    g[k] = in ? ld4(de_b + ((size_t)r * d4 + f4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ev[k] = in ? ld4(e + ((size_t)node * d4 + f4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    dot += g[k].x * ev[k].x + g[k].y * ev[k].y + g[k].z * ev[k].z + g[k].w * ev[k].w;
+  }
+  for (int o = 1; o < lpr; o <<= 1) dot += __shfl_xor(dot, o, 64);
+  if (!ok) return;
+  const float inv = inv_den[node];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int f4 = li + k * 64;
+    if (f4 >= d4) continue;
+    float4 dx;
+    dx.x = (g[k].x - ev[k].x * dot) * inv;
+    dx.y = (g[k].y - ev[k].y * dot) * inv;
+    dx.z = (g[k].z - ev[k].z * dot) * inv;
+    dx.w = (g[k].w - ev[k].w * dot) * inv;
+    st4(dx_b + ((size_t)r * d4 + f4) * 4, dx);
+    const float4 pg = elu_grad4(ld4(p + ((size_t)node * d4 + f4) * 4));
+    st4(dp_b + ((size_t)r * d4 + f4) * 4, scale4(c, mul4(dx, pg)));
+  }
+}
+
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(int b, int d4, const float *__restrict__ src,
+                                                               const int32_t *__restrict__ rows, float *__restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)b * d4) return;
+  const int r = (int)(i / d4), f4 = (int)(i % d4);
+  float *p = dst + ((size_t)rows[r] * d4 + f4) * 4;
+  st4(p, add4(ld4(p), ld4(src + i * 4)));
+}
+
+// ---- K10  torch.optim.Adam (single-tensor form of torch/optim/adam.py; train.py:139-141,184) -------
+__global__ __launch_bounds__(256) void adam_kernel(int64_t count, float *__restrict__ param, const float *__restrict__ grad,
+                                                   float *__restrict__ m, float *__restrict__ v, float lr_over_bc1,
+                                                   float inv_sqrt_bc2, float beta1, float beta2, float eps,
+                                                   float *__restrict__ wt, int dim) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const float g = grad[i];
+  const float mi = m[i] + (g - m[i]) * (1.f - beta1);      // exp_avg.lerp_(grad, 1 - beta1)
+  const float vi = v[i] * beta2 + (1.f - beta2) * g * g;  // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;     // (sqrt(v) / sqrt(bc2)) + eps
+  const float pn = param[i] - lr_over_bc1 * (mi / denom);
+  param[i] = pn;
+  if (wt) {
+    const int r = (int)(i / dim), cidx = (int)(i % dim);
+    wt[(size_t)cidx * dim + r] = pn;
+  }
+}
+
+__global__ __launch_bounds__(256) void transpose2_kernel(int dim, const float *__restrict__ a, const float *__restrict__ b,
+                                                         float *__restrict__ at, float *__restrict__ bt) {
+  __shared__ float tile[2][32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int r = by + k, cidx = bx + tx;
+    if (r < dim && cidx < dim) {
+      tile[0][k][tx] = a[(size_t)r * dim + cidx];
+      tile[1][k][tx] = b[(size_t)r * dim + cidx];
+    }
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int r = bx + k, cidx = by + tx;
+    if (r < dim && cidx < dim) {
+      at[(size_t)r * dim + cidx] = tile[0][tx][k];
+      bt[(size_t)r * dim + cidx] = tile[1][tx][k];
+    }
+  }
+}
+
+static void row_geometry(int d, int &d4, int &lpr_log2, int &vpl) {
+  d4 = d / 4;
+  lpr_log2 = 2;
+  while ((1 << lpr_log2) < d4 && lpr_log2 < 6) ++lpr_log2;
+  vpl = d4 <= 64 ? 1 : d4 <= 128 ? 2 : 4;
+}
+
+int rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(n >= 0 && x && e && inv_den, "rownorm_fwd: null operand");
+  if (n == 0) return GSS_OK;
+  int d4, lg, vpl;
+  row_geometry(d, d4, lg, vpl);
+  const int rows_per_block = 4 * (64 >> lg);
+  dim3 grid(ceil_div(n, rows_per_block)), block(256);
+  hipStream_t st = as_stream(stream);
+  if (vpl == 1)
+    hipLaunchKernelGGL((rownorm_fwd_kernel<1>), grid, block, 0, st, n, d4, lg, x, e, inv_den);
+  else if (vpl == 2)
+    hipLaunchKernelGGL((rownorm_fwd_kernel<2>), grid, block, 0, st, n, d4, lg, x, e, inv_den);
+  else
+    hipLaunchKernelGGL((rownorm_fwd_kernel<4>), grid, block, 0, st, n, d4, lg, x, e, inv_den);
+  GSS_LAUNCH_CHECK("rownorm_fwd_kernel");
+  return GSS_OK;
+}
+
+int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b, const float *e, const float *inv_den,
+                    const float *p, float c, float *dx_b, float *dp_b, void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(b >= 0 && de_b && idx && e && inv_den && p && dx_b && dp_b, "rownorm_elu_bwd: null operand");
+  if (b == 0) return GSS_OK;
+  int d4, lg, vpl;
+  row_geometry(d, d4, lg, vpl);
+  const int rows_per_block = 4 * (64 >> lg);
+  dim3 grid(ceil_div(b, rows_per_block)), block(256);
+  hipStream_t st = as_stream(stream);
+  if (vpl == 1)
+    hipLaunchKernelGGL((rownorm_elu_bwd_kernel<1>), grid, block, 0, st, b, d4, lg, de_b, idx, e, inv_den, p, c, dx_b, dp_b);
+  else if (vpl == 2)
+    hipLaunchKernelGGL((rownorm_elu_bwd_kernel<2>), grid, block, 0, st, b, d4, lg, de_b, idx, e, inv_den, p, c, dx_b, dp_b);
+  else
+    hipLaunchKernelGGL((rownorm_elu_bwd_kernel<4>), grid, block, 0, st, b, d4, lg, de_b, idx, e, inv_den, p, c, dx_b, dp_b);
+  GSS_LAUNCH_CHECK("rownorm_elu_bwd_kernel");
+  return GSS_OK;
+}
+
+int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(b >= 0 && src && rows && dst, "scatter_add_rows: null operand");
+  if (b == 0) return GSS_OK;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(ceil_div((int64_t)b * d / 4, 256)), dim3(256), 0, as_stream(stream), b,
+                     d / 4, src, rows, dst);
+  GSS_LAUNCH_CHECK("scatter_add_rows_kernel");
+  return GSS_OK;
+}
+
+int adam_step(int64_t count, float *param, const float *grad, float *m, float *v, int32_t step, float lr, float beta1,
+              float beta2, float eps, float *wt, int32_t dim, void *stream) {
+  GSS_REQUIRE(count >= 0 && param && grad && m && v && step >= 1, "adam_step: bad argument (step is 1-based)");
+  GSS_REQUIRE(!wt || (int64_t)dim * dim == count, "adam_step: transposed copy needs count == dim*dim");
+  if (count == 0) return GSS_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, as_stream(stream), count, param, grad, m, v,
+                     (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, wt, dim > 0 ? dim : 1);
+  GSS_LAUNCH_CHECK("adam_kernel");
+  return GSS_OK;
+}
+
+int transpose2(int32_t dim, const float *a, const float *b, float *at, float *bt, void *stream) {
+  const int nb = ceil_div(dim, 32);
+  hipLaunchKernelGGL(transpose2_kernel, dim3(nb, nb), dim3(256), 0, as_stream(stream), dim, a, b, at, bt);
+  GSS_LAUNCH_CHECK("transpose2_kernel");
+  return GSS_OK;
+}
+
+}  // namespace gss
+
+using namespace gss;
+extern "C" {
+int gss_rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, void *stream) {
+  return rownorm_fwd(n, d, x, e, inv_den, stream);
+}
+int gss_rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b, const float *e, const float *inv_den,
+                        const float *p, float c, float *dx_b, float *dp_b, void *stream) {
+  return rownorm_elu_bwd(d, de_b, idx, b, e, inv_den, p, c, dx_b, dp_b, stream);
+}
+int gss_scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, void *stream) {
+  return scatter_add_rows(d, src, rows, b, dst, stream);
+}
+int gss_adam_step(int64_t count, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int32_t step, float lr,
+                  float beta1, float beta2, float eps, float *wt, int32_t dim, void *stream) {
+  return adam_step(count, param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, wt, dim, stream);
+}
+}

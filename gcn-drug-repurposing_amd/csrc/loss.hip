@@ -1,0 +1,223 @@
+// loss.hip -- GSS similarity loss, forward and backward fused (K6/K7 of SURVEY.md section 2b).
+//
+// Replaces GSS_loss.gss_loss (modules/model.py:214-221) and its autograd:
+//   E_B = e[idx];  S = E_B E_B^T;  loss = mean(-alpha/2 (relu(S) - beta)^2)
+//   dE_B[i] = sum_j (G_ij + G_ji) E_B[j] = 2 sum_j G_ij E_B[j],   G = -alpha/B^2 (relu(S)-beta) 1[S>0]
+// (S is symmetric bit for bit: S_ij and S_ji are the same fmaf chain over k.)
+//
+// Flash-style: the B x B matrices S and G are never written.  A wave owns a 16-row i-tile and walks
+// j-tiles: S'^T tile = E_j E_i^T on v_mfma_f32_16x16x4_f32 (d/4 MFMAs), G elementwise in registers,
+// then dE_i += G E_j (d/4 MFMAs).  The accumulator layout of the first product (lane = i, register =
+// j & 3, lane quarter = j >> 2) is exactly the B-operand layout of the second, so G never leaves the
+// registers.  A workgroup's 4 waves split the j range, several workgroups (grid.y) split it further;
+// partial dE tiles are tree-reduced in LDS and the grid.y partials are summed by loss_finish_kernel.
+//
+// Roofline: MFMA fp32.  flops = 2 B^2 d (S) + 2 B^2 d (G E) = 4 B^2 d, S tiles computed once.
+#include "ops.h"
+
+namespace gss {
+
+__device__ __forceinline__ f32x4 mfma16l(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+constexpr int kLossWaves = 4;
+
+struct LossArgs {
+  int d, b, js;  // js = grid.y
+  const float *e;
+  const int32_t *idx;
+  float beta, alpha;
+  float *de_part;     // [js][b][d]
+  double *loss_part;  // [grid.x * grid.y]
+};
+
+template <int NG>
+__global__ __launch_bounds__(64 * kLossWaves) void loss_fused_kernel(LossArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *red = reinterpret_cast<float4 *>(smem);  // [2 slots][NG*4 tiles][64 lanes]
+  __shared__ double lsum[kLossWaves];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int d = g.d, B = g.b;
+  const int fbase = blockIdx.z * (64 * NG);
+  const int i0 = blockIdx.x * 16;
+  const int nj = (B + 15) / 16;
+  const int nslots = kLossWaves * g.js;
+  const int slot = blockIdx.y * kLossWaves + w;
+  const float coef = -g.alpha / ((float)B * (float)B);
+  const float beta = g.beta;
+
+  const float *ei = g.e + (size_t)g.idx[min(B - 1, i0 + c)] * d + 4 * q;
+  const bool i_ok = (i0 + c) < B;
+
+  f32x4 acc[NG][4];
+#pragma unroll
+  for (int G = 0; G < NG; ++G)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[G][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float lacc = 0.f;
+
+  for (int jt = slot; jt < nj; jt += nslots) {
+    const int j0 = jt * 16;
+    // ---- S'[j][i] = E_j . E_i  (A = E_j rows, B = E_i rows), k order kc + 4 q + e
+    const float *ej = g.e + (size_t)g.idx[min(B - 1, j0 + c)] * d + 4 * q;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < d; kc += 16) {
+      const float4 a4 = ld4(ej + kc);
+      const float4 b4 = ld4(ei + kc);
+      s = mfma16l(a4.x, b4.x, s);
+      s = mfma16l(a4.y, b4.y, s);
+      s = mfma16l(a4.z, b4.z, s);
+      s = mfma16l(a4.w, b4.w, s);
+    }
+    // lane (c, q), reg r: S[i0 + c][j0 + 4 q + r]
+    float gv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = i_ok && (j0 + 4 * q + r) < B;
+      const float sv = s[r];
+      const float t = fmaxf(sv, 0.f) - beta;
+      lacc += ok ? t * t : 0.f;
+      gv[r] = (ok && sv > 0.f) ? coef * t : 0.f;
+    }
+    // ---- dE_i[f] += sum_j G[i][j] E_j[f]:  A = E_j^T (feature rows), B = G, k slot q at step r is j0+4q+r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float *er = g.e + (size_t)g.idx[min(B - 1, j0 + 4 * q + r)] * d + fbase + 4 * c;
+#pragma unroll
+      for (int G = 0; G < NG; ++G) {
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fbase + 64 * G + 4 * c < d) a4 = ld4(er + 64 * G);
+        acc[G][0] = mfma16l(a4.x, gv[r], acc[G][0]);
+        acc[G][1] = mfma16l(a4.y, gv[r], acc[G][1]);
+        acc[G][2] = mfma16l(a4.z, gv[r], acc[G][2]);
+        acc[G][3] = mfma16l(a4.w, gv[r], acc[G][3]);
+      }
+    }
+  }
+
+  // ---- tree-reduce the partial dE tiles of the 4 waves (fixed order)
+  for (int half = kLossWaves / 2; half >= 1; half >>= 1) {
+    if (w >= half && w < 2 * half) {
+      float4 *dst = red + (size_t)(w - half) * NG * 4 * 64;
+#pragma unroll
+      for (int G = 0; G < NG; ++G)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(G * 4 + e) * 64 + lane] = make_float4(acc[G][e][0], acc[G][e][1], acc[G][e][2], acc[G][e][3]);
+    }
+    __syncthreads();
+    if (w < half) {
+      const float4 *src = red + (size_t)w * NG * 4 * 64;
+#pragma unroll
+      for (int G = 0; G < NG; ++G)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float4 v = src[(G * 4 + e) * 64 + lane];
+          acc[G][e][0] += v.x;
+          acc[G][e][1] += v.y;
+          acc[G][e][2] += v.z;
+          acc[G][e][3] += v.w;
+        }
+    }
+    __syncthreads();
+  }
+  // tile (G, e), lane (c, q), reg r: node i0 + c, feature fbase + 64 G + 4 (4 q + r) + e
+  if (w == 0 && i_ok) {
+    float *out = g.de_part + ((size_t)blockIdx.y * B + (i0 + c)) * d;
+#pragma unroll
+    for (int G = 0; G < NG; ++G)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = fbase + 64 * G + 16 * q + 4 * r;
+        if (f < d) st4(out + f, make_float4(acc[G][0][r], acc[G][1][r], acc[G][2][r], acc[G][3][r]));
+      }
+  }
+  // ---- loss partial (only the z == 0 slab counts it)
+  const double ws = wave_sum_d((double)lacc);
+  if (lane == 0) lsum[w] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.z == 0) {
+    double t = 0.0;
+    for (int k = 0; k < kLossWaves; ++k) t += lsum[k];
+    g.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = t;
+  }
+}
+
+// de_b = 2 * sum_js de_part[js] ; loss = -alpha/2 / B^2 * sum(loss_part)
+__global__ __launch_bounds__(256) void loss_finish_kernel(int b, int d, int js, int nloss, const float *__restrict__ de_part,
+                                                           const double *__restrict__ loss_part, float alpha,
+                                                           float *__restrict__ de_b, float *__restrict__ loss_out) {
+  const size_t n4 = (size_t)b * d / 4;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) {
+    float4 s = ld4(de_part + i * 4);
+    for (int k = 1; k < js; ++k) s = add4(s, ld4(de_part + ((size_t)k * b * d) + i * 4));
+    st4(de_b + i * 4, scale4(2.f, s));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    double t = 0.0;
+    for (int k = threadIdx.x; k < nloss; k += 64) t += loss_part[k];
+    t = wave_sum_d(t);
+    if (threadIdx.x == 0) loss_out[0] = (float)(-0.5 * (double)alpha * t / ((double)b * (double)b));
+  }
+}
+
+static void loss_geometry(int32_t b, int32_t d, int &ni, int &js, int &nz, int &ng) {
+  ni = ceil_div(b, 16);
+  const int nj = ni;
+  js = ceil_div(512, ni);
+  const int js_max = ceil_div(nj, kLossWaves);
+  if (js > js_max) js = js_max;
+  if (js > 16) js = 16;
+  if (js < 1) js = 1;
+  const int groups = ceil_div(d, 64);
+  ng = groups <= 1 ? 1 : groups <= 2 ? 2 : groups <= 4 ? 4 : 8;
+  nz = ceil_div(groups, ng);
+}
+
+size_t loss_workspace_bytes(int32_t b, int32_t d) {
+  int ni, js, nz, ng;
+  loss_geometry(b, d, ni, js, nz, ng);
+  size_t de = sizeof(float) * (size_t)js * b * d;
+  de = (de + 15) / 16 * 16;
+  return de + sizeof(double) * (size_t)ni * js;
+}
+
+int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha,
+                 float *loss_out, float *de_b, void *ws, void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(n > 0 && b > 0 && e && idx && loss_out && de_b && ws, "loss_fwd_bwd: null operand or empty batch");
+  hipStream_t st = as_stream(stream);
+  int ni, js, nz, ng;
+  loss_geometry(b, d, ni, js, nz, ng);
+  size_t de_bytes = sizeof(float) * (size_t)js * b * d;
+  de_bytes = (de_bytes + 15) / 16 * 16;
+  LossArgs g{d, b, js, e, idx, beta, alpha, (float *)ws, (double *)((char *)ws + de_bytes)};
+  dim3 grid(ni, js, nz), block(64 * kLossWaves);
+  const size_t lds = (size_t)2 * ng * 4 * 64 * sizeof(float4);
+  switch (ng) {
+    case 1: hipLaunchKernelGGL((loss_fused_kernel<1>), grid, block, lds, st, g); break;
+    case 2: hipLaunchKernelGGL((loss_fused_kernel<2>), grid, block, lds, st, g); break;
+    case 4: hipLaunchKernelGGL((loss_fused_kernel<4>), grid, block, lds, st, g); break;
+    default: hipLaunchKernelGGL((loss_fused_kernel<8>), grid, block, lds, st, g); break;
+  }
+  GSS_LAUNCH_CHECK("loss_fused_kernel");
+  const int nb = ceil_div((int64_t)b * d / 4, 256);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, b, d, js, ni * js, g.de_part, g.loss_part,
+                     alpha, de_b, loss_out);
+  GSS_LAUNCH_CHECK("loss_finish_kernel");
+  return GSS_OK;
+}
+
+}  // namespace gss
+
+using namespace gss;
+extern "C" {
+size_t gss_loss_workspace_bytes(int32_t b, int32_t d) { return loss_workspace_bytes(b, d); }
+int gss_loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha,
+                     float *loss_out, float *de_b, void *ws, void *stream) {
+  return loss_fwd_bwd(n, d, e, idx, b, beta, alpha, loss_out, de_b, ws, stream);
+}
+}

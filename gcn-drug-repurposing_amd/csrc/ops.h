@@ -1,0 +1,38 @@
+// ops.h -- internal launchers shared between the per-op C entry points and the plan.
+#pragma once
+#include "common.h"
+
+struct gss_csr {
+  int32_t n_rows, n_cols;
+  int64_t nnz;
+  const int32_t *rowptr, *col;
+  const float *val;
+  int32_t n_long;
+  int32_t *d_long_rows;
+  int32_t max_row;
+};
+
+namespace gss {
+int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream);
+int spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
+              float *u, float *t, void *stream);
+int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
+              float *dp, float *gx_out, void *stream);
+int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
+              const float *b2, const float *p_prev, float decay, float *p, float *x_next, void *stream);
+int dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t, const float *w2t, const int32_t *rows,
+                    float *g_ax, float *g_am, void *stream);
+size_t wgrad_workspace_bytes(int32_t n, int32_t d);
+int dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, const float *am, const int32_t *rows,
+                     float *gw1, float *gw2, float *gb, int accumulate, void *ws, void *stream);
+int rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, void *stream);
+int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b, const float *e, const float *inv_den,
+                    const float *p, float c, float *dx_b, float *dp_b, void *stream);
+int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, void *stream);
+int adam_step(int64_t count, float *param, const float *grad, float *m, float *v, int32_t step, float lr, float beta1,
+              float beta2, float eps, float *wt, int32_t dim, void *stream);
+int transpose2(int32_t dim, const float *a, const float *b, float *at, float *bt, void *stream);
+size_t loss_workspace_bytes(int32_t b, int32_t d);
+int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha,
+                 float *loss_out, float *de_b, void *ws, void *stream);
+}  // namespace gss

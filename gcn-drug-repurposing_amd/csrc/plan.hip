@@ -1,0 +1,257 @@
+// plan.hip -- one training replica: owns every activation / gradient buffer and enqueues a whole
+// iteration of train.py:155-184 (forward, gss_loss, backward, Adam) from a single host call, so
+// the ~25 kernels of a step are launched back to back from C++ with no Python in between.
+//
+// Layer l (0-based) keeps x_l (input), AX_l, AM_l, P_l for the backward pass (model.py:163-173).
+// The backward pass exploits that dLoss/dE is non-zero only on the B batch rows: normalise-bwd,
+// ELU-bwd, the top layer's weight gradient and its input gradient run on B rows instead of N.
+#include <vector>
+
+#include "ops.h"
+
+struct gss_plan {
+  gss_plan_desc desc;
+  const gss_csr *a, *at;
+  const float *x;
+  float *w1, *b1, *w2, *b2;
+  // one slab, carved
+  char *slab;
+  size_t slab_bytes;
+  std::vector<float *> ax, am, p, xin;  // xin[l] = input of layer l (xin[0] = x)
+  float *m_tmp, *x_last, *emb, *inv_den;
+  float *g_ax, *g_am, *u, *t, *dp, *gx[2];
+  float *de_b, *dx_b, *dp_b;
+  float *w1t, *w2t;
+  float *grad[4];
+  float *adam_m[4], *adam_v[4];
+  float *loss;
+  void *loss_ws, *wgrad_ws;
+  int32_t step;
+  bool layer1_valid;
+};
+
+using namespace gss;
+
+namespace {
+struct Carver {
+  size_t off = 0;
+  char *base = nullptr;
+  template <typename T>
+  T *take(size_t count) {
+    off = (off + 255) / 256 * 256;
+    T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+    off += sizeof(T) * count;
+    return p;
+  }
+};
+
+void carve(gss_plan *p, Carver &c) {
+  const gss_plan_desc &D = p->desc;
+  const size_t nd = (size_t)D.n * D.d;
+  const size_t bd = (size_t)D.max_batch * D.d;
+  const int L = D.num_layers;
+  p->ax.assign(L, nullptr);
+  p->am.assign(L, nullptr);
+  p->p.assign(L, nullptr);
+  p->xin.assign(L, nullptr);
+  for (int l = 0; l < L; ++l) {
+    p->ax[l] = c.take<float>(nd);
+    p->am[l] = c.take<float>(nd);
+    p->p[l] = c.take<float>(nd);
+    p->xin[l] = l == 0 ? const_cast<float *>(p->x) : c.take<float>(nd);
+  }
+  p->m_tmp = c.take<float>(nd);
+  p->x_last = c.take<float>(nd);
+  p->inv_den = c.take<float>(D.n);
+  if (L > 1) {
+    p->g_ax = c.take<float>(nd);
+    p->g_am = c.take<float>(nd);
+    p->u = c.take<float>(nd);
+    p->t = c.take<float>(nd);
+    p->dp = c.take<float>(nd);
+    p->gx[0] = L > 2 ? c.take<float>(nd) : nullptr;
+    p->gx[1] = L > 2 ? c.take<float>(nd) : nullptr;
+  } else {
+    p->g_ax = p->g_am = p->u = p->t = p->dp = p->gx[0] = p->gx[1] = nullptr;
+  }
+  p->de_b = c.take<float>(bd);
+  p->dx_b = c.take<float>(bd);
+  p->dp_b = c.take<float>(bd);
+  p->w1t = c.take<float>((size_t)D.d * D.d);
+  p->w2t = c.take<float>((size_t)D.d * D.d);
+  const size_t cnt[4] = {(size_t)D.d * D.d, (size_t)D.d, (size_t)D.d * D.d, (size_t)D.d};
+  for (int k = 0; k < 4; ++k) {
+    p->adam_m[k] = c.take<float>(cnt[k]);
+    p->adam_v[k] = c.take<float>(cnt[k]);
+  }
+  p->loss_ws = c.take<char>(loss_workspace_bytes(D.max_batch, D.d));
+  const size_t wg_n = wgrad_workspace_bytes(D.n, D.d), wg_b = wgrad_workspace_bytes(D.max_batch, D.d);
+  p->wgrad_ws = c.take<char>(wg_n > wg_b ? wg_n : wg_b);
+}
+}  // namespace
+
+extern "C" {
+
+int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a, const gss_csr *at, const gss_plan_io *io) {
+  GSS_REQUIRE(out && desc && a && io, "plan_create: null argument");
+  GSS_REQUIRE(io->x && io->w1 && io->b1 && io->w2 && io->b2 && io->emb && io->loss && io->gw1 && io->gb1 && io->gw2 && io->gb2,
+              "plan_create: null pointer in gss_plan_io");
+  if (int rc = check_d(desc->d)) return rc;
+  GSS_REQUIRE(desc->n > 0 && desc->num_layers >= 1 && desc->num_layers <= 64, "plan_create: n=%d num_layers=%d", desc->n,
+              desc->num_layers);
+  GSS_REQUIRE(desc->max_batch >= 1 && desc->max_batch <= desc->n, "plan_create: max_batch=%d out of [1, n=%d]", desc->max_batch,
+              desc->n);
+  GSS_REQUIRE(a->n_rows == desc->n && a->n_cols == desc->n, "plan_create: A is %d x %d, expected %d x %d", a->n_rows, a->n_cols,
+              desc->n, desc->n);
+  GSS_REQUIRE(desc->num_layers == 1 || (at && at->n_rows == desc->n && at->n_cols == desc->n),
+              "plan_create: A^T missing or mis-shaped (needed for num_layers >= 2)");
+  gss_plan *p = new gss_plan();
+  p->desc = *desc;
+  p->a = a;
+  p->at = at;
+  p->x = io->x;
+  p->w1 = io->w1;
+  p->b1 = io->b1;
+  p->w2 = io->w2;
+  p->b2 = io->b2;
+  p->emb = io->emb;
+  p->loss = io->loss;
+  p->grad[0] = io->gw1;
+  p->grad[1] = io->gb1;
+  p->grad[2] = io->gw2;
+  p->grad[3] = io->gb2;
+  p->step = 0;
+  p->layer1_valid = false;
+  Carver sizing;
+  carve(p, sizing);
+  p->slab_bytes = sizing.off + 256;
+  hipError_t e = hipMalloc((void **)&p->slab, p->slab_bytes);
+  if (e != hipSuccess) {
+    const size_t want = p->slab_bytes;
+    delete p;
+    return fail(GSS_ENOMEM, "plan_create: hipMalloc(%zu bytes) -> %s", want, hipGetErrorString(e));
+  }
+  e = hipMemset(p->slab, 0, p->slab_bytes);
+  if (e != hipSuccess) {
+    (void)hipFree(p->slab);
+    delete p;
+    return fail(GSS_EHIP, "plan_create: hipMemset -> %s", hipGetErrorString(e));
+  }
+  Carver real;
+  real.base = p->slab;
+  carve(p, real);
+  *out = p;
+  return GSS_OK;
+}
+
+void gss_plan_destroy(gss_plan *p) {
+  if (!p) return;
+  if (p->slab) (void)hipFree(p->slab);
+  delete p;
+}
+
+int gss_plan_forward(gss_plan *p, void *stream) {
+  GSS_REQUIRE(p, "plan_forward: null plan");
+  const gss_plan_desc &D = p->desc;
+  const int L = D.num_layers;
+  for (int l = 0; l < L; ++l) {
+    const float *xl = p->xin[l];
+    const bool cached = (l == 0 && D.cache_layer1 && p->layer1_valid);
+    if (!cached) {
+      // AX = A x ; M = AX (.) x      (model.py:163,168)
+      if (int rc = spmm_fwd(p->a, D.d, xl, p->ax[l], xl, p->m_tmp, stream)) return rc;
+      // AM = A M                      (model.py:169)
+      if (int rc = spmm_fwd(p->a, D.d, p->m_tmp, p->am[l], nullptr, nullptr, stream)) return rc;
+      if (l == 0) p->layer1_valid = true;
+    }
+    float *xn = (l == L - 1) ? p->x_last : p->xin[l + 1];
+    if (int rc = dense_fwd(D.n, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr,
+                           D.layer_decay, p->p[l], xn, stream))
+      return rc;
+  }
+  return rownorm_fwd(D.n, D.d, p->x_last, p->emb, p->inv_den, stream);
+}
+
+int gss_plan_loss_backward(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
+  GSS_REQUIRE(p && idx, "plan_loss_backward: null argument");
+  const gss_plan_desc &D = p->desc;
+  GSS_REQUIRE(b >= 1 && b <= D.max_batch, "plan_loss_backward: batch %d out of [1, %d]", b, D.max_batch);
+  if (int rc = loss_fwd_bwd(D.n, D.d, p->emb, idx, b, beta, D.alpha, p->loss, p->de_b, p->loss_ws, stream)) return rc;
+  return gss_plan_backward(p, idx, b, nullptr, stream);
+}
+
+int gss_plan_backward(gss_plan *p, const int32_t *idx, int32_t b, const float *de_rows, void *stream) {
+  GSS_REQUIRE(p && idx, "plan_backward: null argument");
+  const gss_plan_desc &D = p->desc;
+  GSS_REQUIRE(b >= 1 && b <= D.max_batch, "plan_backward: %d rows out of [1, %d]", b, D.max_batch);
+  const int L = D.num_layers;
+  hipStream_t st = as_stream(stream);
+  const float *de_b = de_rows ? de_rows : p->de_b;
+  // top layer, batch rows only
+  const float c_top = L > 1 ? D.layer_decay : 1.f;
+  if (int rc = rownorm_elu_bwd(D.d, de_b, idx, b, p->emb, p->inv_den, p->p[L - 1], c_top, p->dx_b, p->dp_b, stream)) return rc;
+  if (int rc = dense_bwd_weight(b, D.d, p->dp_b, p->ax[L - 1], p->am[L - 1], idx, p->grad[0], p->grad[2], p->grad[1], 0,
+                                p->wgrad_ws, stream))
+    return rc;
+  if (L > 1) {
+    const size_t nd_bytes = sizeof(float) * (size_t)D.n * D.d;
+    if (int rc = transpose2(D.d, p->w1, p->w2, p->w1t, p->w2t, stream)) return rc;
+    GSS_HIP(hipMemsetAsync(p->g_ax, 0, nd_bytes, st));
+    GSS_HIP(hipMemsetAsync(p->g_am, 0, nd_bytes, st));
+    if (int rc = dense_bwd_input(b, D.d, p->dp_b, p->w1t, p->w2t, idx, p->g_ax, p->g_am, stream)) return rc;
+    if (int rc = spmm_bwd1(p->at, D.d, p->g_am, p->g_ax, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream)) return rc;
+    for (int lp = L - 2; lp >= 0; --lp) {
+      const float c = lp == 0 ? 1.f : D.layer_decay;
+      const float *res = (lp + 2 <= L - 1) ? p->gx[(lp + 2) & 1] : nullptr;
+      float *gx_out = (lp >= 1 && L > 2) ? p->gx[(lp + 1) & 1] : nullptr;
+      if (int rc = spmm_bwd2(p->at, D.d, p->u, p->t, p->p[lp], c, res, p->dp, gx_out, stream)) return rc;
+      if (lp + 2 == L)
+        if (int rc = scatter_add_rows(D.d, p->dx_b, idx, b, p->dp, stream)) return rc;
+      if (int rc = dense_bwd_weight(D.n, D.d, p->dp, p->ax[lp], p->am[lp], nullptr, p->grad[0], p->grad[2], p->grad[1], 1,
+                                    p->wgrad_ws, stream))
+        return rc;
+      if (lp >= 1) {
+        if (int rc = dense_bwd_input(D.n, D.d, p->dp, p->w1t, p->w2t, nullptr, p->g_ax, p->g_am, stream)) return rc;
+        if (int rc = spmm_bwd1(p->at, D.d, p->g_am, p->g_ax, p->xin[lp], p->ax[lp], p->u, p->t, stream)) return rc;
+      }
+    }
+  }
+  // b1 and b2 enter the sum p = ... + b1 + ... + b2 symmetrically: same gradient (model.py:165,170,172)
+  GSS_HIP(hipMemcpyAsync(p->grad[3], p->grad[1], sizeof(float) * D.d, hipMemcpyDeviceToDevice, st));
+  return GSS_OK;
+}
+
+int gss_plan_adam(gss_plan *p, void *stream) {
+  GSS_REQUIRE(p, "plan_adam: null plan");
+  const gss_plan_desc &D = p->desc;
+  p->step += 1;
+  float *params[4] = {p->w1, p->b1, p->w2, p->b2};
+  const int64_t cnt[4] = {(int64_t)D.d * D.d, D.d, (int64_t)D.d * D.d, D.d};
+  for (int k = 0; k < 4; ++k)
+    if (int rc = adam_step(cnt[k], params[k], p->grad[k], p->adam_m[k], p->adam_v[k], p->step, D.lr, D.beta1, D.beta2, D.eps,
+                           nullptr, 0, stream))
+      return rc;
+  return GSS_OK;
+}
+
+int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
+  if (int rc = gss_plan_forward(p, stream)) return rc;
+  if (int rc = gss_plan_loss_backward(p, idx, b, beta, stream)) return rc;
+  return gss_plan_adam(p, stream);
+}
+
+const float *gss_plan_activation(const gss_plan *p, int layer, int which) {
+  if (!p || layer < 0 || layer >= p->desc.num_layers) return nullptr;
+  return which == 0 ? p->ax[layer] : which == 1 ? p->am[layer] : which == 2 ? p->p[layer] : nullptr;
+}
+size_t gss_plan_device_bytes(const gss_plan *p) { return p ? p->slab_bytes : 0; }
+void gss_plan_set_step(gss_plan *p, int32_t step) {
+  if (p) p->step = step;
+}
+int32_t gss_plan_get_step(const gss_plan *p) { return p ? p->step : 0; }
+int gss_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream) {
+  GSS_REQUIRE(dst && src, "memcpy_d2d: null pointer");
+  GSS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+  return GSS_OK;
+}
+}

@@ -1,0 +1,365 @@
+// spmm.hip -- CSR SpMM  Y = A X  for the GSS layer (K1/K2/K9 of SURVEY.md section 2b).
+//
+// Replaces torch.sparse.mm at modules/model.py:163,169 (and its autograd for layers >= 2).
+//
+// Mapping (wave64): one wave owns one output row.  A feature row of d floats is d/4 float4s; a row
+// vector is covered by LPR = min(64, pow2ceil(d/4)) lanes, so a wave gathers EP = 64/LPR neighbour
+// rows per load instruction (d=128: two 512-B rows per global_load_dwordx4).  The wave first loads 64
+// (col,val) pairs with one coalesced load each, then broadcasts them lane-group-wise with
+// ds_bpermute while the gathers of an unrolled group are in flight.  Edge-slot partial sums are
+// combined with xor-shuffles at the end (fixed order -> bitwise reproducible).  Rows longer than
+// kLongRow edges are skipped here and handled by spmm_long_kernel with a whole 1024-thread
+// workgroup per row (LDS reduction in wave order).  The Hadamard / backward elementwise work that
+// the reference does in separate torch ops is fused into the row epilogue.
+//
+// Roofline: HBM-bound.  Algorithmic bytes per launch = 8 nnz + 4 (N+1) + 4 N d (X once) + 4 N d (Y),
+// plus 4 N d per extra epilogue operand/output.
+#include "ops.h"
+
+namespace gss {
+
+constexpr int kLongRow = 512;   // rows with more stored entries go to the long-row kernel
+constexpr int kRowsPerBlock = 16;
+constexpr int kLongThreads = 1024;
+
+enum SpmmMode { SPMM_PLAIN = 0, SPMM_FWD1 = 1, SPMM_BWD1 = 2, SPMM_BWD2 = 3 };
+
+struct SpmmEpi {
+  const float *a0, *a1, *a2;
+  float *o0, *o1;
+  float c;
+};
+
+struct CsrView {
+  const int32_t *rowptr, *col;
+  const float *val;
+  int32_t n_rows;
+};
+
+// accumulate sum_e val[e] * X[col[e]] over edges [e0, e1) for this wave.  On return every lane with
+// li < d4 (VPL chunks) holds the full sum for its float4 column(s).
+template <int LPR_LOG2, int VPL>
+__device__ __forceinline__ void row_accumulate(const CsrView &a, const float *__restrict__ x, int d4, int e0, int e1,
+                                               int lane, float4 (&acc)[VPL]) {
+  constexpr int LPR = 1 << LPR_LOG2;
+  constexpr int EP = 64 / LPR;
+  constexpr int UNROLL = (EP >= 16) ? 4 : (64 / EP >= 8 ? 8 : 64 / EP);  // EP*UNROLL divides 64
+  const int g = lane >> LPR_LOG2;
+  const int li = lane & (LPR - 1);
+  const bool col_ok = (VPL > 1) || (li < d4);
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t rowstride = (size_t)d4 * 4;
+  for (int base = e0; base < e1; base += 64) {
+    const int ce = base + lane;
+    int c = 0;
+    float w = 0.f;
+    if (ce < e1) {
+      c = a.col[ce];
+      w = a.val[ce];
+    }
+    const int cnt = min(64, e1 - base);
+    for (int t = 0; t < cnt; t += EP * UNROLL) {
+      float4 xv[UNROLL][VPL];
+      float wv[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int src = t + u * EP + g;
+        const int cc = __shfl(c, src, 64);
+        wv[u] = __shfl(w, src, 64);
+        const bool ok = (src < cnt) && col_ok;
+        if (!ok) wv[u] = 0.f;
+        const float *xr = x + (size_t)cc * rowstride;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int f4 = li + v * 64;
+          xv[u][v] = (ok && (VPL == 1 || f4 < d4)) ? ld4(xr + (size_t)f4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) acc[v] = fma4(wv[u], xv[u][v], acc[v]);
+    }
+  }
+  // combine the EP edge slots
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      acc[v].x += __shfl_xor(acc[v].x, o, 64);
+      acc[v].y += __shfl_xor(acc[v].y, o, 64);
+      acc[v].z += __shfl_xor(acc[v].z, o, 64);
+      acc[v].w += __shfl_xor(acc[v].w, o, 64);
+    }
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void row_epilogue(const SpmmEpi &ep, size_t off, float4 acc) {
+  if (MODE == SPMM_PLAIN) {
+    st4(ep.o0 + off, acc);
+  } else if (MODE == SPMM_FWD1) {
+    st4(ep.o0 + off, acc);
+    st4(ep.o1 + off, mul4(acc, ld4(ep.a0 + off)));
+  } else if (MODE == SPMM_BWD1) {
+    // u = g_ax + dm (.) x_in ; t = dm (.) ax
+    st4(ep.o0 + off, add4(ld4(ep.a0 + off), mul4(acc, ld4(ep.a1 + off))));
+    st4(ep.o1 + off, mul4(acc, ld4(ep.a2 + off)));
+  } else {
+    // gx = t + A u ; dp = c * gx (.) elu'(p) (+ res)
+    const float4 gx = add4(ld4(ep.a0 + off), acc);
+    float4 dp = scale4(ep.c, mul4(gx, elu_grad4(ld4(ep.a1 + off))));
+    if (ep.a2) dp = add4(dp, ld4(ep.a2 + off));
+    st4(ep.o0 + off, dp);
+    if (ep.o1) st4(ep.o1 + off, gx);
+  }
+}
+
+template <int MODE, int LPR_LOG2, int VPL>
+__global__ __launch_bounds__(256) void spmm_rows_kernel(CsrView a, int d4, const float *__restrict__ x, SpmmEpi ep, int nblk) {
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int bid = xcd_remap(blockIdx.x, nblk);
+  constexpr int LPR = 1 << LPR_LOG2;
+  const int g = lane >> LPR_LOG2;
+  const int li = lane & (LPR - 1);
+  const int row_end = min(a.n_rows, (bid + 1) * kRowsPerBlock);
+  for (int row = bid * kRowsPerBlock + wib; row < row_end; row += 4) {
+    const int e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
+    if (e1 - e0 > kLongRow) continue;  // owned by spmm_long_kernel
+    float4 acc[VPL];
+    row_accumulate<LPR_LOG2, VPL>(a, x, d4, e0, e1, lane, acc);
+    if (g == 0) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const int f4 = li + v * 64;
+        if (f4 < d4) row_epilogue<MODE>(ep, ((size_t)row * d4 + f4) * 4, acc[v]);
+      }
+    }
+  }
+}
+
+// one workgroup (16 waves) per long row: waves take 64-aligned slices of the edge range, partial
+// sums meet in LDS and are added in wave order.
+template <int MODE, int LPR_LOG2, int VPL>
+__global__ __launch_bounds__(kLongThreads) void spmm_long_kernel(CsrView a, const int32_t *__restrict__ long_rows, int d4,
+                                                                  const float *__restrict__ x, SpmmEpi ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *part = reinterpret_cast<float4 *>(smem);  // [16][d4]
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  constexpr int NW = kLongThreads / 64;
+  constexpr int LPR = 1 << LPR_LOG2;
+  const int g = lane >> LPR_LOG2;
+  const int li = lane & (LPR - 1);
+  const int row = long_rows[blockIdx.x];
+  const int e0 = a.rowptr[row], e1 = a.rowptr[row + 1];
+  const int chunks = (e1 - e0 + 63) / 64;
+  const int per = (chunks + NW - 1) / NW;
+  const int s0 = min(e1, e0 + wib * per * 64), s1 = min(e1, e0 + (wib + 1) * per * 64);
+  float4 acc[VPL];
+  row_accumulate<LPR_LOG2, VPL>(a, x, d4, s0, s1, lane, acc);
+  if (g == 0) {
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int f4 = li + v * 64;
+      if (f4 < d4) part[wib * d4 + f4] = acc[v];
+    }
+  }
+  __syncthreads();
+  for (int f4 = threadIdx.x; f4 < d4; f4 += kLongThreads) {
+    float4 s = part[f4];
+    for (int w = 1; w < NW; ++w) s = add4(s, part[w * d4 + f4]);
+    row_epilogue<MODE>(ep, ((size_t)row * d4 + f4) * 4, s);
+  }
+}
+
+template <int MODE, int LPR_LOG2, int VPL>
+static int launch_spmm_t(const gss_csr *a, int d4, const float *x, const SpmmEpi &ep, hipStream_t st);
+
+}  // namespace gss
+
+
+namespace gss {
+
+template <int MODE, int LPR_LOG2, int VPL>
+static int launch_spmm_t(const gss_csr *a, int d4, const float *x, const SpmmEpi &ep, hipStream_t st) {
+  CsrView v{a->rowptr, a->col, a->val, a->n_rows};
+  const int nblk = ceil_div(a->n_rows, kRowsPerBlock);
+  if (nblk > 0) {
+    hipLaunchKernelGGL((spmm_rows_kernel<MODE, LPR_LOG2, VPL>), dim3(nblk), dim3(256), 0, st, v, d4, x, ep, nblk);
+    GSS_LAUNCH_CHECK("spmm_rows_kernel");
+  }
+  if (a->n_long > 0) {
+    const size_t lds = (size_t)(kLongThreads / 64) * d4 * sizeof(float4);
+    hipLaunchKernelGGL((spmm_long_kernel<MODE, LPR_LOG2, VPL>), dim3(a->n_long), dim3(kLongThreads), lds, st, v,
+                       a->d_long_rows, d4, x, ep);
+    GSS_LAUNCH_CHECK("spmm_long_kernel");
+  }
+  return GSS_OK;
+}
+
+template <int MODE>
+static int launch_spmm(const gss_csr *a, int32_t d, const float *x, const SpmmEpi &ep, void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(a && x, "spmm: null operand");
+  hipStream_t st = as_stream(stream);
+  const int d4 = d / 4;
+  if (d4 <= 4) return launch_spmm_t<MODE, 2, 1>(a, d4, x, ep, st);
+  if (d4 <= 8) return launch_spmm_t<MODE, 3, 1>(a, d4, x, ep, st);
+  if (d4 <= 16) return launch_spmm_t<MODE, 4, 1>(a, d4, x, ep, st);
+  if (d4 <= 32) return launch_spmm_t<MODE, 5, 1>(a, d4, x, ep, st);
+  if (d4 <= 64) return launch_spmm_t<MODE, 6, 1>(a, d4, x, ep, st);
+  if (d4 <= 128) return launch_spmm_t<MODE, 6, 2>(a, d4, x, ep, st);
+  return launch_spmm_t<MODE, 6, 4>(a, d4, x, ep, st);
+}
+
+// internal entry points shared with plan.hip
+int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream) {
+  GSS_REQUIRE(y, "spmm: y is null");
+  if (m) {
+    GSS_REQUIRE(h, "spmm: m given without h");
+    SpmmEpi ep{h, nullptr, nullptr, y, m, 0.f};
+    return launch_spmm<SPMM_FWD1>(a, d, x, ep, stream);
+  }
+  SpmmEpi ep{nullptr, nullptr, nullptr, y, nullptr, 0.f};
+  return launch_spmm<SPMM_PLAIN>(a, d, x, ep, stream);
+}
+
+int spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
+              float *u, float *t, void *stream) {
+  GSS_REQUIRE(g_am && g_ax && x_in && ax && u && t, "spmm_bwd1: null operand");
+  SpmmEpi ep{g_ax, x_in, ax, u, t, 0.f};
+  return launch_spmm<SPMM_BWD1>(at, d, g_am, ep, stream);
+}
+
+int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
+              float *dp, float *gx_out, void *stream) {
+  GSS_REQUIRE(u && t && p && dp, "spmm_bwd2: null operand");
+  SpmmEpi ep{t, p, res, dp, gx_out, c};
+  return launch_spmm<SPMM_BWD2>(at, d, u, ep, stream);
+}
+
+// ---- K11 normalize_adj ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowsum_kernel(int n, const int32_t *__restrict__ rowptr, const double *__restrict__ val,
+                                                     double *__restrict__ dinv, double *__restrict__ rowsum) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int e0 = rowptr[row], e1 = rowptr[row + 1];
+  double s = 0.0;
+  for (int e = e0 + lane; e < e1; e += 64) s += val[e];
+  s = wave_sum_d(s);
+  if (lane == 0) {
+    dinv[row] = pow(s, -0.5);  // np.power(rowsum, -0.5), helper.py:85
+    if (rowsum) rowsum[row] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                    const double *__restrict__ val, const double *__restrict__ dinv,
+                                                    float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int e0 = rowptr[row], e1 = rowptr[row + 1];
+  const double di = dinv[row];
+  // (A_ D^-1/2)^T D^-1/2 ^T : column scale first, then row scale (helper.py:86-87)
+  for (int e = e0 + lane; e < e1; e += 64) out[e] = (float)((val[e] * dinv[col[e]]) * di);
+}
+
+}  // namespace gss
+
+using namespace gss;
+
+extern "C" {
+
+int gss_normalize_adj(int32_t n, const int32_t *rowptr, const int32_t *col, const double *val, float *val_out,
+                      double *rowsum_out, void *stream) {
+  GSS_REQUIRE(n >= 0 && rowptr && col && val && val_out, "normalize_adj: null operand");
+  if (n == 0) return GSS_OK;
+  hipStream_t st = as_stream(stream);
+  double *dinv = nullptr;
+  GSS_HIP(hipMallocAsync((void **)&dinv, sizeof(double) * (size_t)n, st));
+  const int nblk = ceil_div(n, 4);
+  hipLaunchKernelGGL(rowsum_kernel, dim3(nblk), dim3(256), 0, st, n, rowptr, val, dinv, rowsum_out);
+  GSS_LAUNCH_CHECK("rowsum_kernel");
+  hipLaunchKernelGGL(scale_kernel, dim3(nblk), dim3(256), 0, st, n, rowptr, col, val, dinv, val_out);
+  GSS_LAUNCH_CHECK("scale_kernel");
+  GSS_HIP(hipFreeAsync(dinv, st));
+  return GSS_OK;
+}
+
+int gss_csr_create(gss_csr **out, int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *h_rowptr,
+                   const int32_t *d_rowptr, const int32_t *d_col, const float *d_val) {
+  GSS_REQUIRE(out && h_rowptr && d_rowptr && (nnz == 0 || (d_col && d_val)), "csr_create: null operand");
+  GSS_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && nnz < (int64_t)INT32_MAX, "csr_create: bad sizes n_rows=%d n_cols=%d nnz=%lld",
+              n_rows, n_cols, (long long)nnz);
+  GSS_REQUIRE(h_rowptr[0] == 0 && (int64_t)h_rowptr[n_rows] == nnz, "csr_create: rowptr[0]=%d rowptr[n]=%d do not match nnz=%lld",
+              h_rowptr[0], h_rowptr[n_rows], (long long)nnz);
+  gss_csr *a = new gss_csr();
+  a->n_rows = n_rows;
+  a->n_cols = n_cols;
+  a->nnz = nnz;
+  a->rowptr = d_rowptr;
+  a->col = d_col;
+  a->val = d_val;
+  a->n_long = 0;
+  a->d_long_rows = nullptr;
+  a->max_row = 0;
+  int32_t *h_long = nullptr;
+  int n_long = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    n_long = 0;
+    for (int32_t r = 0; r < n_rows; ++r) {
+      const int32_t len = h_rowptr[r + 1] - h_rowptr[r];
+      if (len < 0) {
+        delete[] h_long;
+        delete a;
+        return fail(GSS_EINVAL, "csr_create: rowptr not monotone at row %d", r);
+      }
+      if (len > a->max_row) a->max_row = len;
+      if (len > kLongRow) {
+        if (pass == 1) h_long[n_long] = r;
+        ++n_long;
+      }
+    }
+    if (pass == 0) {
+      if (n_long == 0) break;
+      h_long = new int32_t[n_long];
+    }
+  }
+  if (n_long > 0) {
+    hipError_t e = hipMalloc((void **)&a->d_long_rows, sizeof(int32_t) * (size_t)n_long);
+    if (e == hipSuccess) e = hipMemcpy(a->d_long_rows, h_long, sizeof(int32_t) * (size_t)n_long, hipMemcpyHostToDevice);
+    delete[] h_long;
+    if (e != hipSuccess) {
+      if (a->d_long_rows) (void)hipFree(a->d_long_rows);
+      delete a;
+      return fail(GSS_ENOMEM, "csr_create: long-row list: %s", hipGetErrorString(e));
+    }
+    a->n_long = n_long;
+  }
+  *out = a;
+  return GSS_OK;
+}
+
+void gss_csr_destroy(gss_csr *a) {
+  if (!a) return;
+  if (a->d_long_rows) (void)hipFree(a->d_long_rows);
+  delete a;
+}
+
+int gss_spmm(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream) {
+  return spmm_fwd(a, d, x, y, h, m, stream);
+}
+int gss_spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
+                  float *u, float *t, void *stream) {
+  return spmm_bwd1(at, d, g_am, g_ax, x_in, ax, u, t, stream);
+}
+int gss_spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
+                  float *dp, float *gx_out, void *stream) {
+  return spmm_bwd2(at, d, u, t, p, c, res, dp, gx_out, stream);
+}
+}

@@ -1,0 +1,97 @@
+"""GssEngine: Python owner of one gss_plan (include/gssgcn.h) -- one training replica on one GPU.
+
+torch tensors are only the containers: parameters, embeddings, loss and gradients live in torch
+allocations whose device pointers are handed to the plan once; every arithmetic step is a HIP kernel
+enqueued by libgssgcn.so on torch's current stream."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .graph import GssGraph
+
+PARAM_NAMES = ("W1", "b1", "W2", "b2")
+
+
+class GssEngine:
+    def __init__(self, graph: GssGraph, x: torch.Tensor, params, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4,
+                 max_batch=None, cache_layer1=False, betas=(0.9, 0.999), eps=1e-8):
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+        n, d = x.shape
+        assert n == graph.n, f"features have {n} rows, graph has {graph.n} nodes"
+        if num_layers > 1 and graph.at is None:
+            raise ValueError("num_layers >= 2 needs the transposed CSR (GssGraph(need_transpose=True))")
+        self.graph, self.x = graph, x
+        self.n, self.d, self.num_layers = n, d, int(num_layers)
+        self.max_batch = int(max_batch or n)
+        self.params = list(params)
+        shapes = [(d, d), (d,), (d, d), (d,)]
+        for p, s in zip(self.params, shapes):
+            assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and tuple(p.shape) == s, (p.shape, s)
+        dev = x.device
+        self.emb = torch.empty(n, d, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.grads = [torch.zeros(s, dtype=torch.float32, device=dev) for s in shapes]
+        self.lib = _lib.load()
+        self.desc = _lib.PlanDesc(n, d, self.num_layers, self.max_batch, float(layer_decay), float(alpha), float(lr),
+                                  float(betas[0]), float(betas[1]), float(eps), 1 if cache_layer1 else 0)
+        io = _lib.PlanIO(x.data_ptr(), *[p.data_ptr() for p in self.params], self.emb.data_ptr(), self.loss.data_ptr(),
+                         *[g.data_ptr() for g in self.grads])
+        self._param_ptrs = [p.data_ptr() for p in self.params]
+        h = C.c_void_p()
+        _lib.check(self.lib.gss_plan_create(C.byref(h), C.byref(self.desc), graph.a.handle,
+                                            graph.at.handle if graph.at is not None else None, C.byref(io)), "gss_plan_create")
+        self.handle = h
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            self.lib.gss_plan_destroy(h)
+            self.handle = None
+
+    def params_moved(self):
+        return [p.data_ptr() for p in self.params] != self._param_ptrs
+
+    # -- the four phases of train.py:158-184 -------------------------------------------------------
+    def forward(self):
+        _lib.check(self.lib.gss_plan_forward(self.handle, _lib.current_stream()), "gss_plan_forward")
+        return self.emb
+
+    def loss_backward(self, idx32: torch.Tensor, beta: float, count=None, offset=0):
+        b = int(count if count is not None else idx32.numel())
+        _lib.check(self.lib.gss_plan_loss_backward(self.handle, idx32.data_ptr() + 4 * offset, b, float(beta),
+                                                   _lib.current_stream()), "gss_plan_loss_backward")
+
+    def backward(self, rows32: torch.Tensor, de_rows: torch.Tensor):
+        assert de_rows.is_contiguous() and de_rows.dtype == torch.float32
+        _lib.check(self.lib.gss_plan_backward(self.handle, rows32.data_ptr(), int(rows32.numel()), de_rows.data_ptr(),
+                                              _lib.current_stream()), "gss_plan_backward")
+
+    def adam(self):
+        _lib.check(self.lib.gss_plan_adam(self.handle, _lib.current_stream()), "gss_plan_adam")
+
+    def step(self, idx32: torch.Tensor, beta: float, count=None, offset=0):
+        b = int(count if count is not None else idx32.numel())
+        _lib.check(self.lib.gss_plan_step(self.handle, idx32.data_ptr() + 4 * offset, b, float(beta), _lib.current_stream()),
+                   "gss_plan_step")
+
+    def percentile(self, q: float) -> float:
+        """beta = np.percentile(E E^T, q) of the current embeddings (train.py:165-167), exact, on device."""
+        out = C.c_float()
+        _lib.check(self.lib.gss_percentile(self.n, self.d, self.emb.data_ptr(), float(q), C.byref(out), _lib.current_stream()),
+                   "gss_percentile")
+        return float(out.value)
+
+    def activation(self, layer: int, which: str) -> torch.Tensor:
+        """copy of AX / AM / P of a layer (parity tests)"""
+        src = self.lib.gss_plan_activation(self.handle, layer, {"AX": 0, "AM": 1, "P": 2}[which])
+        assert src, (layer, which)
+        out = torch.empty(self.n, self.d, dtype=torch.float32, device=self.x.device)
+        _lib.check(self.lib.gss_memcpy_d2d(out.data_ptr(), src, out.numel() * 4, _lib.current_stream()), "gss_memcpy_d2d")
+        return out
+
+    def device_bytes(self) -> int:
+        return int(self.lib.gss_plan_device_bytes(self.handle))

@@ -1,0 +1,168 @@
+"""The train.py entry point of the reference (train.py:12-193), same flags, same files, HIP inside.
+
+    python train.py --emb-file F --num-layers 2 --hidden-units 128 --k 5 --kq 5 --epochs 20 --lr 0.0003 \\
+                    --graph-mode descriptor --beta-percentile 98 --batch-size 2048
+
+reads F ('.embs.txt'), trains the GSS graph-convolution embedding and writes ./graph_embs.txt.
+Flags the reference parses but never uses (--dataset, --data-path, --report-hard, --regularizer-scale, --kq)
+are accepted and ignored.  New optional flags: --adj-file (weighted edgelist / .sif adjacency instead of the
+kNN graph), --out, --cache-layer1, --batch-file (replay recorded batches), --log-loss.
+"""
+from __future__ import annotations
+
+import argparse
+import time
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from . import embio
+from .engine import GssEngine
+from .graph import GssGraph, edgelist_adj, knn_descriptor_adj
+from .model import ResidualGraphConvolutionalNetwork
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="GSS-GCN embedding trainer on MI355X (train.py of gcn-drug-repurposing)")
+    p.add_argument('--kq', type=int, default=5, help='Top k number for the query graph (unused, as in the reference).')
+    p.add_argument('--k', type=int, default=5, help='Top k number for the index graph.')
+    p.add_argument('--alpha', type=float, default=1, help='Parameter alpha for gss loss.')
+    p.add_argument('--beta', type=float, default=None, help='Parameter beta for gss loss.')
+    p.add_argument('--beta-percentile', type=float, default=None,
+                   help="Select beta by the percentile of the similarity matrix's distribution.")
+    p.add_argument('--seed', type=int, default=None, help='Random seed.')
+    p.add_argument('--epochs', type=int, default=200, help='Number of epochs to train.')
+    p.add_argument('--batch-size', type=int, default=0, help='Batch size; 0 trains on all samples at once.')
+    p.add_argument('--hidden-units', type=int, default=128, help='Number of units in hidden layer')
+    p.add_argument('--num-layers', type=int, default=2, help='Number of layers')
+    p.add_argument('--loss', type=str, default='gss', help='Loss type (only gss is live in the reference).')
+    p.add_argument('--lr', type=float, default=0.0001, help='Learning rate.')
+    p.add_argument('--init-weights', type=float, default=1e-5, help='Std of the off-diagonal weight init (epsilon).')
+    p.add_argument('--regularizer-scale', type=float, default=1e-5, help='(unused)')
+    p.add_argument('--layer-decay', type=float, default=0.3, help='Residual GCN layer decay.')
+    p.add_argument('--dataset', type=str, default='roxford5k', help='(unused)')
+    p.add_argument('--emb-file', type=str, default=None, help='embedding file name.')
+    p.add_argument('--data-path', type=str, default=None, help='(unused)')
+    p.add_argument('--gpu-id', type=int, default=None, help='Which GPU to use (default: LOCAL_RANK or 0).')
+    p.add_argument('--report-hard', action='store_true', help='(unused)')
+    p.add_argument('--graph-mode', type=str, default='descriptor', choices=['descriptor', 'ransac', 'approx_ransac'])
+    # additions
+    p.add_argument('--adj-file', type=str, default=None,
+                   help="weighted edgelist ('u v w') or .sif adjacency over the nodes of --emb-file; replaces the kNN graph")
+    p.add_argument('--out', type=str, default='graph_embs.txt', help='output file (reference: ./graph_embs.txt)')
+    p.add_argument('--cache-layer1', action='store_true', help="keep layer 1's two SpMM results across steps (inputs are constant)")
+    p.add_argument('--batch-file', type=str, default=None, help='.npz with batches/batch_sizes to replay instead of sampling')
+    p.add_argument('--log-loss', action='store_true', help='print the last loss of every epoch')
+    return p
+
+
+class _IndexDataset(Dataset):
+    """item == index (method/dataset.py:5-23)"""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return i
+
+
+def epoch_batches(loader):
+    """One epoch of the reference sampler (method/dataset.py:25-28, train.py:127-131): a shuffled
+    DataLoader over node ids.  Drawn from torch's global RNG exactly like the reference, so the same
+    --seed gives the same batches."""
+    return [b for b in loader]
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    for key in vars(args):
+        print(key + ":" + str(vars(args)[key]))
+    if args.beta is not None and args.beta_percentile is not None:
+        raise Exception('beta and beta_percentile can not be used at the same time!')
+    if args.beta is None and args.beta_percentile is None:
+        raise Exception('At least one of beta and beta_percentile should be set!')
+    if args.loss != 'gss':
+        raise Exception("only --loss gss is supported (tri_loss is dead code in the reference, modules/model.py:223-240)")
+    if args.graph_mode != 'descriptor':
+        raise Exception("--graph-mode ransac/approx_ransac need the image-retrieval RANSAC graphs the reference never ships")
+    if not torch.cuda.is_available():
+        raise RuntimeError("no GPU visible: this trainer has no CPU path (the reference's CPU path is the oracle, not the product)")
+    dev = torch.device('cuda', args.gpu_id if args.gpu_id is not None else 0)
+    torch.cuda.set_device(dev)
+
+    if args.seed:                       # seed 0 / None leaves the RNGs unseeded, like train.py:74-76
+        torch.manual_seed(args.seed)
+        np.random.seed(args.seed)
+
+    names, X = embio.read_embs(args.emb_file)                 # train.py:79-81
+    n, d = X.shape
+    if d != args.hidden_units:
+        raise Exception(f"--hidden-units {args.hidden_units} must equal the embedding width {d} (modules/model.py:142)")
+
+    t0 = time.time()
+    if args.adj_file:
+        src, dst, w, _ = embio.read_edgelist(args.adj_file, names)
+        adj = edgelist_adj(src, dst, w, n)
+    else:
+        adj = knn_descriptor_adj(X, args.k)                   # train.py:93 -> helper.py:39-53
+    graph = GssGraph(adj, device=dev, need_transpose=args.num_layers > 1)   # train.py:100-101
+    print('Created G with [k={}] [shape=[{}, {}]] [nnz(A_hat)={}] in {:.2f}s'.format(args.k, n, n, graph.nnz, time.time() - t0))
+
+    bsz = args.batch_size if args.batch_size > 0 else n
+    model = ResidualGraphConvolutionalNetwork(train_batch_size=bsz, val_batch_size=n, num_layers=args.num_layers,
+                                              hidden_units=args.hidden_units, init_weights=args.init_weights,
+                                              layer_decay=args.layer_decay).to(dev)   # train.py:111-121
+    feats = torch.tensor(X, dtype=torch.float32).to(dev)      # method/dataset.py:13
+    params = [p.data for p in model._params()]
+    engine = GssEngine(graph, feats, params, num_layers=args.num_layers, layer_decay=args.layer_decay, alpha=args.alpha,
+                       lr=args.lr, max_batch=min(bsz, n), cache_layer1=args.cache_layer1)
+    loader = DataLoader(_IndexDataset(n), batch_size=bsz, shuffle=True, num_workers=0, drop_last=False)
+
+    replay = None
+    if args.batch_file:
+        z = np.load(args.batch_file)
+        offs = np.concatenate([[0], np.cumsum(z['batch_sizes'])])
+        replay = [z['batches'][offs[i]:offs[i + 1]] for i in range(len(z['batch_sizes']))]
+    steps_per_epoch = (n + bsz - 1) // bsz
+
+    beta_score = args.beta
+    itr = 0
+    step_no = 0
+    while itr < args.epochs:                                  # train.py:151
+        start_time = time.time()
+        if replay is not None:
+            batches = [torch.as_tensor(b) for b in replay[itr * steps_per_epoch:(itr + 1) * steps_per_epoch]]
+        else:
+            batches = epoch_batches(loader)
+        sizes = [int(b.numel()) for b in batches]
+        idx32 = torch.cat(batches).to(torch.int32).to(dev)
+        off = 0
+        for batch_id, b in enumerate(sizes):
+            if itr == 0 and batch_id == 0:
+                engine.forward()                              # train.py:158-161
+                if args.beta_percentile is not None:
+                    beta_score = engine.percentile(args.beta_percentile)   # train.py:165-167
+                    print(f"beta:{beta_score}")
+                engine.loss_backward(idx32, beta_score, count=b, offset=off)   # train.py:175,183
+                engine.adam()                                 # train.py:184
+            else:
+                engine.step(idx32, beta_score, count=b, offset=off)
+            off += b
+            step_no += 1
+        itr += 1
+        if args.log_loss:
+            print(f"iter {itr} loss {float(engine.loss.item()):.8f} time {time.time() - start_time:.4f}s")
+        else:
+            print(f"iter {itr}")
+    torch.cuda.synchronize()
+    # embeddings of the last forward, i.e. before the last optimizer step (train.py:158,193)
+    embio.write_graph_embs(args.out, engine.emb.cpu().numpy())
+    return engine
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,171 @@
+/*
+ * gssgcn.h -- C ABI of libgssgcn.so, the MI355X (gfx950) implementation of the GSS-GCN
+ * training hot path of bowang-lab/gcn-drug-repurposing.
+ *
+ * The reference has no native code: its hot path is a sequence of torch calls.  Each entry
+ * point below replaces the torch call(s) named in its comment (file:line relative to the
+ * reference root).  A reference maintainer binds these with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless its name starts with h_
+ *   - matrices are dense row-major fp32 [rows][d]; CSR uses int32 rowptr/col and fp32 values
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
+ *     asynchronous on it and never synchronise the device
+ *   - return 0 on success, a negative GSS_E* code on failure; gss_last_error() gives the text
+ *   - d (feature width == --hidden-units, modules/model.py:142) must be a multiple of 16, <= 1024
+ */
+#ifndef GSSGCN_H
+#define GSSGCN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSS_ABI_VERSION 1
+
+#define GSS_OK 0
+#define GSS_EINVAL (-22)   /* bad argument (shape, null pointer, unsupported d) */
+#define GSS_ENOMEM (-12)   /* hipMalloc failed */
+#define GSS_EHIP (-5)      /* a HIP call or kernel launch failed */
+
+typedef struct gss_csr gss_csr;   /* a CSR operand plus its launch schedule (row bins) */
+typedef struct gss_plan gss_plan; /* activations + workspace of one training replica/shard */
+
+int gss_abi_version(void);
+const char *gss_last_error(void);
+
+/* ---- K11  preprocess_graph, helpers/helper.py:82-89 (+ fp32 cast helper.py:95) ----------
+ * In: CSR of (A + I) with fp64 values (diagonal already inserted, columns sorted).
+ * Out: val_out[e] = (float)(dinv[row] * val[e] * dinv[col[e]]), dinv = rowsum^-1/2 in fp64;
+ *      rowsum_out (nullable) = fp64 row sums D_ii.  Row sums <= 0 give NaN/inf like the reference. */
+int gss_normalize_adj(int32_t n, const int32_t *rowptr, const int32_t *col, const double *val,
+                      float *val_out, double *rowsum_out, void *stream);
+
+/* ---- CSR handle ---------------------------------------------------------------------------
+ * Borrows d_rowptr/d_col/d_val (caller keeps them alive).  h_rowptr is a HOST copy of rowptr used
+ * once to bin rows by length (long rows get a whole workgroup).  n_cols is the height of the dense
+ * operand (== n_rows on one GPU, the global N for a row shard). */
+int gss_csr_create(gss_csr **out, int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *h_rowptr,
+                   const int32_t *d_rowptr, const int32_t *d_col, const float *d_val);
+void gss_csr_destroy(gss_csr *a);
+
+/* ---- K1/K2  torch.sparse.mm + torch.mul, modules/model.py:163,168-169 -----------------------
+ * y = A x  (x: [n_cols][d], y: [n_rows][d]).  If m != NULL also m = y (.) h, h: [n_rows][d]
+ * (the Hadamard of model.py:168 fused into the epilogue of the first SpMM). */
+int gss_spmm(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream);
+
+/* backward SpMMs (autograd of model.py:163-169 for layers >= 2), A here is CSR(A_hat^T):
+ *   gss_spmm_bwd1: dm = A g_am;  u = g_ax + dm (.) x_in;  t = dm (.) ax
+ *   gss_spmm_bwd2: gx = t + A u; dp = c * gx (.) elu'(p) (+ res if res != NULL); gx_out nullable */
+int gss_spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in,
+                  const float *ax, float *u, float *t, void *stream);
+int gss_spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c,
+                  const float *res, float *dp, float *gx_out, void *stream);
+
+/* ---- K3/K4  nn.Linear x2 + add + F.elu + residual, modules/model.py:165,170-173,201-203 -------
+ * p = ax W1^T + b1 + am W2^T + b2;  o = elu(p);  x_next = p_prev ? p_prev + decay*o : o.
+ * W1, W2: [d][d] row-major ([out][in], the nn.Linear layout).  fp32 MFMA (v_mfma_f32_16x16x4_f32). */
+int gss_dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1,
+                  const float *w2, const float *b2, const float *p_prev, float decay, float *p, float *x_next,
+                  void *stream);
+
+/* input gradients of the two Linear layers: g_ax = dp W1, g_am = dp W2 (w1t/w2t are the TRANSPOSED
+ * weights, [in][out]).  If rows != NULL, row r of the compact [n][d] input is written to row rows[r]
+ * of the outputs (scatter of batch-row gradients into zeroed [N][d] buffers). */
+int gss_dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t, const float *w2t,
+                        const int32_t *rows, float *g_ax, float *g_am, void *stream);
+
+/* weight gradients: gw1 (+)= dp^T ax, gw2 (+)= dp^T am, gb (+)= colsum(dp), fixed-order two-stage
+ * reduction (bitwise reproducible).  rows != NULL: dp is compact [n][d] and ax/am rows are gathered
+ * at rows[r].  accumulate != 0 adds to the existing gw1/gw2/gb.  ws: workspace of
+ * gss_wgrad_workspace_bytes(n, d) bytes. */
+size_t gss_wgrad_workspace_bytes(int32_t n, int32_t d);
+int gss_dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, const float *am,
+                         const int32_t *rows, float *gw1, float *gw2, float *gb, int accumulate, void *ws,
+                         void *stream);
+
+/* ---- K5  F.normalize(x, dim=1), modules/model.py:205 (eps 1e-12) -----------------------------
+ * e = x / max(||x||, eps); inv_den[i] = 1 / max(||x_i||, eps) is kept for the backward pass. */
+int gss_rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, void *stream);
+
+/* ---- K6/K7  GSS_loss.gss_loss + its autograd, modules/model.py:214-221 ------------------------
+ * E_B = e[idx]; S = E_B E_B^T; loss = mean(-alpha/2 (relu(S) - beta)^2) written to loss_out[0];
+ * de_b[b] = dLoss/dE_B[b] = sum_j (G_bj + G_jb) E_B[j], G = -alpha/B^2 (relu(S)-beta) 1[S>0].
+ * S is never materialised.  idx: int32[B], unique.  ws: gss_loss_workspace_bytes(B, d) bytes. */
+size_t gss_loss_workspace_bytes(int32_t b, int32_t d);
+int gss_loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta,
+                     float alpha, float *loss_out, float *de_b, void *ws, void *stream);
+
+/* backward of K5 + K4 on the batch rows: dx_b = (de_b - e_b (e_b . de_b)) * inv_den[idx];
+ * dp_b = c * dx_b (.) elu'(p[idx]).  All [B][d] compact. */
+int gss_rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b, const float *e,
+                        const float *inv_den, const float *p, float c, float *dx_b, float *dp_b, void *stream);
+
+/* dst[rows[r]] += src[r] for r < b (rows unique) */
+int gss_scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, void *stream);
+
+/* ---- K10  torch.optim.Adam.step, train.py:139-141,184 -----------------------------------------
+ * One tensor of `count` floats; step is the 1-based step number.  lr, betas, eps as torch defaults.
+ * If wt != NULL the updated parameter, viewed as [dim][dim], is also written transposed to wt. */
+int gss_adam_step(int64_t count, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                  int32_t step, float lr, float beta1, float beta2, float eps, float *wt, int32_t dim,
+                  void *stream);
+
+/* ---- K12  np.percentile(E E^T, q), train.py:165-167 -------------------------------------------
+ * Exact q-th percentile (linear interpolation) of all n*n inner products of the rows of e, by
+ * 3-pass radix select on device.  Result to h_out (host float), synchronises the stream. */
+int gss_percentile(int32_t n, int32_t d, const float *e, double q, float *h_out, void *stream);
+
+/* ---- whole training step (train.py:158-184) ---------------------------------------------------
+ * A plan owns every activation/gradient buffer of one replica so that a step is ONE host call that
+ * enqueues all kernels.  a / at: CSR(A_hat) and CSR(A_hat^T) (at may be NULL for num_layers == 1). */
+typedef struct gss_plan_desc {
+  int32_t n;          /* nodes (rows of this replica) */
+  int32_t d;          /* hidden units */
+  int32_t num_layers; /* model.py:199 */
+  int32_t max_batch;  /* largest batch the plan will see */
+  float layer_decay;  /* model.py:202 */
+  float alpha;        /* model.py:220 */
+  float lr, beta1, beta2, eps; /* Adam */
+  int32_t cache_layer1; /* 1: keep AX/AM of layer 1 (inputs are constant) across steps */
+} gss_plan_desc;
+
+/* caller-owned tensors the plan reads and writes (all device pointers, fp32) */
+typedef struct gss_plan_io {
+  const float *x;             /* [n][d] input features (train.py:125) */
+  float *w1, *b1, *w2, *b2;   /* gcn_layer.dense{,2}.{weight,bias}; updated in place by gss_plan_adam */
+  float *emb;                 /* [n][d] out: unit-norm embeddings of the last forward */
+  float *loss;                /* [1]    out: loss of the last gss_plan_loss_backward */
+  float *gw1, *gb1, *gw2, *gb2; /* out: gradients of the last backward */
+} gss_plan_io;
+
+int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a, const gss_csr *at,
+                    const gss_plan_io *io);
+void gss_plan_destroy(gss_plan *p);
+/* forward only (model.py:197-207): writes io.emb */
+int gss_plan_forward(gss_plan *p, void *stream);
+/* loss + backward for batch idx[0..b): writes io.loss and io.g* */
+int gss_plan_loss_backward(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream);
+/* backward only, for an arbitrary upstream gradient that is non-zero on `b` unique rows: de_rows is the
+ * compact [b][d] dLoss/dEmbedding of rows[0..b) (the autograd-glue path; NULL = the plan's own de_b) */
+int gss_plan_backward(gss_plan *p, const int32_t *rows, int32_t b, const float *de_rows, void *stream);
+/* Adam on the four tensors with the plan's gradients; step numbers are counted by the plan */
+int gss_plan_adam(gss_plan *p, void *stream);
+/* forward + loss + backward + Adam = one iteration of train.py:155-184 */
+int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream);
+/* layer activations for parity tests: which 0 AX, 1 AM, 2 P of layer `layer` (0-based) */
+const float *gss_plan_activation(const gss_plan *p, int layer, int which);
+size_t gss_plan_device_bytes(const gss_plan *p);
+/* set the 1-based Adam step counter (resume) / read it */
+void gss_plan_set_step(gss_plan *p, int32_t step);
+int32_t gss_plan_get_step(const gss_plan *p);
+/* plain device-to-device copy on `stream` (lets a ctypes host read plan-owned activations) */
+int gss_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSSGCN_H */

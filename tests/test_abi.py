@@ -1,0 +1,67 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/gssgcn.h declares
+(no compute calls -- there is no GPU here)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import gcn_drug_repurposing_amd as pkg
+    if not os.path.exists(pkg._lib.LIB_PATH):
+        pkg.build()
+    return pkg.load()
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "gssgcn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gss_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    import gcn_drug_repurposing_amd as pkg
+    names = header_functions()
+    assert len(names) >= 30
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg._lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (gss_[a-z0-9_]+)", out))
+    assert set(names) <= exported, sorted(set(names) - exported)
+    assert set(names) == set(pkg._lib.SIGNATURES), sorted(set(names) ^ set(pkg._lib.SIGNATURES))
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_abi_version_and_error_text(lib):
+    assert lib.gss_abi_version() == 1
+    assert isinstance(lib.gss_last_error(), bytes)
+
+
+def test_code_object_is_gfx950_only():
+    import gcn_drug_repurposing_amd as pkg
+    blob = open(pkg._lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_90"):
+        assert other not in blob
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import gcn_drug_repurposing_amd as pkg
+    monkeypatch.setattr(pkg._lib, "_lib", None)
+    monkeypatch.setattr(pkg._lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(pkg.GssError, match="no CPU fallback"):
+        pkg._lib.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg_dir = os.path.join(ROOT, "gcn-drug-repurposing_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+    for f in ("train.py",):
+        assert "oracle" not in open(os.path.join(ROOT, f)).read()

@@ -1,0 +1,306 @@
+"""-m gpu: every libgssgcn.so entry point against the numpy oracle / scipy on seeded inputs (called through
+the C ABI with ctypes, device buffers held in torch tensors)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import golden_batches, golden_csr, golden_params, load_golden
+from oracle import gss_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    import gcn_drug_repurposing_amd as pkg
+    from gcn_drug_repurposing_amd import _lib, graph
+    lib = pkg.load()
+
+    class NS:
+        pass
+    ns = NS()
+    ns.lib, ns._lib, ns.graph = lib, _lib, graph
+    ns.st = lambda: _lib.current_stream()
+    return ns
+
+
+def cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def rel_err(got, ref):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+def random_graph(rng, n, avg_deg, hub_rows=(), hub_deg=0, empty_rows=()):
+    m = n * avg_deg
+    r = rng.randint(0, n, m)
+    c = rng.randint(0, n, m)
+    for h in hub_rows:
+        r = np.concatenate([r, np.full(hub_deg, h)])
+        c = np.concatenate([c, rng.choice(n, hub_deg, replace=False)])
+    keep = ~np.isin(r, list(empty_rows))
+    r, c = r[keep], c[keep]
+    a = sp.csr_matrix((rng.uniform(0.1, 1.0, len(r)), (r, c)), shape=(n, n))
+    a.sum_duplicates()
+    a.sort_indices()
+    return a
+
+
+# ---------------------------------------------------------------- K11
+def test_normalize_adj_matches_reference_fixture(G, op_case):
+    name, g = op_case
+    gg = G.graph.GssGraph(golden_csr(g, "A"))
+    ref = golden_csr(g, "Ahat")
+    assert np.array_equal(gg.a.h_indptr, ref.indptr)
+    assert np.array_equal(gg.a.col.cpu().numpy(), ref.indices)
+    got = gg.a.val.cpu().numpy()
+    assert got.dtype == np.float32
+    # fp64 pipeline then fp32 cast: equal to the reference's cast up to 1 ulp
+    np.testing.assert_allclose(got, ref.data.astype(np.float32), rtol=1.2e-7, atol=0)
+    np.testing.assert_allclose(gg.rowsum.cpu().numpy(), g["rowsum"], rtol=1e-13)
+    # the transposed operand is the same matrix transposed
+    t = gg.at.to_scipy()
+    assert abs(t - gg.a.to_scipy().T).max() == 0
+
+
+def test_spmm_row_sums_within_1e5(G, op_case):
+    """north_star: SpMM row sums within 1e-5 (fp32) of the host preprocess_graph result."""
+    name, g = op_case
+    gg = G.graph.GssGraph(golden_csr(g, "A"))
+    n = gg.n
+    ones = torch.ones(n, 16, device="cuda")
+    y = torch.empty(n, 16, device="cuda")
+    G._lib.check(G.lib.gss_spmm(gg.a.handle, 16, ones.data_ptr(), y.data_ptr(), None, None, G.st()))
+    ref = np.asarray(golden_csr(g, "Ahat").sum(1)).reshape(-1)
+    assert np.abs(y[:, 0].cpu().numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max())
+
+
+# ---------------------------------------------------------------- K1 / K2 / K9
+@pytest.mark.parametrize("d", [16, 48, 64, 128, 256, 512, 1024])
+def test_spmm_all_widths_with_hub_and_empty_rows(G, d):
+    rng = np.random.RandomState(d)
+    n = 1500
+    a = random_graph(rng, n, 7, hub_rows=(3, 700), hub_deg=1200, empty_rows=(0, 11, n - 1))
+    a32 = sp.csr_matrix((a.data.astype(np.float32), a.indices, a.indptr), shape=a.shape)
+    csr = G.graph.DeviceCSR(a32.indptr, a32.indices, a32.data, n, n, "cuda")
+    assert csr.h_indptr[4] - csr.h_indptr[3] > 512  # exercises the long-row kernel
+    x = rng.randn(n, d).astype(np.float32)
+    h = rng.randn(n, d).astype(np.float32)
+    xd, hd = cu(x), cu(h)
+    y = torch.full((n, d), float("nan"), device="cuda")
+    m = torch.full((n, d), float("nan"), device="cuda")
+    G._lib.check(G.lib.gss_spmm(csr.handle, d, xd.data_ptr(), y.data_ptr(), hd.data_ptr(), m.data_ptr(), G.st()))
+    ref = a32.astype(np.float64) @ x.astype(np.float64)
+    assert rel_err(y.cpu().numpy(), ref) < 2e-6
+    assert rel_err(m.cpu().numpy(), ref * h) < 2e-6
+    assert np.all(y.cpu().numpy()[[0, 11, n - 1]] == 0)
+    y2 = torch.full((n, d), float("nan"), device="cuda")
+    G._lib.check(G.lib.gss_spmm(csr.handle, d, xd.data_ptr(), y2.data_ptr(), None, None, G.st()))
+    assert torch.equal(y, y2)  # bitwise reproducible, with and without the fused epilogue
+
+
+def test_spmm_backward_epilogues(G):
+    rng = np.random.RandomState(5)
+    n, d = 900, 128
+    a = random_graph(rng, n, 9, hub_rows=(5,), hub_deg=700)
+    a32 = sp.csr_matrix((a.data.astype(np.float32), a.indices, a.indptr), shape=a.shape)
+    csr = G.graph.DeviceCSR(a32.indptr, a32.indices, a32.data, n, n, "cuda")
+    A = a32.astype(np.float64)
+    gam, gax, xin, ax, p, res = (rng.randn(n, d).astype(np.float32) for _ in range(6))
+    u = torch.empty(n, d, device="cuda")
+    t = torch.empty(n, d, device="cuda")
+    G._lib.check(G.lib.gss_spmm_bwd1(csr.handle, d, cu(gam).data_ptr(), cu(gax).data_ptr(), cu(xin).data_ptr(),
+                                     cu(ax).data_ptr(), u.data_ptr(), t.data_ptr(), G.st()))
+    dm = A @ gam.astype(np.float64)
+    assert rel_err(u.cpu().numpy(), gax + dm * xin) < 2e-6
+    assert rel_err(t.cpu().numpy(), dm * ax) < 2e-6
+    uu, tt = u.cpu().numpy().astype(np.float64), t.cpu().numpy().astype(np.float64)
+    for use_res, want_gx in ((False, False), (True, True)):
+        dp = torch.empty(n, d, device="cuda")
+        gx = torch.empty(n, d, device="cuda")
+        resd = cu(res) if use_res else None
+        G._lib.check(G.lib.gss_spmm_bwd2(csr.handle, d, u.data_ptr(), t.data_ptr(), cu(p).data_ptr(), 0.3,
+                                         resd.data_ptr() if use_res else None, dp.data_ptr(),
+                                         gx.data_ptr() if want_gx else None, G.st()))
+        gref = tt + A @ uu
+        dref = 0.3 * gref * np.where(p > 0, 1.0, np.exp(np.minimum(p, 0).astype(np.float64)))
+        if use_res:
+            dref = dref + res
+            assert rel_err(gx.cpu().numpy(), gref) < 2e-6
+        assert rel_err(dp.cpu().numpy(), dref) < 2e-6
+
+
+# ---------------------------------------------------------------- K3 / K4 / K8
+@pytest.mark.parametrize("n,d", [(1000, 128), (77, 16), (300, 32), (513, 64), (200, 256), (130, 48)])
+def test_dense_fwd(G, n, d):
+    rng = np.random.RandomState(n + d)
+    ax, am, pprev = (rng.randn(n, d).astype(np.float32) for _ in range(3))
+    w1, w2 = (np.eye(d, dtype=np.float32) + 0.1 * rng.randn(d, d).astype(np.float32) for _ in range(2))
+    b1, b2 = (0.1 * rng.randn(d).astype(np.float32) for _ in range(2))
+    for prev in (None, pprev):
+        p = torch.full((n, d), float("nan"), device="cuda")
+        xn = torch.full((n, d), float("nan"), device="cuda")
+        G._lib.check(G.lib.gss_dense_fwd(n, d, cu(ax).data_ptr(), cu(am).data_ptr(), cu(w1).data_ptr(), cu(b1).data_ptr(),
+                                         cu(w2).data_ptr(), cu(b2).data_ptr(), cu(prev).data_ptr() if prev is not None else None,
+                                         0.3, p.data_ptr(), xn.data_ptr(), G.st()))
+        pref = ax.astype(np.float64) @ w1.T.astype(np.float64) + b1 + am.astype(np.float64) @ w2.T.astype(np.float64) + b2
+        o = np.where(pref > 0, pref, np.expm1(np.minimum(pref, 0)))
+        xref = o if prev is None else prev + 0.3 * o
+        assert rel_err(p.cpu().numpy(), pref) < 3e-6
+        assert rel_err(xn.cpu().numpy(), xref) < 3e-6
+
+
+@pytest.mark.parametrize("n,d", [(700, 128), (50, 16), (333, 64)])
+def test_dense_bwd_input_dense_and_scattered(G, n, d):
+    rng = np.random.RandomState(n)
+    dp = rng.randn(n, d).astype(np.float32)
+    w1, w2 = (rng.randn(d, d).astype(np.float32) for _ in range(2))
+    gax = torch.empty(n, d, device="cuda")
+    gam = torch.empty(n, d, device="cuda")
+    G._lib.check(G.lib.gss_dense_bwd_input(n, d, cu(dp).data_ptr(), cu(w1.T.copy()).data_ptr(), cu(w2.T.copy()).data_ptr(), None,
+                                           gax.data_ptr(), gam.data_ptr(), G.st()))
+    assert rel_err(gax.cpu().numpy(), dp.astype(np.float64) @ w1) < 3e-6
+    assert rel_err(gam.cpu().numpy(), dp.astype(np.float64) @ w2) < 3e-6
+    big = 3 * n
+    rows = rng.permutation(big)[:n].astype(np.int32)
+    gax2 = torch.zeros(big, d, device="cuda")
+    gam2 = torch.zeros(big, d, device="cuda")
+    G._lib.check(G.lib.gss_dense_bwd_input(n, d, cu(dp).data_ptr(), cu(w1.T.copy()).data_ptr(), cu(w2.T.copy()).data_ptr(),
+                                           cu(rows).data_ptr(), gax2.data_ptr(), gam2.data_ptr(), G.st()))
+    ref = np.zeros((big, d))
+    ref[rows] = dp.astype(np.float64) @ w1
+    assert rel_err(gax2.cpu().numpy(), ref) < 3e-6
+    assert torch.equal(gax2[cu(rows).long()], gax)
+
+
+@pytest.mark.parametrize("n,d", [(5000, 128), (100, 16), (2048, 64), (999, 256), (64, 32)])
+def test_dense_bwd_weight(G, n, d):
+    rng = np.random.RandomState(n + d)
+    dp, ax, am = (rng.randn(n, d).astype(np.float32) for _ in range(3))
+    ws = torch.empty(G.lib.gss_wgrad_workspace_bytes(n, d), dtype=torch.uint8, device="cuda")
+    gw1 = torch.full((d, d), float("nan"), device="cuda")
+    gw2 = torch.full((d, d), float("nan"), device="cuda")
+    gb = torch.full((d,), float("nan"), device="cuda")
+    args = (n, d, cu(dp).data_ptr(), cu(ax).data_ptr(), cu(am).data_ptr())
+    G._lib.check(G.lib.gss_dense_bwd_weight(*args, None, gw1.data_ptr(), gw2.data_ptr(), gb.data_ptr(), 0, ws.data_ptr(), G.st()))
+    r1 = dp.T.astype(np.float64) @ ax
+    r2 = dp.T.astype(np.float64) @ am
+    rb = dp.astype(np.float64).sum(0)
+    assert rel_err(gw1.cpu().numpy(), r1) < 3e-6
+    assert rel_err(gw2.cpu().numpy(), r2) < 3e-6
+    assert rel_err(gb.cpu().numpy(), rb) < 3e-6
+    first = gw1.clone()
+    G._lib.check(G.lib.gss_dense_bwd_weight(*args, None, gw1.data_ptr(), gw2.data_ptr(), gb.data_ptr(), 1, ws.data_ptr(), G.st()))
+    assert rel_err(gw1.cpu().numpy(), 2 * r1) < 3e-6 and rel_err(gb.cpu().numpy(), 2 * rb) < 3e-6
+    G._lib.check(G.lib.gss_dense_bwd_weight(*args, None, gw1.data_ptr(), gw2.data_ptr(), gb.data_ptr(), 0, ws.data_ptr(), G.st()))
+    assert torch.equal(gw1, first)  # reproducible
+    # gathered rows: dp compact [b][d], ax/am indexed
+    b = max(1, n // 3)
+    rows = rng.permutation(n)[:b].astype(np.int32)
+    G._lib.check(G.lib.gss_dense_bwd_weight(b, d, cu(dp[:b]).data_ptr(), cu(ax).data_ptr(), cu(am).data_ptr(), cu(rows).data_ptr(),
+                                            gw1.data_ptr(), gw2.data_ptr(), gb.data_ptr(), 0, ws.data_ptr(), G.st()))
+    assert rel_err(gw1.cpu().numpy(), dp[:b].T.astype(np.float64) @ ax[rows]) < 3e-6
+    assert rel_err(gw2.cpu().numpy(), dp[:b].T.astype(np.float64) @ am[rows]) < 3e-6
+
+
+# ---------------------------------------------------------------- K5
+@pytest.mark.parametrize("n,d", [(1000, 128), (33, 16), (257, 64), (100, 512), (64, 1024)])
+def test_rownorm_fwd_and_bwd(G, n, d):
+    rng = np.random.RandomState(d)
+    x = rng.randn(n, d).astype(np.float32)
+    x[0] = 0  # norm below eps -> 0 / eps
+    e = torch.empty(n, d, device="cuda")
+    inv = torch.empty(n, device="cuda")
+    G._lib.check(G.lib.gss_rownorm_fwd(n, d, cu(x).data_ptr(), e.data_ptr(), inv.data_ptr(), G.st()))
+    den = np.maximum(np.sqrt((x.astype(np.float64) ** 2).sum(1)), 1e-12)
+    assert rel_err(e.cpu().numpy(), x / den[:, None]) < 1e-6
+    assert np.all(e.cpu().numpy()[0] == 0)
+    b = max(1, n // 2)
+    rows = rng.permutation(np.arange(1, n))[:b].astype(np.int32)
+    de = rng.randn(b, d).astype(np.float32)
+    p = rng.randn(n, d).astype(np.float32)
+    dx = torch.empty(b, d, device="cuda")
+    dpb = torch.empty(b, d, device="cuda")
+    G._lib.check(G.lib.gss_rownorm_elu_bwd(d, cu(de).data_ptr(), cu(rows).data_ptr(), b, e.data_ptr(), inv.data_ptr(),
+                                           cu(p).data_ptr(), 0.4, dx.data_ptr(), dpb.data_ptr(), G.st()))
+    eb = (x / den[:, None])[rows]
+    dxr = (de - eb * (eb * de).sum(1, keepdims=True)) / den[rows][:, None]
+    assert rel_err(dx.cpu().numpy(), dxr) < 3e-6
+    assert rel_err(dpb.cpu().numpy(), 0.4 * dxr * np.where(p[rows] > 0, 1.0, np.exp(np.minimum(p[rows], 0)))) < 3e-6
+
+
+# ---------------------------------------------------------------- K6 / K7
+@pytest.mark.parametrize("n,d,b", [(3000, 128, 2048), (500, 16, 500), (400, 64, 1), (900, 256, 333), (300, 32, 17), (2000, 128, 1288)])
+def test_loss_fwd_bwd(G, n, d, b):
+    rng = np.random.RandomState(b)
+    x = rng.randn(n, d)
+    x[:, 0] += 1.0  # mostly positive similarities, some negative
+    e = (x / np.sqrt((x ** 2).sum(1, keepdims=True))).astype(np.float32)
+    idx = rng.permutation(n)[:b].astype(np.int32)
+    beta, alpha = 0.25, 1.7
+    loss = torch.zeros(1, device="cuda")
+    de = torch.full((b, d), float("nan"), device="cuda")
+    ws = torch.empty(G.lib.gss_loss_workspace_bytes(b, d), dtype=torch.uint8, device="cuda")
+    G._lib.check(G.lib.gss_loss_fwd_bwd(n, d, cu(e).data_ptr(), cu(idx).data_ptr(), b, beta, alpha, loss.data_ptr(),
+                                        de.data_ptr(), ws.data_ptr(), G.st()))
+    e64 = e.astype(np.float64)
+    lref = O.gss_loss(e64, beta, idx, alpha)
+    dref = O.loss_grad_emb(e64, beta, idx, alpha)[idx]
+    assert abs(loss.item() - lref) < 2e-6 * abs(lref)
+    assert rel_err(de.cpu().numpy(), dref) < 5e-6
+
+
+# ---------------------------------------------------------------- K10
+def test_adam_matches_torch_semantics(G):
+    rng = np.random.RandomState(0)
+    d = 48
+    params = {k: rng.randn(*s).astype(np.float32) for k, s in (("W1", (d, d)), ("b1", (d,)), ("W2", (d, d)), ("b2", (d,)))}
+    ref = {k: v.copy() for k, v in params.items()}
+    dev = {k: cu(v) for k, v in params.items()}
+    m = {k: torch.zeros_like(v) for k, v in dev.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in dev.items()}
+    wt = torch.empty(d, d, device="cuda")
+    state = {}
+    for step in range(1, 6):
+        grads = {k: (rng.randn(*v.shape) * 10 ** rng.uniform(-6, 0)).astype(np.float32) for k, v in params.items()}
+        O.adam_step(ref, grads, state, 3e-4)
+        for k in dev:
+            G._lib.check(G.lib.gss_adam_step(dev[k].numel(), dev[k].data_ptr(), cu(grads[k]).data_ptr(), m[k].data_ptr(),
+                                             v2[k].data_ptr(), step, 3e-4, 0.9, 0.999, 1e-8,
+                                             wt.data_ptr() if k == "W1" else None, d if k == "W1" else 0, G.st()))
+        for k in dev:
+            assert np.abs(dev[k].cpu().numpy() - ref[k]).max() < 3e-4 * 1e-4
+        assert torch.equal(wt, dev["W1"].t())
+
+
+# ---------------------------------------------------------------- K12
+@pytest.mark.parametrize("n,d,q", [(700, 64, 98.0), (129, 16, 50.0), (1000, 128, 99.9), (300, 32, 0.0), (300, 32, 100.0)])
+def test_percentile_exact(G, n, d, q):
+    rng = np.random.RandomState(n)
+    x = rng.randn(n, d)
+    e = (x / np.sqrt((x ** 2).sum(1, keepdims=True))).astype(np.float32)
+    ed = cu(e)
+    out = C.c_float()
+    G._lib.check(G.lib.gss_percentile(n, d, ed.data_ptr(), q, C.byref(out), G.st()))
+    ref = np.percentile((e.astype(np.float64) @ e.astype(np.float64).T).flatten(), q)
+    assert abs(out.value - ref) < 2e-6
+
+
+def test_bad_arguments_fail_loudly(G):
+    x = torch.zeros(10, 20, device="cuda")
+    with pytest.raises(G._lib.GssError, match="multiple of 16"):
+        G._lib.check(G.lib.gss_rownorm_fwd(10, 20, x.data_ptr(), x.data_ptr(), x.data_ptr(), G.st()))
+    with pytest.raises(G._lib.GssError):
+        G._lib.check(G.lib.gss_dense_fwd(10, 16, None, None, None, None, None, None, None, 0.3, None, None, G.st()))
