@@ -146,7 +146,7 @@ def main(argv=None):
                 engine.forward()                              # train.py:158-161
                 if args.beta_percentile is not None:
                     beta_score = engine.percentile(args.beta_percentile)   # train.py:165-167
-                    print(f"beta:{beta_score}")
+                    print(f"selected beta:{beta_score}")
                 engine.loss_backward(idx32, beta_score, count=b, offset=off)   # train.py:175,183
                 engine.adam()                                 # train.py:184
             else:
