@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline workload on MI355X.
+
+    python bench.py --gpus 1 --steps 60 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one iteration of train.py:155-184 (full-graph forward of the L-layer GSS GCN, gss_loss on one
+batch of B node ids, backward, Adam) on the whole_graph stand-in (BASELINE.json configs[1]: N = 29,960,
+nnz(A_hat) = 988,028, d = 128, L = 2, B = 2048, synthetic -- the real edgelist is not shipped).
+
+Prints ONE JSON line.  `value` = SpMM edge traversals per second over the whole job (every step executes 2L
+forward + 2(L-1) backward SpMMs over nnz(A_hat) stored entries; nothing is cached or skipped), i.e. end-to-end
+training throughput in the metric's unit; `epoch_time_s` is the other half of BASELINE.json's metric.
+`roofline` prices the dominant kernel (the plain forward SpMM) from HIP events recorded around every launch
+during a second pass over the same steps; `cpu_baseline` times the reference's torch-CPU op sequence
+(oracle/torch_cpu_path.py, kind "port") on the host cores for a few steps of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def spmm_bytes(nnz, n, d, extra_rows=0):
+    """8 nnz + 4 (N+1) + 4 N d (X once) + 4 N d (Y) [+ 4 N d per extra operand]"""
+    return 8 * nnz + 4 * (n + 1) + 8 * n * d + 4 * n * d * extra_rows
+
+
+def build_workload(name, d_override=None):
+    from gcn_drug_repurposing_amd import synth
+    if name == "whole_graph":
+        adj, _, _ = synth.whole_graph_standin(seed=1)
+        d, L, B = 128, 2, 2048
+        x = synth.gaussian_features(adj.shape[0], d_override or d, seed=2)
+    elif name == "whole_graph_pathway":
+        adj, _, _ = synth.whole_graph_standin(seed=1, pathway_edges=True)
+        d, L, B = 256, 3, 2048
+        x = synth.gaussian_features(adj.shape[0], d_override or d, seed=3)
+    elif name.startswith("rmat"):
+        # rmat:<nodes>:<edges>, default a 1/10-scale version of BASELINE config 5 that builds in ~1 minute
+        parts = name.split(":")
+        n = int(parts[1]) if len(parts) > 1 else 1_000_000
+        m = int(parts[2]) if len(parts) > 2 else 20_000_000
+        adj = synth.rmat_adj(n, m, seed=4)
+        d, L, B = 128, 2, 2048
+        x = synth.gaussian_features(n, d_override or d, seed=5)
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return adj, x, (d_override or d), L, B
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="whole_graph")
+    ap.add_argument("--hidden-units", type=int, default=None)
+    ap.add_argument("--cache-layer1", action="store_true", help="also report the step time with layer-1 SpMMs cached")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import gcn_drug_repurposing_amd as pkg
+    from gcn_drug_repurposing_amd.graph import GssGraph
+    pkg.load()
+
+    adj, x_host, d, L, B = build_workload(args.workload, args.hidden_units)
+    n = adj.shape[0]
+    B = min(B, n)
+    steps_per_epoch = (n + B - 1) // B
+    rng = np.random.RandomState(1234)
+    batches = []
+    while len(batches) < args.warmup + args.steps:
+        perm = rng.permutation(n).astype(np.int32)
+        batches += [perm[i:i + B] for i in range(0, n, B)]
+    batches = batches[:args.warmup + args.steps]
+    beta, alpha, lr, decay = 0.25, 1.0, 3e-4, 0.3
+    np.random.seed(7)
+    w = np.random.randn(d, d) * 1e-5
+    np.fill_diagonal(w, 1.0)
+    params_host = {"W1": w.astype(np.float32), "b1": np.zeros(d, np.float32), "W2": w.astype(np.float32).copy(),
+                   "b2": np.zeros(d, np.float32)}
+
+    if world == 1:
+        from gcn_drug_repurposing_amd.engine import GssEngine
+        graph = GssGraph(adj, need_transpose=L > 1)
+        nnz = graph.nnz
+        feats = torch.from_numpy(x_host).cuda()
+        params = [torch.from_numpy(params_host[k].copy()).cuda() for k in ("W1", "b1", "W2", "b2")]
+        engine = GssEngine(graph, feats, params, num_layers=L, layer_decay=decay, alpha=alpha, lr=lr, max_batch=B)
+        parallelism = "single"
+    else:
+        from gcn_drug_repurposing_amd.dist import ShardedEngine
+        engine = ShardedEngine(adj, x_host, params_host, num_layers=L, layer_decay=decay, alpha=alpha, lr=lr, max_batch=B)
+        nnz = engine.global_nnz
+        parallelism = f"node-range shards x{world}, RCCL all-gather per SpMM hop"
+
+    idx_all = torch.from_numpy(np.concatenate(batches)).cuda()
+    offs = np.concatenate([[0], np.cumsum([len(b) for b in batches])]).astype(np.int64)
+
+    def run(lo, hi):
+        for s in range(lo, hi):
+            engine.step(idx_all, beta, count=int(offs[s + 1] - offs[s]), offset=int(offs[s]))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(0, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.warmup, args.warmup + args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_end = float(engine.loss.item())
+    if not np.isfinite(loss_end):
+        raise SystemExit(f"non-finite loss {loss_end} after the timed steps")
+
+    spmm_per_step = 2 * L + 2 * (L - 1)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = spmm_per_step * nnz * args.steps / elapsed
+
+    out = {
+        "metric": "gcn_spmm_edges_per_s", "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "epoch_time_s": ms_per_step * 1e-3 * steps_per_epoch,
+        "config": {"workload": f"{args.workload} stand-in: N={n}, nnz(A_hat)={nnz}, d={d}, L={L}, B={B}, "
+                               f"{steps_per_epoch} steps/epoch; full train step (fwd+gss_loss+bwd+Adam), "
+                               f"{spmm_per_step} SpMMs/step all executed",
+                   "parallelism": parallelism, "final_loss": loss_end},
+    }
+
+    # ---- roofline leg: HIP events around every kernel class over the same steps (rank 0, single GPU) ----
+    if world == 1:
+        engine.profile(True)
+        run(args.warmup, args.warmup + args.steps)
+        prof = engine.profile_read()
+        engine.profile(False)
+        ms, cnt = prof["spmm_fwd"]
+        avg_s = ms / max(cnt, 1) * 1e-3
+        alg = spmm_bytes(nnz, n, d)
+        achieved = alg / avg_s / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "spmm_rows_kernel<PLAIN> (AM = A_hat . M, forward)",
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": None, "alg_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6, "launches": cnt}
+        out["spmm_kernel_edges_per_s"] = nnz / avg_s
+        out["kernel_us"] = {k: (v[0] / max(v[1], 1) * 1e3) for k, v in prof.items() if v[1]}
+        out["kernel_ms_per_step"] = {k: v[0] / args.steps for k, v in prof.items() if v[1]}
+        dense_ms, dense_cnt = prof["dense_fwd"]
+        if dense_cnt:
+            fl = 2.0 * n * (2 * d) * d
+            out["mfma_dense_fwd"] = {"achieved": fl / (dense_ms / dense_cnt * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                                     "unit": "TFLOP/s"}
+            out["mfma_dense_fwd"]["frac"] = out["mfma_dense_fwd"]["achieved"] / MFMA_F32_PEAK_TFLOPS
+        if args.cache_layer1:
+            from gcn_drug_repurposing_amd.engine import GssEngine
+            eng2 = GssEngine(graph, feats, [p.clone() for p in params], num_layers=L, layer_decay=decay, alpha=alpha, lr=lr,
+                             max_batch=B, cache_layer1=True)
+            for s in range(args.warmup):
+                eng2.step(idx_all, beta, count=int(offs[s + 1] - offs[s]), offset=int(offs[s]))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s in range(args.warmup, args.warmup + args.steps):
+                eng2.step(idx_all, beta, count=int(offs[s + 1] - offs[s]), offset=int(offs[s]))
+            torch.cuda.synchronize()
+            out["ms_per_step_layer1_cached"] = (time.perf_counter() - t1) / args.steps * 1e3
+
+    # ---- CPU baseline leg (rank 0, N=1 only): the reference's torch-CPU op sequence on the host cores ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import gss_oracle as O
+        from oracle.torch_cpu_path import TorchCpuPath
+        a_hat, _ = O.preprocess_graph(adj)
+        cpu = TorchCpuPath(O.to_fp32_csr(a_hat), x_host, params_host, L, decay, alpha, lr)
+        cpu_steps = max(2, args.cpu_steps)
+        ts = cpu.time_steps([b.astype(np.int64) for b in batches[:cpu_steps + 1]], beta, warmup=1)
+        t_step = float(np.median(ts))
+        t_spmm = cpu.time_spmm(3)
+        out["cpu_baseline"] = {"value": spmm_per_step * nnz / t_step, "unit": "edges/s", "cores": torch.get_num_threads(),
+                               "kind": "port",
+                               "sample": f"{len(ts)} timed steps (median) of the same workload after 1 warm-up, "
+                                         f"torch {torch.__version__} CPU, torch.sparse.mm COO fp32",
+                               "s_per_step": t_step, "epoch_time_s": t_step * steps_per_epoch,
+                               "spmm_kernel_edges_per_s": nnz / t_spmm, "host_cpus": os.cpu_count()}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

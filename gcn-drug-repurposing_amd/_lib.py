@@ -62,8 +62,15 @@ SIGNATURES = {
     "gss_plan_device_bytes": (_SZ, [_P]),
     "gss_plan_set_step": (None, [_P, _I32]),
     "gss_plan_get_step": (_I32, [_P]),
+    "gss_plan_profile": (C.c_int, [_P, C.c_int]),
+    "gss_plan_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), _P]),
+    "gss_debug_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "gss_memcpy_d2d": (C.c_int, [_P, _P, _SZ, _P]),
 }
+
+
+PROF_CLASSES = ("spmm_fwd_hadamard", "spmm_fwd", "spmm_bwd1", "spmm_bwd2", "dense_fwd", "dgrad", "wgrad", "wgrad_batch",
+                "loss", "rownorm", "elementwise", "adam")
 
 
 def build(verbose: bool = False) -> str:

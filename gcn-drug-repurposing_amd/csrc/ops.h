@@ -1,5 +1,7 @@
 // ops.h -- internal launchers shared between the per-op C entry points and the plan.
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 struct gss_csr {
@@ -10,6 +12,9 @@ struct gss_csr {
   int32_t n_long;
   int32_t *d_long_rows;
   int32_t max_row;
+  std::vector<int32_t> h_rowptr;  // host copy, used to build segment descriptors lazily
+  int32_t *d_segs[5];             // balanced SpMM: int4 descriptors per lane group, by log2(groups per wave)
+  int32_t n_seg_blocks[5];
 };
 
 namespace gss {

@@ -28,11 +28,46 @@ struct gss_plan {
   void *loss_ws, *wgrad_ws;
   int32_t step;
   bool layer1_valid;
+  // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
+  bool prof_on;
+  std::vector<hipEvent_t> ev;      // pairs: 2 k = start, 2 k + 1 = stop
+  std::vector<int> ev_cls;
+  size_t ev_used;
+  double prof_ms[GSS_PROF_CLASSES];
+  int64_t prof_cnt[GSS_PROF_CLASSES];
 };
 
 using namespace gss;
 
 namespace {
+// RAII pair of events around one launcher call
+struct ProfScope {
+  gss_plan *p;
+  hipStream_t st;
+  size_t slot;
+  bool on;
+  ProfScope(gss_plan *plan, int cls, void *stream) : p(plan), st(as_stream(stream)), slot(0), on(plan->prof_on) {
+    if (!on) return;
+    if (p->ev_used * 2 + 2 > p->ev.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        on = false;
+        return;
+      }
+      p->ev.push_back(a);
+      p->ev.push_back(b);
+      p->ev_cls.push_back(cls);
+    }
+    slot = p->ev_used++;
+    p->ev_cls[slot] = cls;
+    (void)hipEventRecord(p->ev[2 * slot], st);
+  }
+  ~ProfScope() {
+    if (on) (void)hipEventRecord(p->ev[2 * slot + 1], st);
+  }
+};
+#define PROF(cls) ProfScope prof_scope_##__LINE__(p, cls, stream)
+
 struct Carver {
   size_t off = 0;
   char *base = nullptr;
@@ -122,6 +157,12 @@ int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a,
   p->grad[3] = io->gb2;
   p->step = 0;
   p->layer1_valid = false;
+  p->prof_on = false;
+  p->ev_used = 0;
+  for (int k = 0; k < GSS_PROF_CLASSES; ++k) {
+    p->prof_ms[k] = 0.0;
+    p->prof_cnt[k] = 0;
+  }
   Carver sizing;
   carve(p, sizing);
   p->slab_bytes = sizing.off + 256;
@@ -146,6 +187,7 @@ int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a,
 
 void gss_plan_destroy(gss_plan *p) {
   if (!p) return;
+  for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   if (p->slab) (void)hipFree(p->slab);
   delete p;
 }
@@ -159,16 +201,24 @@ int gss_plan_forward(gss_plan *p, void *stream) {
     const bool cached = (l == 0 && D.cache_layer1 && p->layer1_valid);
     if (!cached) {
       // AX = A x ; M = AX (.) x      (model.py:163,168)
-      if (int rc = spmm_fwd(p->a, D.d, xl, p->ax[l], xl, p->m_tmp, stream)) return rc;
+      {
+        PROF(GSS_PROF_SPMM_FWD_HAD);
+        if (int rc = spmm_fwd(p->a, D.d, xl, p->ax[l], xl, p->m_tmp, stream)) return rc;
+      }
       // AM = A M                      (model.py:169)
-      if (int rc = spmm_fwd(p->a, D.d, p->m_tmp, p->am[l], nullptr, nullptr, stream)) return rc;
+      {
+        PROF(GSS_PROF_SPMM_FWD);
+        if (int rc = spmm_fwd(p->a, D.d, p->m_tmp, p->am[l], nullptr, nullptr, stream)) return rc;
+      }
       if (l == 0) p->layer1_valid = true;
     }
     float *xn = (l == L - 1) ? p->x_last : p->xin[l + 1];
+    PROF(GSS_PROF_DENSE_FWD);
     if (int rc = dense_fwd(D.n, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr,
                            D.layer_decay, p->p[l], xn, stream))
       return rc;
   }
+  PROF(GSS_PROF_ROWNORM);
   return rownorm_fwd(D.n, D.d, p->x_last, p->emb, p->inv_den, stream);
 }
 
@@ -176,7 +226,10 @@ int gss_plan_loss_backward(gss_plan *p, const int32_t *idx, int32_t b, float bet
   GSS_REQUIRE(p && idx, "plan_loss_backward: null argument");
   const gss_plan_desc &D = p->desc;
   GSS_REQUIRE(b >= 1 && b <= D.max_batch, "plan_loss_backward: batch %d out of [1, %d]", b, D.max_batch);
-  if (int rc = loss_fwd_bwd(D.n, D.d, p->emb, idx, b, beta, D.alpha, p->loss, p->de_b, p->loss_ws, stream)) return rc;
+  {
+    PROF(GSS_PROF_LOSS);
+    if (int rc = loss_fwd_bwd(D.n, D.d, p->emb, idx, b, beta, D.alpha, p->loss, p->de_b, p->loss_ws, stream)) return rc;
+  }
   return gss_plan_backward(p, idx, b, nullptr, stream);
 }
 
@@ -189,29 +242,56 @@ int gss_plan_backward(gss_plan *p, const int32_t *idx, int32_t b, const float *d
   const float *de_b = de_rows ? de_rows : p->de_b;
   // top layer, batch rows only
   const float c_top = L > 1 ? D.layer_decay : 1.f;
-  if (int rc = rownorm_elu_bwd(D.d, de_b, idx, b, p->emb, p->inv_den, p->p[L - 1], c_top, p->dx_b, p->dp_b, stream)) return rc;
-  if (int rc = dense_bwd_weight(b, D.d, p->dp_b, p->ax[L - 1], p->am[L - 1], idx, p->grad[0], p->grad[2], p->grad[1], 0,
-                                p->wgrad_ws, stream))
-    return rc;
+  {
+    PROF(GSS_PROF_ELEMENTWISE);
+    if (int rc = rownorm_elu_bwd(D.d, de_b, idx, b, p->emb, p->inv_den, p->p[L - 1], c_top, p->dx_b, p->dp_b, stream)) return rc;
+  }
+  {
+    PROF(GSS_PROF_WGRAD_BATCH);
+    if (int rc = dense_bwd_weight(b, D.d, p->dp_b, p->ax[L - 1], p->am[L - 1], idx, p->grad[0], p->grad[2], p->grad[1], 0,
+                                  p->wgrad_ws, stream))
+      return rc;
+  }
   if (L > 1) {
     const size_t nd_bytes = sizeof(float) * (size_t)D.n * D.d;
-    if (int rc = transpose2(D.d, p->w1, p->w2, p->w1t, p->w2t, stream)) return rc;
-    GSS_HIP(hipMemsetAsync(p->g_ax, 0, nd_bytes, st));
-    GSS_HIP(hipMemsetAsync(p->g_am, 0, nd_bytes, st));
-    if (int rc = dense_bwd_input(b, D.d, p->dp_b, p->w1t, p->w2t, idx, p->g_ax, p->g_am, stream)) return rc;
-    if (int rc = spmm_bwd1(p->at, D.d, p->g_am, p->g_ax, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream)) return rc;
+    {
+      PROF(GSS_PROF_ELEMENTWISE);
+      if (int rc = transpose2(D.d, p->w1, p->w2, p->w1t, p->w2t, stream)) return rc;
+      GSS_HIP(hipMemsetAsync(p->g_ax, 0, nd_bytes, st));
+      GSS_HIP(hipMemsetAsync(p->g_am, 0, nd_bytes, st));
+    }
+    {
+      PROF(GSS_PROF_DGRAD);
+      if (int rc = dense_bwd_input(b, D.d, p->dp_b, p->w1t, p->w2t, idx, p->g_ax, p->g_am, stream)) return rc;
+    }
+    {
+      PROF(GSS_PROF_SPMM_BWD1);
+      if (int rc = spmm_bwd1(p->at, D.d, p->g_am, p->g_ax, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream)) return rc;
+    }
     for (int lp = L - 2; lp >= 0; --lp) {
       const float c = lp == 0 ? 1.f : D.layer_decay;
       const float *res = (lp + 2 <= L - 1) ? p->gx[(lp + 2) & 1] : nullptr;
       float *gx_out = (lp >= 1 && L > 2) ? p->gx[(lp + 1) & 1] : nullptr;
-      if (int rc = spmm_bwd2(p->at, D.d, p->u, p->t, p->p[lp], c, res, p->dp, gx_out, stream)) return rc;
-      if (lp + 2 == L)
+      {
+        PROF(GSS_PROF_SPMM_BWD2);
+        if (int rc = spmm_bwd2(p->at, D.d, p->u, p->t, p->p[lp], c, res, p->dp, gx_out, stream)) return rc;
+      }
+      if (lp + 2 == L) {
+        PROF(GSS_PROF_ELEMENTWISE);
         if (int rc = scatter_add_rows(D.d, p->dx_b, idx, b, p->dp, stream)) return rc;
-      if (int rc = dense_bwd_weight(D.n, D.d, p->dp, p->ax[lp], p->am[lp], nullptr, p->grad[0], p->grad[2], p->grad[1], 1,
-                                    p->wgrad_ws, stream))
-        return rc;
+      }
+      {
+        PROF(GSS_PROF_WGRAD);
+        if (int rc = dense_bwd_weight(D.n, D.d, p->dp, p->ax[lp], p->am[lp], nullptr, p->grad[0], p->grad[2], p->grad[1], 1,
+                                      p->wgrad_ws, stream))
+          return rc;
+      }
       if (lp >= 1) {
-        if (int rc = dense_bwd_input(D.n, D.d, p->dp, p->w1t, p->w2t, nullptr, p->g_ax, p->g_am, stream)) return rc;
+        {
+          PROF(GSS_PROF_DGRAD);
+          if (int rc = dense_bwd_input(D.n, D.d, p->dp, p->w1t, p->w2t, nullptr, p->g_ax, p->g_am, stream)) return rc;
+        }
+        PROF(GSS_PROF_SPMM_BWD1);
         if (int rc = spmm_bwd1(p->at, D.d, p->g_am, p->g_ax, p->xin[lp], p->ax[lp], p->u, p->t, stream)) return rc;
       }
     }
@@ -225,6 +305,7 @@ int gss_plan_adam(gss_plan *p, void *stream) {
   GSS_REQUIRE(p, "plan_adam: null plan");
   const gss_plan_desc &D = p->desc;
   p->step += 1;
+  PROF(GSS_PROF_ADAM);
   float *params[4] = {p->w1, p->b1, p->w2, p->b2};
   const int64_t cnt[4] = {(int64_t)D.d * D.d, D.d, (int64_t)D.d * D.d, D.d};
   for (int k = 0; k < 4; ++k)
@@ -249,6 +330,31 @@ void gss_plan_set_step(gss_plan *p, int32_t step) {
   if (p) p->step = step;
 }
 int32_t gss_plan_get_step(const gss_plan *p) { return p ? p->step : 0; }
+int gss_plan_profile(gss_plan *p, int enable) {
+  GSS_REQUIRE(p, "plan_profile: null plan");
+  p->prof_on = enable != 0;
+  return GSS_OK;
+}
+
+int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void *stream) {
+  GSS_REQUIRE(p && ms_out && count_out, "plan_profile_read: null argument");
+  GSS_HIP(hipStreamSynchronize(as_stream(stream)));
+  for (size_t k = 0; k < p->ev_used; ++k) {
+    float ms = 0.f;
+    GSS_HIP(hipEventElapsedTime(&ms, p->ev[2 * k], p->ev[2 * k + 1]));
+    p->prof_ms[p->ev_cls[k]] += ms;
+    p->prof_cnt[p->ev_cls[k]] += 1;
+  }
+  p->ev_used = 0;
+  for (int k = 0; k < GSS_PROF_CLASSES; ++k) {
+    ms_out[k] = p->prof_ms[k];
+    count_out[k] = p->prof_cnt[k];
+    p->prof_ms[k] = 0.0;
+    p->prof_cnt[k] = 0;
+  }
+  return GSS_OK;
+}
+
 int gss_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream) {
   GSS_REQUIRE(dst && src, "memcpy_d2d: null pointer");
   GSS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));

@@ -14,6 +14,9 @@
 //
 // Roofline: HBM-bound.  Algorithmic bytes per launch = 8 nnz + 4 (N+1) + 4 N d (X once) + 4 N d (Y),
 // plus 4 N d per extra epilogue operand/output.
+#include <algorithm>
+#include <vector>
+
 #include "ops.h"
 
 namespace gss {
@@ -175,6 +178,128 @@ __global__ __launch_bounds__(kLongThreads) void spmm_long_kernel(CsrView a, cons
   }
 }
 
+
+// ---- variant 2 (default): nnz-balanced segments, whole-row gathers -------------------------------------
+//
+// Degrees are heavy-tailed (at config 2, 9 % of the rows hold 47 % of the entries and hubs reach thousands),
+// so the row-per-wave mapping above ends on a few overloaded waves: rocprofv3 shows its waves alive for 46k
+// cycles on average in a 190k-cycle kernel.  Measured dead end, for the record: cutting the feature dimension
+// into 64-byte slices pinned to one XCD's L2 balances perfectly but triples the L2 request count (64-B
+// requests) and ran slower (111 us vs 90 us at d = 128) -- gathers must stay whole 128-B lines.
+//
+// Here the host cuts every row into segments of <= kSegEdges entries (build_segments, once per feature width)
+// and packs them into a descriptor list, one descriptor per lane group; a lane group is the LPR lanes that
+// cover one feature row (32 lanes x float4 = 512 B at d = 128).  A row with s segments occupies an aligned
+// block of p = pow2ceil(s) consecutive groups of one 1024-thread workgroup (16 waves); rows too long for that
+// take the whole workgroup with longer segments.  Each group loads its segment's (col,val) pairs with one
+// coalesced access, broadcasts them with ds_bpermute and keeps 8 row gathers in flight.  Partial sums are
+// combined with xor-shuffles inside a wave and through LDS across the waves of a row's block, always in the
+// same order -> bitwise reproducible, no atomics, no second pass.
+constexpr int kSegEdges = 32;
+constexpr int kBalThreads = 1024;
+constexpr int kBalWaves = kBalThreads / 64;
+
+template <int MODE, int LPR_LOG2, int VPL>
+__global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, const int4 *__restrict__ segs, int d4,
+                                                                   const float *__restrict__ x, SpmmEpi ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *part = reinterpret_cast<float4 *>(smem);  // [16 waves][d4]
+  constexpr int LPR = 1 << LPR_LOG2;
+  constexpr int GPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int g = lane >> LPR_LOG2;
+  const int li = lane & (LPR - 1);
+  const int4 sd = segs[((size_t)blockIdx.x * kBalWaves + wib) * GPW + g];  // {row, first edge, edge count, flags | log2 p}
+  const int row = sd.x;
+  const int e0 = sd.y, e1 = sd.y + sd.z;
+  const int plog = sd.w & 0xff;
+  const bool multiwave = (sd.w & 0x100) != 0;  // workgroup-uniform: some row of this workgroup spans several waves
+  const bool col_ok = (VPL > 1) || (li < d4);
+  const size_t rowstride = (size_t)d4 * 4;
+  float4 acc[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int base = e0; __any(base < e1); base += LPR) {
+    const int ce = base + li;
+    int c = 0;
+    float w = 0.f;
+    if (ce < e1) {
+      c = a.col[ce];
+      w = a.val[ce];
+    }
+    const int cnt = min(LPR, e1 - base);  // <= 0 once this group is done
+    for (int t = 0; __any(t < cnt); t += 8) {
+      float4 xv[8][VPL];
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int src = (g << LPR_LOG2) + ((t + u) & (LPR - 1));
+        const int cc = __shfl(c, src, 64);
+        wv[u] = __shfl(w, src, 64);
+        const bool ok = (t + u < cnt) && col_ok;
+        if (!ok) wv[u] = 0.f;
+        const float *xr = x + (size_t)cc * rowstride;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int f4 = li + v * 64;
+          xv[u][v] = (ok && (VPL == 1 || f4 < d4)) ? ld4(xr + (size_t)f4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) acc[v] = fma4(wv[u], xv[u][v], acc[v]);
+    }
+  }
+  // combine the groups of a row inside the wave (aligned power-of-two block of groups)
+  const int pcount = 1 << plog;
+#pragma unroll
+  for (int o = 1; o < GPW; o <<= 1) {
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const float tx = __shfl_xor(acc[v].x, o * LPR, 64), ty = __shfl_xor(acc[v].y, o * LPR, 64);
+      const float tz = __shfl_xor(acc[v].z, o * LPR, 64), tw = __shfl_xor(acc[v].w, o * LPR, 64);
+      if (pcount > o) {
+        acc[v].x += tx;
+        acc[v].y += ty;
+        acc[v].z += tz;
+        acc[v].w += tw;
+      }
+    }
+  }
+  if (pcount <= GPW) {
+    if (row >= 0 && (g & (pcount - 1)) == 0) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const int f4 = li + v * 64;
+        if (f4 < d4) row_epilogue<MODE>(ep, ((size_t)row * d4 + f4) * 4, acc[v]);
+      }
+    }
+  }
+  if (!multiwave) return;
+  // rows spanning nw = p / GPW waves: wave sums meet in LDS, the row's first wave adds them in wave order
+  const int nw = pcount > GPW ? pcount / GPW : 1;
+  if (nw > 1 && g == 0) {
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int f4 = li + v * 64;
+      if (f4 < d4) part[wib * d4 + f4] = acc[v];
+    }
+  }
+  __syncthreads();
+  if (nw > 1 && (wib & (nw - 1)) == 0 && g == 0 && row >= 0) {
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int f4 = li + v * 64;
+      if (f4 >= d4) continue;
+      float4 t = part[wib * d4 + f4];
+      for (int k = 1; k < nw; ++k) t = add4(t, part[(wib + k) * d4 + f4]);
+      row_epilogue<MODE>(ep, ((size_t)row * d4 + f4) * 4, t);
+    }
+  }
+}
+
 template <int MODE, int LPR_LOG2, int VPL>
 static int launch_spmm_t(const gss_csr *a, int d4, const float *x, const SpmmEpi &ep, hipStream_t st);
 
@@ -200,12 +325,104 @@ static int launch_spmm_t(const gss_csr *a, int d4, const float *x, const SpmmEpi
   return GSS_OK;
 }
 
+int g_spmm_variant = 2;
+
+// Segment descriptors for the balanced kernel, built on first use for a given groups-per-wave count.
+static int build_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks) {
+  gss_csr *m = const_cast<gss_csr *>(a);  // lazily filled cache; a gss_csr is used from one host thread
+  if (m->d_segs[gpw_log2]) {
+    *out = (const int4 *)m->d_segs[gpw_log2];
+    *n_blocks = m->n_seg_blocks[gpw_log2];
+    return GSS_OK;
+  }
+  const int gpw = 1 << gpw_log2;
+  const int ngb = kBalWaves * gpw;  // groups per workgroup
+  int ngb_log2 = 0;
+  while ((1 << ngb_log2) < ngb) ++ngb_log2;
+  const int32_t *rp = m->h_rowptr.data();
+  struct RowItem {
+    int32_t row, len, plog;
+  };
+  std::vector<RowItem> items;
+  items.reserve((size_t)a->n_rows);
+  for (int32_t r = 0; r < a->n_rows; ++r) {
+    const int32_t len = rp[r + 1] - rp[r];
+    const int sgm = len <= kSegEdges ? 1 : (len + kSegEdges - 1) / kSegEdges;
+    int plog = 0;
+    while ((1 << plog) < sgm && plog < ngb_log2) ++plog;  // longer rows: whole workgroup, longer segments
+    items.push_back({r, len, plog});
+  }
+  std::stable_sort(items.begin(), items.end(), [](const RowItem &x, const RowItem &y) {
+    return x.plog != y.plog ? x.plog > y.plog : x.len > y.len;
+  });
+  std::vector<int32_t> segs;
+  segs.reserve(((size_t)a->n_rows + (size_t)a->nnz / kSegEdges + 2 * ngb) * 4);
+  for (const RowItem &it : items) {  // sizes are non-increasing powers of two: blocks stay aligned
+    const int p = 1 << it.plog;
+    const int per = (it.len + p - 1) / p;
+    for (int k = 0; k < p; ++k) {
+      const int b0 = std::min(it.len, k * per), b1 = std::min(it.len, (k + 1) * per);
+      segs.push_back(it.row);
+      segs.push_back(rp[it.row] + b0);
+      segs.push_back(b1 - b0);
+      segs.push_back(it.plog);
+    }
+  }
+  while ((segs.size() / 4) % ngb != 0) {
+    segs.push_back(-1);
+    segs.push_back(0);
+    segs.push_back(0);
+    segs.push_back(0);
+  }
+  const int nblk = (int)(segs.size() / 4 / ngb);
+  for (int bi = 0; bi < nblk; ++bi) {  // flag workgroups that need the LDS step
+    bool multi = false;
+    for (int k = 0; k < ngb; ++k) multi |= (1 << segs[((size_t)bi * ngb + k) * 4 + 3]) > gpw;
+    if (multi)
+      for (int k = 0; k < ngb; ++k) segs[((size_t)bi * ngb + k) * 4 + 3] |= 0x100;
+  }
+  const size_t bytes = segs.size() * sizeof(int32_t);
+  if (bytes) {
+    GSS_HIP(hipMalloc((void **)&m->d_segs[gpw_log2], bytes));
+    GSS_HIP(hipMemcpy(m->d_segs[gpw_log2], segs.data(), bytes, hipMemcpyHostToDevice));
+  }
+  m->n_seg_blocks[gpw_log2] = nblk;
+  *out = (const int4 *)m->d_segs[gpw_log2];
+  *n_blocks = nblk;
+  return GSS_OK;
+}
+
+template <int MODE, int LPR_LOG2, int VPL>
+static int launch_balanced_t(const gss_csr *a, int d4, const float *x, const SpmmEpi &ep, hipStream_t st) {
+  const int4 *segs = nullptr;
+  int nblk = 0;
+  if (int rc = build_segments(a, 6 - LPR_LOG2, &segs, &nblk)) return rc;
+  if (nblk == 0) return GSS_OK;
+  CsrView v{a->rowptr, a->col, a->val, a->n_rows};
+  const size_t lds = (size_t)kBalWaves * d4 * sizeof(float4);
+  hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL>), dim3(nblk), dim3(kBalThreads), lds, st, v, segs, d4, x, ep);
+  GSS_LAUNCH_CHECK("spmm_balanced_kernel");
+  return GSS_OK;
+}
+
+template <int MODE>
+static int launch_balanced(const gss_csr *a, int d4, const float *x, const SpmmEpi &ep, hipStream_t st) {
+  if (d4 <= 4) return launch_balanced_t<MODE, 2, 1>(a, d4, x, ep, st);
+  if (d4 <= 8) return launch_balanced_t<MODE, 3, 1>(a, d4, x, ep, st);
+  if (d4 <= 16) return launch_balanced_t<MODE, 4, 1>(a, d4, x, ep, st);
+  if (d4 <= 32) return launch_balanced_t<MODE, 5, 1>(a, d4, x, ep, st);
+  if (d4 <= 64) return launch_balanced_t<MODE, 6, 1>(a, d4, x, ep, st);
+  if (d4 <= 128) return launch_balanced_t<MODE, 6, 2>(a, d4, x, ep, st);
+  return launch_balanced_t<MODE, 6, 4>(a, d4, x, ep, st);
+}
+
 template <int MODE>
 static int launch_spmm(const gss_csr *a, int32_t d, const float *x, const SpmmEpi &ep, void *stream) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(a && x, "spmm: null operand");
   hipStream_t st = as_stream(stream);
   const int d4 = d / 4;
+  if (g_spmm_variant == 2) return launch_balanced<MODE>(a, d4, x, ep, st);
   if (d4 <= 4) return launch_spmm_t<MODE, 2, 1>(a, d4, x, ep, st);
   if (d4 <= 8) return launch_spmm_t<MODE, 3, 1>(a, d4, x, ep, st);
   if (d4 <= 16) return launch_spmm_t<MODE, 4, 1>(a, d4, x, ep, st);
@@ -308,6 +525,10 @@ int gss_csr_create(gss_csr **out, int32_t n_rows, int32_t n_cols, int64_t nnz, c
   a->n_long = 0;
   a->d_long_rows = nullptr;
   a->max_row = 0;
+  for (int k = 0; k < 5; ++k) {
+    a->d_segs[k] = nullptr;
+    a->n_seg_blocks[k] = 0;
+  }
   int32_t *h_long = nullptr;
   int n_long = 0;
   for (int pass = 0; pass < 2; ++pass) {
@@ -341,6 +562,7 @@ int gss_csr_create(gss_csr **out, int32_t n_rows, int32_t n_cols, int64_t nnz, c
     }
     a->n_long = n_long;
   }
+  a->h_rowptr.assign(h_rowptr, h_rowptr + (size_t)n_rows + 1);
   *out = a;
   return GSS_OK;
 }
@@ -348,7 +570,19 @@ int gss_csr_create(gss_csr **out, int32_t n_rows, int32_t n_cols, int64_t nnz, c
 void gss_csr_destroy(gss_csr *a) {
   if (!a) return;
   if (a->d_long_rows) (void)hipFree(a->d_long_rows);
+  for (int k = 0; k < 5; ++k)
+    if (a->d_segs[k]) (void)hipFree(a->d_segs[k]);
   delete a;
+}
+
+int gss_debug_set_option(const char *name, int value) {
+  GSS_REQUIRE(name, "debug_set_option: null name");
+  if (strcmp(name, "spmm_variant") == 0) {
+    GSS_REQUIRE(value == 1 || value == 2, "spmm_variant must be 1 or 2");
+    g_spmm_variant = value;
+    return GSS_OK;
+  }
+  return fail(GSS_EINVAL, "unknown option %s", name);
 }
 
 int gss_spmm(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream) {

@@ -45,11 +45,12 @@ class GssEngine:
         _lib.check(self.lib.gss_plan_create(C.byref(h), C.byref(self.desc), graph.a.handle,
                                             graph.at.handle if graph.at is not None else None, C.byref(io)), "gss_plan_create")
         self.handle = h
+        self._destroy = self.lib.gss_plan_destroy
 
     def __del__(self):
         h = getattr(self, "handle", None)
         if h is not None and h.value:
-            self.lib.gss_plan_destroy(h)
+            self._destroy(h)
             self.handle = None
 
     def params_moved(self):
@@ -92,6 +93,17 @@ class GssEngine:
         out = torch.empty(self.n, self.d, dtype=torch.float32, device=self.x.device)
         _lib.check(self.lib.gss_memcpy_d2d(out.data_ptr(), src, out.numel() * 4, _lib.current_stream()), "gss_memcpy_d2d")
         return out
+
+    def profile(self, enable=True):
+        _lib.check(self.lib.gss_plan_profile(self.handle, 1 if enable else 0), "gss_plan_profile")
+
+    def profile_read(self):
+        """-> {class: (total_ms, launches)} since the last read (synchronises the stream)"""
+        k = len(_lib.PROF_CLASSES)
+        ms = (C.c_double * k)()
+        cnt = (C.c_int64 * k)()
+        _lib.check(self.lib.gss_plan_profile_read(self.handle, ms, cnt, _lib.current_stream()), "gss_plan_profile_read")
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(_lib.PROF_CLASSES)}
 
     def device_bytes(self) -> int:
         return int(self.lib.gss_plan_device_bytes(self.handle))

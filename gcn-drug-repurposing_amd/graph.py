@@ -74,11 +74,12 @@ class DeviceCSR:
         _lib.check(lib.gss_csr_create(C.byref(h), self.n_rows, self.n_cols, self.nnz, self.h_indptr.ctypes.data,
                                       self.rowptr.data_ptr(), self.col.data_ptr(), self.val.data_ptr()), "gss_csr_create")
         self.handle = h
+        self._destroy = lib.gss_csr_destroy   # bound now: module globals may be gone at interpreter shutdown
 
     def __del__(self):
         h = getattr(self, "handle", None)
         if h is not None and h.value:
-            _lib.load().gss_csr_destroy(h)
+            self._destroy(h)
             self.handle = None
 
     def to_scipy(self):

@@ -162,6 +162,29 @@ size_t gss_plan_device_bytes(const gss_plan *p);
 /* set the 1-based Adam step counter (resume) / read it */
 void gss_plan_set_step(gss_plan *p, int32_t step);
 int32_t gss_plan_get_step(const gss_plan *p);
+/* Per-kernel-class timing with HIP events recorded on the caller's stream around every launch of a
+ * plan call (bench.py's live roofline measurement).  gss_plan_profile_read synchronises the stream, returns
+ * the accumulated milliseconds and launch counts per class (arrays of GSS_PROF_CLASSES) and resets them. */
+enum {
+  GSS_PROF_SPMM_FWD_HAD = 0, /* AX = A x with fused Hadamard epilogue */
+  GSS_PROF_SPMM_FWD = 1,     /* AM = A M */
+  GSS_PROF_SPMM_BWD1 = 2,
+  GSS_PROF_SPMM_BWD2 = 3,
+  GSS_PROF_DENSE_FWD = 4,
+  GSS_PROF_DGRAD = 5,
+  GSS_PROF_WGRAD = 6,        /* N-row weight gradient (+ its reduce) */
+  GSS_PROF_WGRAD_BATCH = 7,  /* batch-row weight gradient of the top layer */
+  GSS_PROF_LOSS = 8,
+  GSS_PROF_ROWNORM = 9,
+  GSS_PROF_ELEMENTWISE = 10, /* norm/ELU backward on batch rows, transposes, memsets, scatter */
+  GSS_PROF_ADAM = 11,
+  GSS_PROF_CLASSES = 12
+};
+int gss_plan_profile(gss_plan *p, int enable);
+int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void *stream);
+/* tuning/debug knobs (A/B runs inside one process): "spmm_variant" = 1 (whole-row gather, wave per row) or
+ * 2 (feature-sliced, XCD-L2-resident gather; default) */
+int gss_debug_set_option(const char *name, int value);
 /* plain device-to-device copy on `stream` (lets a ctypes host read plan-owned activations) */
 int gss_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
 

@@ -88,8 +88,15 @@ def test_spmm_row_sums_within_1e5(G, op_case):
 
 
 # ---------------------------------------------------------------- K1 / K2 / K9
+@pytest.fixture(params=[1, 2])
+def spmm_variant(request, G):
+    G._lib.check(G.lib.gss_debug_set_option(b"spmm_variant", request.param))
+    yield request.param
+    G._lib.check(G.lib.gss_debug_set_option(b"spmm_variant", 2))
+
+
 @pytest.mark.parametrize("d", [16, 48, 64, 128, 256, 512, 1024])
-def test_spmm_all_widths_with_hub_and_empty_rows(G, d):
+def test_spmm_all_widths_with_hub_and_empty_rows(G, d, spmm_variant):
     rng = np.random.RandomState(d)
     n = 1500
     a = random_graph(rng, n, 7, hub_rows=(3, 700), hub_deg=1200, empty_rows=(0, 11, n - 1))
@@ -111,7 +118,7 @@ def test_spmm_all_widths_with_hub_and_empty_rows(G, d):
     assert torch.equal(y, y2)  # bitwise reproducible, with and without the fused epilogue
 
 
-def test_spmm_backward_epilogues(G):
+def test_spmm_backward_epilogues(G, spmm_variant):
     rng = np.random.RandomState(5)
     n, d = 900, 128
     a = random_graph(rng, n, 9, hub_rows=(5,), hub_deg=700)
