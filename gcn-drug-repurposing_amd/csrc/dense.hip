@@ -64,41 +64,55 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
     for (int u = 0; u < FT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // operand row pointers for both halves of K (k < ksplit from in0 / w[.][0], the rest from in1 / w[.][1])
+  const float *bp[2][2];
+  const float *ap[2][FT];
+#pragma unroll
   for (int kh = 0; kh < 2; ++kh) {
-    const int kbeg = kh ? g.ksplit : 0;
-    const int kend = kh ? g.K : g.ksplit;
-    if (kbeg >= kend) continue;
     const float *in = kh ? g.in1 : g.in0;
     const int ld = kh ? g.ld_in1 : g.ld_in0;
     const float *w = g.w[jh][kh];
-    const float *bp[2];
-    bp[0] = in + (size_t)node[0] * ld + 4 * q;
-    bp[1] = in + (size_t)node[1] * ld + 4 * q;
-    const float *ap[FT];
 #pragma unroll
-    for (int u = 0; u < FT; ++u) ap[u] = w + (size_t)(jrow0 + 16 * u + r) * g.ld_w + 4 * q;
-    const int klen = kend - kbeg;
+    for (int t = 0; t < 2; ++t) bp[kh][t] = in ? in + (size_t)node[t] * ld + 4 * q : nullptr;
+#pragma unroll
+    for (int u = 0; u < FT; ++u) ap[kh][u] = w ? w + (size_t)(jrow0 + 16 * u + r) * g.ld_w + 4 * q : nullptr;
+  }
+  const int nchunk = g.K / 16;
+  const int csplit = g.ksplit / 16;
 
-    for (int kc = 0; kc < klen; kc += 16) {
-      float4 b[2], a[FT];
-      b[0] = ld4(bp[0] + kc);
-      b[1] = ld4(bp[1] + kc);
+  auto load_chunk = [&](int ci, float4 (&b)[2], float4 (&a)[FT]) {
+    const int kh = ci >= csplit ? 1 : 0;
+    const int off = (ci - (kh ? csplit : 0)) * 16;
+    b[0] = ld4(bp[kh][0] + off);
+    b[1] = ld4(bp[kh][1] + off);
 #pragma unroll
-      for (int u = 0; u < FT; ++u) a[u] = ld4(ap[u] + kc);
+    for (int u = 0; u < FT; ++u) a[u] = ld4(ap[kh][u] + off);
+  };
+  auto mma_chunk = [&](const float4 (&b)[2], const float4 (&a)[FT]) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 4; ++e) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const float bv = e == 0 ? b[t].x : e == 1 ? b[t].y : e == 2 ? b[t].z : b[t].w;
+      for (int t = 0; t < 2; ++t) {
+        const float bv = e == 0 ? b[t].x : e == 1 ? b[t].y : e == 2 ? b[t].z : b[t].w;
 #pragma unroll
-          for (int u = 0; u < FT; ++u) {
-            const float av = e == 0 ? a[u].x : e == 1 ? a[u].y : e == 2 ? a[u].z : a[u].w;
-            acc[t][u] = mfma16(av, bv, acc[t][u]);
-          }
+        for (int u = 0; u < FT; ++u) {
+          const float av = e == 0 ? a[u].x : e == 1 ? a[u].y : e == 2 ? a[u].z : a[u].w;
+          acc[t][u] = mfma16(av, bv, acc[t][u]);
         }
       }
     }
+  };
+  // register double buffer: the loads of chunk c+1 are in flight under the 8*FT MFMAs of chunk c
+  float4 b0[2], a0[FT], b1[2], a1[FT];
+  load_chunk(0, b0, a0);
+  int ci = 0;
+  for (; ci + 2 <= nchunk; ci += 2) {
+    load_chunk(ci + 1, b1, a1);
+    mma_chunk(b0, a0);
+    if (ci + 2 < nchunk) load_chunk(ci + 2, b0, a0);
+    mma_chunk(b1, a1);
   }
+  if (ci < nchunk) mma_chunk(b0, a0);
 
   // epilogue: lane (r, q) holds OUT[node0 + 16 t + r][j0 + 16 u + 4 q + 0..3]
 #pragma unroll
@@ -128,11 +142,182 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
   }
 }
 
+// ---- LDS-staged variant (default) -----------------------------------------------------------------------
+// Workgroup tile = 128 nodes x BN features (BN = 16 NT), 4 waves of 32 nodes x BN.  Per 16-wide K chunk the
+// operands arrive by LDS-DMA (global_load_lds_dwordx4): one wave instruction moves one MFMA fragment block
+// -- 16 rows x 64 B = 1 KB -- and writes it lane-linear (lane l's 16 B at base + 16 l).  The consuming lane
+// has the same (row = l & 15, k = 4 (l >> 4)) role as the staging lane, so a fragment is read back with one
+// conflict-free ds_read_b128 at base + 16 l.  Two LDS buffers; the DMA of chunk c+1 is in flight under the
+// 8 NT MFMAs of chunk c; one barrier per chunk.  Compared with fetching fragments from L1/L2 per wave (the
+// kernel above, kept for A/B) this cuts L2->L1 traffic from ~48 to ~8 B/clk/CU.
+// LDS-DMA in inline asm: hipcc must not see these loads, otherwise it drains them (vmcnt(0)) before every
+// ds_read / barrier and the multi-chunk pipeline collapses (cdna guide section 5 'Pipelining across barriers').
+// M0 (the LDS destination base) is written in the same statement that uses it and restored afterwards.
+__device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_byte_addr)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NT, int MT, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BN = 16 * NT;
+  constexpr int BM = 64 * MT;              // nodes per workgroup (MT 16-node tiles per wave)
+  constexpr int XT = BM * 16;              // floats per X chunk tile
+  constexpr int BUF = XT + BN * 16;        // floats per buffer
+  constexpr int WG = (NT + 3) / 4;         // W fragment blocks staged per wave
+  constexpr int G = MT + WG;               // DMA instructions per wave and chunk (uniform over waves)
+  constexpr int NBUF = 4, PF = 3;          // chunks ci+1 .. ci+PF-1 stay in flight while chunk ci is consumed
+  float *lds = reinterpret_cast<float *>(smem);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int node_base = blockIdx.x * BM;
+  const int j0 = blockIdx.y * BN;
+  const int jh = j0 >= g.jsplit ? 1 : 0;
+  const int jrow0 = j0 - (jh ? g.jsplit : 0);
+
+  // staging sources of this lane: X fragment blocks w and w + 4, W fragment blocks (w + 4 i) mod NT
+  // (when NT < 4 some waves restage a block another wave also stages: same bytes, same place, and it keeps
+  // the per-wave DMA count G uniform so one counted vmcnt fits all waves)
+  const float *xsrc[2][MT];
+  const float *wsrc[2][WG];
+  int wblk[WG];
+#pragma unroll
+  for (int i = 0; i < WG; ++i) wblk[i] = (w + 4 * i) % NT;
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    const float *in = kh ? g.in1 : g.in0;
+    const int ld = kh ? g.ld_in1 : g.ld_in0;
+    const float *wp = g.w[jh][kh];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int node = min(g.n - 1, node_base + 16 * (w + 4 * i) + r);
+      xsrc[kh][i] = in ? in + (size_t)node * ld + 4 * q : nullptr;
+    }
+#pragma unroll
+    for (int i = 0; i < WG; ++i) wsrc[kh][i] = wp ? wp + (size_t)(jrow0 + 16 * wblk[i] + r) * g.ld_w + 4 * q : nullptr;
+  }
+  const int nchunk = g.K / 16;
+  const int csplit = g.ksplit / 16;
+  auto stage = [&](int ci) {
+    const int kh = ci >= csplit ? 1 : 0;
+    const int off = (ci - (kh ? csplit : 0)) * 16;
+    const unsigned buf = lds_base + (unsigned)((ci % NBUF) * BUF) * 4u;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) glds16(xsrc[kh][i] + off, buf + (unsigned)((w + 4 * i) * 1024));
+#pragma unroll
+    for (int i = 0; i < WG; ++i) glds16(wsrc[kh][i] + off, buf + (unsigned)(XT * 4 + wblk[i] * 1024));
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int u = 0; u < NT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int c = 0; c < PF && c < nchunk; ++c) stage(c);
+  for (int ci = 0; ci < nchunk; ++ci) {
+    // chunk ci has landed once at most min(PF-1, nchunk-1-ci) younger chunks of this wave are outstanding
+    const int younger = min(PF - 1, nchunk - 1 - ci);
+    if (younger >= 2)
+      wait_vmcnt<2 * G>();
+    else if (younger == 1)
+      wait_vmcnt<G>();
+    else
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // every wave's share of chunk ci is in LDS; buffer (ci-1)%NBUF is free again
+    const float *cur = lds + (ci % NBUF) * BUF;
+    float4 b[MT], a[NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) b[t] = *reinterpret_cast<const float4 *>(cur + (MT * w + t) * 256 + lane * 4);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) a[u] = *reinterpret_cast<const float4 *>(cur + XT + u * 256 + lane * 4);
+    if (ci + PF < nchunk) stage(ci + PF);  // into buffer (ci-1)%NBUF, last read before the barrier above
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const float bv = e == 0 ? b[t].x : e == 1 ? b[t].y : e == 2 ? b[t].z : b[t].w;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          const float av = e == 0 ? a[u].x : e == 1 ? a[u].y : e == 2 ? a[u].z : a[u].w;
+          acc[t][u] = mfma16(av, bv, acc[t][u]);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the MFMA cluster inside its iteration
+  }
+
+  // epilogue: lane (r, q) holds OUT[node_base + 16 (MT w + t) + r][j0 + 16 u + 4 q + 0..3]
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int nd = node_base + 16 * (MT * w + t) + r;
+    if (nd >= g.n) continue;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int j = j0 + 16 * u + 4 * q;
+      float4 v = make_float4(acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]);
+      if (EPI == EPI_FWD) {
+        const float4 bb = add4(ld4(g.b1 + j), ld4(g.b2 + j));
+        const float4 pv = add4(v, bb);
+        const size_t off = (size_t)nd * g.ld_out0 + j;
+        st4(g.out0 + off, pv);
+        float4 o = make_float4(elu1(pv.x), elu1(pv.y), elu1(pv.z), elu1(pv.w));
+        if (g.p_prev) o = add4(ld4(g.p_prev + off), scale4(g.decay, o));
+        st4(g.x_next + off, o);
+      } else {
+        const int orow = g.rows ? g.rows[nd] : nd;
+        if (jh == 0)
+          st4(g.out0 + (size_t)orow * g.ld_out0 + j, v);
+        else
+          st4(g.out1 + (size_t)orow * g.ld_out1 + (j - g.jsplit), v);
+      }
+    }
+  }
+}
+
+int g_gemm_variant = 2;
+
 template <int EPI>
 static int launch_gemm(const GemmArgs &g, int d, hipStream_t st) {
+  if (g.n <= 0) return GSS_OK;
+  if (g_gemm_variant >= 2) {
+    const int nt = (d % 128 == 0) ? 8 : (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
+    // 64-node tiles give 2-3 co-resident workgroups per CU (epilogue traffic overlaps MFMA); at d >= 256 the
+    // W-staging redundancy of small tiles costs more than that buys (measured, tools/gemm_bench.py)
+    const int mt = g_gemm_variant == 3 ? 2 : g_gemm_variant == 4 ? 1 : (d >= 256 ? 2 : 1);
+    dim3 grid(ceil_div(g.n, 64 * mt), g.J / (16 * nt));
+    const size_t lds = 4 * (size_t)(64 * mt * 16 + 16 * nt * 16) * sizeof(float);
+#define GSS_GEMM_CASE(NTV)                                                                              \
+  case NTV:                                                                                             \
+    if (mt == 2)                                                                                        \
+      hipLaunchKernelGGL((gemm_nt_lds_kernel<NTV, 2, EPI>), grid, dim3(256), lds, st, g);               \
+    else                                                                                                \
+      hipLaunchKernelGGL((gemm_nt_lds_kernel<NTV, 1, EPI>), grid, dim3(256), lds, st, g);               \
+    break;
+    switch (nt) {
+      GSS_GEMM_CASE(8)
+      GSS_GEMM_CASE(4)
+      GSS_GEMM_CASE(2)
+      default:
+        GSS_GEMM_CASE(1)
+    }
+#undef GSS_GEMM_CASE
+    GSS_LAUNCH_CHECK("gemm_nt_lds_kernel");
+    return GSS_OK;
+  }
   const int ft = (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
   dim3 grid(ceil_div(g.n, 128), g.J / (16 * ft));
-  if (g.n <= 0) return GSS_OK;
   if (ft == 4)
     hipLaunchKernelGGL((gemm_nt_kernel<4, EPI>), grid, dim3(256), 0, st, g);
   else if (ft == 2)
@@ -337,26 +522,48 @@ __global__ __launch_bounds__(256) void wgrad_simple_kernel(WgradArgs g) {
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int d, int nslices, const float *__restrict__ part_w,
                                                             const float *__restrict__ part_b, float *__restrict__ gw1,
-                                                            float *__restrict__ gw2, float *__restrict__ gb, int accumulate) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+                                                            float *__restrict__ gw2, float *__restrict__ gb, float *__restrict__ gb2,
+                                                            int accumulate) {
+  // 64 consecutive outputs per workgroup; wave w sums slices w, w+4, ... (4 loads in flight), LDS adds the 4
+  // wave sums in wave order -> fixed summation order
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + lane;
   const int nw = d * 2 * d;
-  if (idx < nw) {
-    float s = 0.f;
-    for (int sl = 0; sl < nslices; ++sl) s += part_w[(size_t)sl * nw + idx];
-    const int f = idx / (2 * d), k = idx % (2 * d);
-    float *dst = k < d ? gw1 + (size_t)f * d + k : gw2 + (size_t)f * d + (k - d);
-    *dst = accumulate ? *dst + s : s;
-  } else if (idx < nw + d) {
-    const int f = idx - nw;
-    float s = 0.f;
-    for (int sl = 0; sl < nslices; ++sl) s += part_b[(size_t)sl * d + f];
-    gb[f] = accumulate ? gb[f] + s : s;
+  const int total = nw + d;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (idx < total) {
+    const float *src = idx < nw ? part_w + idx : part_b + (idx - nw);
+    const size_t stride = idx < nw ? (size_t)nw : (size_t)d;
+    int sl = w;
+    for (; sl + 12 < nslices; sl += 16) {
+      s0 += src[(size_t)sl * stride];
+      s1 += src[(size_t)(sl + 4) * stride];
+      s2 += src[(size_t)(sl + 8) * stride];
+      s3 += src[(size_t)(sl + 12) * stride];
+    }
+    for (; sl < nslices; sl += 4) s0 += src[(size_t)sl * stride];
+  }
+  red[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && idx < total) {
+    const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (idx < nw) {
+      const int f = idx / (2 * d), k = idx % (2 * d);
+      float *dst = k < d ? gw1 + (size_t)f * d + k : gw2 + (size_t)f * d + (k - d);
+      *dst = accumulate ? *dst + s : s;
+    } else {
+      const int f = idx - nw;
+      const float v = accumulate ? gb[f] + s : s;
+      gb[f] = v;
+      if (gb2) gb2[f] = v;
+    }
   }
 }
 
 static void wgrad_geometry(int32_t n, int32_t d, int &nslices, int &rows_per_slice) {
   const int tiles = (d % 64 == 0) ? (d / 64) * (2 * d / 64) : ceil_div((int64_t)d * 2 * d + d, 256);
-  int want = ceil_div(512, tiles);
+  int want = ceil_div(256, tiles);
   const int max_slices = n > 0 ? ceil_div(n, 32) : 1;
   if (want > max_slices) want = max_slices;
   if (want < 1) want = 1;
@@ -371,7 +578,7 @@ size_t wgrad_workspace_bytes(int32_t n, int32_t d) {
 }
 
 int dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, const float *am, const int32_t *rows,
-                     float *gw1, float *gw2, float *gb, int accumulate, void *ws, void *stream) {
+                     float *gw1, float *gw2, float *gb, float *gb2, int accumulate, void *ws, void *stream) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(n >= 0 && dp && ax && am && gw1 && gw2 && gb && ws, "dense_bwd_weight: null operand");
   hipStream_t st = as_stream(stream);
@@ -386,8 +593,8 @@ int dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, con
     hipLaunchKernelGGL(wgrad_simple_kernel, dim3(ceil_div((int64_t)d * 2 * d + d, 256), ns), dim3(256), 0, st, g);
     GSS_LAUNCH_CHECK("wgrad_simple_kernel");
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div((int64_t)d * 2 * d + d, 256)), dim3(256), 0, st, d, ns, g.part_w,
-                     g.part_b, gw1, gw2, gb, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div((int64_t)d * 2 * d + d, 64)), dim3(256), 0, st, d, ns, g.part_w,
+                     g.part_b, gw1, gw2, gb, gb2, accumulate);
   GSS_LAUNCH_CHECK("wgrad_reduce_kernel");
   return GSS_OK;
 }
@@ -408,6 +615,6 @@ int gss_dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t,
 size_t gss_wgrad_workspace_bytes(int32_t n, int32_t d) { return wgrad_workspace_bytes(n, d); }
 int gss_dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, const float *am, const int32_t *rows,
                          float *gw1, float *gw2, float *gb, int accumulate, void *ws, void *stream) {
-  return dense_bwd_weight(n, d, dp, ax, am, rows, gw1, gw2, gb, accumulate, ws, stream);
+  return dense_bwd_weight(n, d, dp, ax, am, rows, gw1, gw2, gb, nullptr, accumulate, ws, stream);
 }
 }

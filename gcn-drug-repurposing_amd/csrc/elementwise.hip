@@ -107,6 +107,27 @@ __global__ __launch_bounds__(256) void adam_kernel(int64_t count, float *__restr
   }
 }
 
+struct Adam4 {
+  AdamTensor t[4];
+  int64_t start[5];
+};
+
+// all four parameter tensors in one launch (the reference's optimizer.step() is one foreach call)
+__global__ __launch_bounds__(256) void adam4_kernel(Adam4 a, float lr_over_bc1, float inv_sqrt_bc2, float beta1, float beta2,
+                                                    float eps) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.start[4]) return;
+  const int k = i < a.start[1] ? 0 : i < a.start[2] ? 1 : i < a.start[3] ? 2 : 3;
+  const int64_t j = i - a.start[k];
+  const float g = a.t[k].grad[j];
+  const float mi = a.t[k].m[j] + (g - a.t[k].m[j]) * (1.f - beta1);
+  const float vi = a.t[k].v[j] * beta2 + (1.f - beta2) * g * g;
+  a.t[k].m[j] = mi;
+  a.t[k].v[j] = vi;
+  const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+  a.t[k].param[j] -= lr_over_bc1 * (mi / denom);
+}
+
 __global__ __launch_bounds__(256) void transpose2_kernel(int dim, const float *__restrict__ a, const float *__restrict__ b,
                                                          float *__restrict__ at, float *__restrict__ bt) {
   __shared__ float tile[2][32][33];
@@ -195,6 +216,24 @@ int adam_step(int64_t count, float *param, const float *grad, float *m, float *v
   hipLaunchKernelGGL(adam_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, as_stream(stream), count, param, grad, m, v,
                      (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, wt, dim > 0 ? dim : 1);
   GSS_LAUNCH_CHECK("adam_kernel");
+  return GSS_OK;
+}
+
+int adam_step4(const AdamTensor (&t)[4], int32_t step, float lr, float beta1, float beta2, float eps, void *stream) {
+  GSS_REQUIRE(step >= 1, "adam: step is 1-based");
+  Adam4 a;
+  a.start[0] = 0;
+  for (int k = 0; k < 4; ++k) {
+    GSS_REQUIRE(t[k].param && t[k].grad && t[k].m && t[k].v && t[k].count >= 0, "adam: null tensor %d", k);
+    a.t[k] = t[k];
+    a.start[k + 1] = a.start[k] + t[k].count;
+  }
+  if (a.start[4] == 0) return GSS_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam4_kernel, dim3(ceil_div(a.start[4], 256)), dim3(256), 0, as_stream(stream), a, (float)((double)lr / bc1),
+                     (float)(1.0 / sqrt(bc2)), beta1, beta2, eps);
+  GSS_LAUNCH_CHECK("adam4_kernel");
   return GSS_OK;
 }
 

@@ -51,6 +51,14 @@ __global__ __launch_bounds__(64 * kLossWaves) void loss_fused_kernel(LossArgs g)
 
   const float *ei = g.e + (size_t)g.idx[min(B - 1, i0 + c)] * d + 4 * q;
   const bool i_ok = (i0 + c) < B;
+  // the i-tile's operand fragments stay in registers for the whole j sweep when d <= 256
+  constexpr bool HOLD_I = NG <= 4;
+  constexpr int NCH = NG * 4;  // 16-wide k chunks covered by the template (d <= 64 NG)
+  float4 bi[HOLD_I ? NCH : 1];
+  if (HOLD_I) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) bi[k] = (16 * k < d) ? ld4(ei + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
   f32x4 acc[NG][4];
 #pragma unroll
@@ -61,17 +69,32 @@ __global__ __launch_bounds__(64 * kLossWaves) void loss_fused_kernel(LossArgs g)
 
   for (int jt = slot; jt < nj; jt += nslots) {
     const int j0 = jt * 16;
-    // ---- S'[j][i] = E_j . E_i  (A = E_j rows, B = E_i rows), k order kc + 4 q + e
+    // ---- S'[j][i] = E_j . E_i  (A = E_j rows, B = E_i rows), k order kc + 4 q + e; two accumulators
+    // break the dependent MFMA chain
     const float *ej = g.e + (size_t)g.idx[min(B - 1, j0 + c)] * d + 4 * q;
-    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < d; kc += 16) {
-      const float4 a4 = ld4(ej + kc);
-      const float4 b4 = ld4(ei + kc);
-      s = mfma16l(a4.x, b4.x, s);
-      s = mfma16l(a4.y, b4.y, s);
-      s = mfma16l(a4.z, b4.z, s);
-      s = mfma16l(a4.w, b4.w, s);
+    f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (HOLD_I) {
+      float4 aj[NCH];
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) aj[k] = (16 * k < d) ? ld4(ej + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        s0 = mfma16l(aj[k].x, bi[k].x, s0);
+        s1 = mfma16l(aj[k].y, bi[k].y, s1);
+        s0 = mfma16l(aj[k].z, bi[k].z, s0);
+        s1 = mfma16l(aj[k].w, bi[k].w, s1);
+      }
+    } else {
+      for (int kc = 0; kc < d; kc += 16) {
+        const float4 a4 = ld4(ej + kc);
+        const float4 b4 = ld4(ei + kc);
+        s0 = mfma16l(a4.x, b4.x, s0);
+        s1 = mfma16l(a4.y, b4.y, s1);
+        s0 = mfma16l(a4.z, b4.z, s0);
+        s1 = mfma16l(a4.w, b4.w, s1);
+      }
     }
+    const f32x4 s = s0 + s1;
     // lane (c, q), reg r: S[i0 + c][j0 + 4 q + r]
     float gv[4];
 #pragma unroll

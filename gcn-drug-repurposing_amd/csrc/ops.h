@@ -29,13 +29,20 @@ int dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t, con
                     float *g_ax, float *g_am, void *stream);
 size_t wgrad_workspace_bytes(int32_t n, int32_t d);
 int dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, const float *am, const int32_t *rows,
-                     float *gw1, float *gw2, float *gb, int accumulate, void *ws, void *stream);
+                     float *gw1, float *gw2, float *gb, float *gb2, int accumulate, void *ws, void *stream);
 int rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, void *stream);
 int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b, const float *e, const float *inv_den,
                     const float *p, float c, float *dx_b, float *dp_b, void *stream);
 int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, void *stream);
 int adam_step(int64_t count, float *param, const float *grad, float *m, float *v, int32_t step, float lr, float beta1,
               float beta2, float eps, float *wt, int32_t dim, void *stream);
+struct AdamTensor {
+  float *param;
+  const float *grad;
+  float *m, *v;
+  int64_t count;
+};
+int adam_step4(const AdamTensor (&t)[4], int32_t step, float lr, float beta1, float beta2, float eps, void *stream);
 int transpose2(int32_t dim, const float *a, const float *b, float *at, float *bt, void *stream);
 size_t loss_workspace_bytes(int32_t b, int32_t d);
 int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha,

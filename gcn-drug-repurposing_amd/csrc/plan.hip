@@ -248,7 +248,7 @@ int gss_plan_backward(gss_plan *p, const int32_t *idx, int32_t b, const float *d
   }
   {
     PROF(GSS_PROF_WGRAD_BATCH);
-    if (int rc = dense_bwd_weight(b, D.d, p->dp_b, p->ax[L - 1], p->am[L - 1], idx, p->grad[0], p->grad[2], p->grad[1], 0,
+    if (int rc = dense_bwd_weight(b, D.d, p->dp_b, p->ax[L - 1], p->am[L - 1], idx, p->grad[0], p->grad[2], p->grad[1], p->grad[3], 0,
                                   p->wgrad_ws, stream))
       return rc;
   }
@@ -282,7 +282,7 @@ int gss_plan_backward(gss_plan *p, const int32_t *idx, int32_t b, const float *d
       }
       {
         PROF(GSS_PROF_WGRAD);
-        if (int rc = dense_bwd_weight(D.n, D.d, p->dp, p->ax[lp], p->am[lp], nullptr, p->grad[0], p->grad[2], p->grad[1], 1,
+        if (int rc = dense_bwd_weight(D.n, D.d, p->dp, p->ax[lp], p->am[lp], nullptr, p->grad[0], p->grad[2], p->grad[1], p->grad[3], 1,
                                       p->wgrad_ws, stream))
           return rc;
       }
@@ -296,8 +296,8 @@ int gss_plan_backward(gss_plan *p, const int32_t *idx, int32_t b, const float *d
       }
     }
   }
-  // b1 and b2 enter the sum p = ... + b1 + ... + b2 symmetrically: same gradient (model.py:165,170,172)
-  GSS_HIP(hipMemcpyAsync(p->grad[3], p->grad[1], sizeof(float) * D.d, hipMemcpyDeviceToDevice, st));
+  // b1 and b2 enter the sum p = ... + b1 + ... + b2 symmetrically (model.py:165,170,172): the reduce kernel
+  // writes the same column sums to both bias gradients
   return GSS_OK;
 }
 
@@ -308,11 +308,9 @@ int gss_plan_adam(gss_plan *p, void *stream) {
   PROF(GSS_PROF_ADAM);
   float *params[4] = {p->w1, p->b1, p->w2, p->b2};
   const int64_t cnt[4] = {(int64_t)D.d * D.d, D.d, (int64_t)D.d * D.d, D.d};
-  for (int k = 0; k < 4; ++k)
-    if (int rc = adam_step(cnt[k], params[k], p->grad[k], p->adam_m[k], p->adam_v[k], p->step, D.lr, D.beta1, D.beta2, D.eps,
-                           nullptr, 0, stream))
-      return rc;
-  return GSS_OK;
+  AdamTensor t[4];
+  for (int k = 0; k < 4; ++k) t[k] = AdamTensor{params[k], p->grad[k], p->adam_m[k], p->adam_v[k], cnt[k]};
+  return adam_step4(t, p->step, D.lr, D.beta1, D.beta2, D.eps, stream);
 }
 
 int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {

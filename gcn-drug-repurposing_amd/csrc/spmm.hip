@@ -326,6 +326,7 @@ static int launch_spmm_t(const gss_csr *a, int d4, const float *x, const SpmmEpi
 }
 
 int g_spmm_variant = 2;
+extern int g_gemm_variant;
 
 // Segment descriptors for the balanced kernel, built on first use for a given groups-per-wave count.
 static int build_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks) {
@@ -580,6 +581,11 @@ int gss_debug_set_option(const char *name, int value) {
   if (strcmp(name, "spmm_variant") == 0) {
     GSS_REQUIRE(value == 1 || value == 2, "spmm_variant must be 1 or 2");
     g_spmm_variant = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "gemm_variant") == 0) {
+    GSS_REQUIRE(value >= 1 && value <= 4, "gemm_variant must be 1..4");
+    g_gemm_variant = value;
     return GSS_OK;
   }
   return fail(GSS_EINVAL, "unknown option %s", name);

@@ -183,7 +183,8 @@ enum {
 int gss_plan_profile(gss_plan *p, int enable);
 int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void *stream);
 /* tuning/debug knobs (A/B runs inside one process): "spmm_variant" = 1 (whole-row gather, wave per row) or
- * 2 (feature-sliced, XCD-L2-resident gather; default) */
+ * 2 (nnz-balanced segments, default); "gemm_variant" = 1 (operand fragments from L1/L2), 2 (LDS-DMA staged, node tile
+ * chosen by width; default), 3 / 4 (LDS-DMA staged, 128- / 64-node tiles forced) */
 int gss_debug_set_option(const char *name, int value);
 /* plain device-to-device copy on `stream` (lets a ctypes host read plan-owned activations) */
 int gss_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);

@@ -150,8 +150,15 @@ def test_spmm_backward_epilogues(G, spmm_variant):
 
 
 # ---------------------------------------------------------------- K3 / K4 / K8
-@pytest.mark.parametrize("n,d", [(1000, 128), (77, 16), (300, 32), (513, 64), (200, 256), (130, 48)])
-def test_dense_fwd(G, n, d):
+@pytest.fixture(params=[1, 2, 3, 4])
+def gemm_variant(request, G):
+    G._lib.check(G.lib.gss_debug_set_option(b"gemm_variant", request.param))
+    yield request.param
+    G._lib.check(G.lib.gss_debug_set_option(b"gemm_variant", 2))
+
+
+@pytest.mark.parametrize("n,d", [(1000, 128), (77, 16), (300, 32), (513, 64), (200, 256), (130, 48), (129, 192)])
+def test_dense_fwd(G, n, d, gemm_variant):
     rng = np.random.RandomState(n + d)
     ax, am, pprev = (rng.randn(n, d).astype(np.float32) for _ in range(3))
     w1, w2 = (np.eye(d, dtype=np.float32) + 0.1 * rng.randn(d, d).astype(np.float32) for _ in range(2))
@@ -171,7 +178,7 @@ def test_dense_fwd(G, n, d):
 
 
 @pytest.mark.parametrize("n,d", [(700, 128), (50, 16), (333, 64)])
-def test_dense_bwd_input_dense_and_scattered(G, n, d):
+def test_dense_bwd_input_dense_and_scattered(G, n, d, gemm_variant):
     rng = np.random.RandomState(n)
     dp = rng.randn(n, d).astype(np.float32)
     w1, w2 = (rng.randn(d, d).astype(np.float32) for _ in range(2))
