@@ -41,7 +41,8 @@ template <int VPL>
 __global__ __launch_bounds__(256) void rownorm_elu_bwd_kernel(int b, int d4, int lpr_log2, const float *__restrict__ de_b,
                                                               const int32_t *__restrict__ idx, const float *__restrict__ e,
                                                               const float *__restrict__ inv_den, const float *__restrict__ p,
-                                                              float c, float *__restrict__ dx_b, float *__restrict__ dp_b) {
+                                                              float c, float *__restrict__ dx_b, float *__restrict__ dp_b,
+                                                              int32_t *__restrict__ pos_set) {
   const int lane = threadIdx.x & 63;
   const int lpr = 1 << lpr_log2;
   const int rpw = 64 >> lpr_log2;
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void rownorm_elu_bwd_kernel(int b, int d4, int
   }
   for (int o = 1; o < lpr; o <<= 1) dot += __shfl_xor(dot, o, 64);
   if (!ok) return;
+  if (pos_set && li == 0) pos_set[node] = r;  // node -> batch position map for the sparsity-aware backward SpMM
   const float inv = inv_den[node];
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
@@ -78,10 +80,12 @@ __global__ __launch_bounds__(256) void rownorm_elu_bwd_kernel(int b, int d4, int
 }
 
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(int b, int d4, const float *__restrict__ src,
-                                                               const int32_t *__restrict__ rows, float *__restrict__ dst) {
+                                                               const int32_t *__restrict__ rows, float *__restrict__ dst,
+                                                               int32_t *__restrict__ pos_clear) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)b * d4) return;
   const int r = (int)(i / d4), f4 = (int)(i % d4);
+  if (pos_clear && f4 == 0) pos_clear[rows[r]] = -1;
   float *p = dst + ((size_t)rows[r] * d4 + f4) * 4;
   st4(p, add4(ld4(p), ld4(src + i * 4)));
 }
@@ -177,7 +181,7 @@ int rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, 
 }
 
 int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b, const float *e, const float *inv_den,
-                    const float *p, float c, float *dx_b, float *dp_b, void *stream) {
+                    const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set, void *stream) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(b >= 0 && de_b && idx && e && inv_den && p && dx_b && dp_b, "rownorm_elu_bwd: null operand");
   if (b == 0) return GSS_OK;
@@ -187,21 +191,21 @@ int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b,
   dim3 grid(ceil_div(b, rows_per_block)), block(256);
   hipStream_t st = as_stream(stream);
   if (vpl == 1)
-    hipLaunchKernelGGL((rownorm_elu_bwd_kernel<1>), grid, block, 0, st, b, d4, lg, de_b, idx, e, inv_den, p, c, dx_b, dp_b);
+    hipLaunchKernelGGL((rownorm_elu_bwd_kernel<1>), grid, block, 0, st, b, d4, lg, de_b, idx, e, inv_den, p, c, dx_b, dp_b, pos_set);
   else if (vpl == 2)
-    hipLaunchKernelGGL((rownorm_elu_bwd_kernel<2>), grid, block, 0, st, b, d4, lg, de_b, idx, e, inv_den, p, c, dx_b, dp_b);
+    hipLaunchKernelGGL((rownorm_elu_bwd_kernel<2>), grid, block, 0, st, b, d4, lg, de_b, idx, e, inv_den, p, c, dx_b, dp_b, pos_set);
   else
-    hipLaunchKernelGGL((rownorm_elu_bwd_kernel<4>), grid, block, 0, st, b, d4, lg, de_b, idx, e, inv_den, p, c, dx_b, dp_b);
+    hipLaunchKernelGGL((rownorm_elu_bwd_kernel<4>), grid, block, 0, st, b, d4, lg, de_b, idx, e, inv_den, p, c, dx_b, dp_b, pos_set);
   GSS_LAUNCH_CHECK("rownorm_elu_bwd_kernel");
   return GSS_OK;
 }
 
-int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, void *stream) {
+int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, int32_t *pos_clear, void *stream) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(b >= 0 && src && rows && dst, "scatter_add_rows: null operand");
   if (b == 0) return GSS_OK;
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(ceil_div((int64_t)b * d / 4, 256)), dim3(256), 0, as_stream(stream), b,
-                     d / 4, src, rows, dst);
+                     d / 4, src, rows, dst, pos_clear);
   GSS_LAUNCH_CHECK("scatter_add_rows_kernel");
   return GSS_OK;
 }
@@ -253,10 +257,10 @@ int gss_rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_d
 }
 int gss_rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b, const float *e, const float *inv_den,
                         const float *p, float c, float *dx_b, float *dp_b, void *stream) {
-  return rownorm_elu_bwd(d, de_b, idx, b, e, inv_den, p, c, dx_b, dp_b, stream);
+  return rownorm_elu_bwd(d, de_b, idx, b, e, inv_den, p, c, dx_b, dp_b, nullptr, stream);
 }
 int gss_scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, void *stream) {
-  return scatter_add_rows(d, src, rows, b, dst, stream);
+  return scatter_add_rows(d, src, rows, b, dst, nullptr, stream);
 }
 int gss_adam_step(int64_t count, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int32_t step, float lr,
                   float beta1, float beta2, float eps, float *wt, int32_t dim, void *stream) {

@@ -32,8 +32,11 @@ int dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, con
                      float *gw1, float *gw2, float *gb, float *gb2, int accumulate, void *ws, void *stream);
 int rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, void *stream);
 int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b, const float *e, const float *inv_den,
-                    const float *p, float c, float *dx_b, float *dp_b, void *stream);
-int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, void *stream);
+                    const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set, void *stream);
+int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, int32_t *pos_clear, void *stream);
+int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,
+                     const float *x_in, const float *ax, float *u, float *t, void *stream);
+bool spmm_sparse_available();
 int adam_step(int64_t count, float *param, const float *grad, float *m, float *v, int32_t step, float lr, float beta1,
               float beta2, float eps, float *wt, int32_t dim, void *stream);
 struct AdamTensor {

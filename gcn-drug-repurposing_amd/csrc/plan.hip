@@ -20,7 +20,8 @@ struct gss_plan {
   std::vector<float *> ax, am, p, xin;  // xin[l] = input of layer l (xin[0] = x)
   float *m_tmp, *x_last, *emb, *inv_den;
   float *g_ax, *g_am, *u, *t, *dp, *gx[2];
-  float *de_b, *dx_b, *dp_b;
+  float *de_b, *dx_b, *dp_b, *gax_b, *gam_b;
+  int32_t *pos;  // node -> batch position (-1 outside the batch) for the sparsity-aware backward SpMM
   float *w1t, *w2t;
   float *grad[4];
   float *adam_m[4], *adam_v[4];
@@ -112,6 +113,9 @@ void carve(gss_plan *p, Carver &c) {
   p->de_b = c.take<float>(bd);
   p->dx_b = c.take<float>(bd);
   p->dp_b = c.take<float>(bd);
+  p->gax_b = L > 1 ? c.take<float>(bd) : nullptr;
+  p->gam_b = L > 1 ? c.take<float>(bd) : nullptr;
+  p->pos = L > 1 ? c.take<int32_t>(D.n) : nullptr;
   p->w1t = c.take<float>((size_t)D.d * D.d);
   p->w2t = c.take<float>((size_t)D.d * D.d);
   const size_t cnt[4] = {(size_t)D.d * D.d, (size_t)D.d, (size_t)D.d * D.d, (size_t)D.d};
@@ -181,6 +185,14 @@ int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a,
   Carver real;
   real.base = p->slab;
   carve(p, real);
+  if (p->pos) {
+    e = hipMemset(p->pos, 0xff, sizeof(int32_t) * (size_t)desc->n);  // all -1
+    if (e != hipSuccess) {
+      (void)hipFree(p->slab);
+      delete p;
+      return fail(GSS_EHIP, "plan_create: hipMemset(pos) -> %s", hipGetErrorString(e));
+    }
+  }
   *out = p;
   return GSS_OK;
 }
@@ -242,9 +254,12 @@ int gss_plan_backward(gss_plan *p, const int32_t *idx, int32_t b, const float *d
   const float *de_b = de_rows ? de_rows : p->de_b;
   // top layer, batch rows only
   const float c_top = L > 1 ? D.layer_decay : 1.f;
+  const bool sparse_top = L > 1 && spmm_sparse_available();
   {
     PROF(GSS_PROF_ELEMENTWISE);
-    if (int rc = rownorm_elu_bwd(D.d, de_b, idx, b, p->emb, p->inv_den, p->p[L - 1], c_top, p->dx_b, p->dp_b, stream)) return rc;
+    if (int rc = rownorm_elu_bwd(D.d, de_b, idx, b, p->emb, p->inv_den, p->p[L - 1], c_top, p->dx_b, p->dp_b,
+                                 sparse_top ? p->pos : nullptr, stream))
+      return rc;
   }
   {
     PROF(GSS_PROF_WGRAD_BATCH);
@@ -253,18 +268,31 @@ int gss_plan_backward(gss_plan *p, const int32_t *idx, int32_t b, const float *d
       return rc;
   }
   if (L > 1) {
-    const size_t nd_bytes = sizeof(float) * (size_t)D.n * D.d;
     {
       PROF(GSS_PROF_ELEMENTWISE);
       if (int rc = transpose2(D.d, p->w1, p->w2, p->w1t, p->w2t, stream)) return rc;
-      GSS_HIP(hipMemsetAsync(p->g_ax, 0, nd_bytes, st));
-      GSS_HIP(hipMemsetAsync(p->g_am, 0, nd_bytes, st));
     }
-    {
-      PROF(GSS_PROF_DGRAD);
-      if (int rc = dense_bwd_input(b, D.d, p->dp_b, p->w1t, p->w2t, idx, p->g_ax, p->g_am, stream)) return rc;
-    }
-    {
+    if (sparse_top) {
+      // the top layer's input gradients live on the b batch rows only: keep them compact and let the SpMM
+      // skip every neighbour that is not a batch row
+      {
+        PROF(GSS_PROF_DGRAD);
+        if (int rc = dense_bwd_input(b, D.d, p->dp_b, p->w1t, p->w2t, nullptr, p->gax_b, p->gam_b, stream)) return rc;
+      }
+      PROF(GSS_PROF_SPMM_BWD1);
+      if (int rc = spmm_bwd1_sparse(p->at, D.d, p->gam_b, p->gax_b, p->pos, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream))
+        return rc;
+    } else {
+      const size_t nd_bytes = sizeof(float) * (size_t)D.n * D.d;
+      {
+        PROF(GSS_PROF_ELEMENTWISE);
+        GSS_HIP(hipMemsetAsync(p->g_ax, 0, nd_bytes, st));
+        GSS_HIP(hipMemsetAsync(p->g_am, 0, nd_bytes, st));
+      }
+      {
+        PROF(GSS_PROF_DGRAD);
+        if (int rc = dense_bwd_input(b, D.d, p->dp_b, p->w1t, p->w2t, idx, p->g_ax, p->g_am, stream)) return rc;
+      }
       PROF(GSS_PROF_SPMM_BWD1);
       if (int rc = spmm_bwd1(p->at, D.d, p->g_am, p->g_ax, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream)) return rc;
     }
@@ -278,7 +306,7 @@ int gss_plan_backward(gss_plan *p, const int32_t *idx, int32_t b, const float *d
       }
       if (lp + 2 == L) {
         PROF(GSS_PROF_ELEMENTWISE);
-        if (int rc = scatter_add_rows(D.d, p->dx_b, idx, b, p->dp, stream)) return rc;
+        if (int rc = scatter_add_rows(D.d, p->dx_b, idx, b, p->dp, sparse_top ? p->pos : nullptr, stream)) return rc;
       }
       {
         PROF(GSS_PROF_WGRAD);

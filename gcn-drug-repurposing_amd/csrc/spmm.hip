@@ -25,12 +25,13 @@ constexpr int kLongRow = 512;   // rows with more stored entries go to the long-
 constexpr int kRowsPerBlock = 16;
 constexpr int kLongThreads = 1024;
 
-enum SpmmMode { SPMM_PLAIN = 0, SPMM_FWD1 = 1, SPMM_BWD1 = 2, SPMM_BWD2 = 3 };
+enum SpmmMode { SPMM_PLAIN = 0, SPMM_FWD1 = 1, SPMM_BWD1 = 2, SPMM_BWD2 = 3, SPMM_BWD1S = 4 };
 
 struct SpmmEpi {
   const float *a0, *a1, *a2;
   float *o0, *o1;
   float c;
+  const int32_t *pos;  // SPMM_BWD1S: node -> row of the compact operands, -1 if the node is not in the batch
 };
 
 struct CsrView {
@@ -99,7 +100,7 @@ __device__ __forceinline__ void row_accumulate(const CsrView &a, const float *__
 }
 
 template <int MODE>
-__device__ __forceinline__ void row_epilogue(const SpmmEpi &ep, size_t off, float4 acc) {
+__device__ __forceinline__ void row_epilogue(const SpmmEpi &ep, size_t off, float4 acc, long coff = -1) {
   if (MODE == SPMM_PLAIN) {
     st4(ep.o0 + off, acc);
   } else if (MODE == SPMM_FWD1) {
@@ -108,6 +109,12 @@ __device__ __forceinline__ void row_epilogue(const SpmmEpi &ep, size_t off, floa
   } else if (MODE == SPMM_BWD1) {
     // u = g_ax + dm (.) x_in ; t = dm (.) ax
     st4(ep.o0 + off, add4(ld4(ep.a0 + off), mul4(acc, ld4(ep.a1 + off))));
+    st4(ep.o1 + off, mul4(acc, ld4(ep.a2 + off)));
+  } else if (MODE == SPMM_BWD1S) {
+    // same with a row-sparse g_ax held compactly: coff addresses its row (or is < 0)
+    float4 u = mul4(acc, ld4(ep.a1 + off));
+    if (coff >= 0) u = add4(u, ld4(ep.a0 + coff));
+    st4(ep.o0 + off, u);
     st4(ep.o1 + off, mul4(acc, ld4(ep.a2 + off)));
   } else {
     // gx = t + A u ; dp = c * gx (.) elu'(p) (+ res)
@@ -196,8 +203,15 @@ __global__ __launch_bounds__(kLongThreads) void spmm_long_kernel(CsrView a, cons
 // combined with xor-shuffles inside a wave and through LDS across the waves of a row's block, always in the
 // same order -> bitwise reproducible, no atomics, no second pass.
 constexpr int kSegEdges = 32;
-constexpr int kBalThreads = 1024;
+constexpr int kBalThreads = 1024;  // 512-thread workgroups (with or without a 64-VGPR cap) measured 5-30 % slower
 constexpr int kBalWaves = kBalThreads / 64;
+
+template <int MODE>
+__device__ __forceinline__ long compact_off(const SpmmEpi &ep, int row, int d4, int f4) {
+  if (MODE != SPMM_BWD1S) return -1;
+  const int pr = ep.pos[row];
+  return pr >= 0 ? ((long)pr * d4 + f4) * 4 : -1;
+}
 
 template <int MODE, int LPR_LOG2, int VPL>
 __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, const int4 *__restrict__ segs, int d4,
@@ -229,6 +243,30 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
       w = a.val[ce];
     }
     const int cnt = min(LPR, e1 - base);  // <= 0 once this group is done
+    if (MODE == SPMM_BWD1S) {
+      // row-sparse operand: only neighbours that are batch rows contribute (about B/N of the entries).  Look
+      // the neighbour up in the node -> compact-row map and walk the hits of this group one at a time.
+      const int cp = (ce < e1) ? ep.pos[c] : -1;
+      const unsigned long long hits = __ballot(cp >= 0);
+      unsigned long long gm = LPR == 64 ? hits : ((hits >> (g << LPR_LOG2)) & ((1ull << LPR) - 1ull));
+      while (__any(gm != 0ull)) {
+        const bool ok = gm != 0ull;
+        const int srcl = ok ? __builtin_ctzll(gm) : 0;
+        gm &= gm - 1ull;
+        const int src = (g << LPR_LOG2) + srcl;
+        const int cc = __shfl(cp, src, 64);
+        const float ww = __shfl(w, src, 64);
+        if (ok && col_ok) {
+          const float *xr = x + (size_t)cc * rowstride;
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) {
+            const int f4 = li + v * 64;
+            if (VPL == 1 || f4 < d4) acc[v] = fma4(ww, ld4(xr + (size_t)f4 * 4), acc[v]);
+          }
+        }
+      }
+      continue;
+    }
     for (int t = 0; __any(t < cnt); t += 8) {
       float4 xv[8][VPL];
       float wv[8];
@@ -273,7 +311,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
         const int f4 = li + v * 64;
-        if (f4 < d4) row_epilogue<MODE>(ep, ((size_t)row * d4 + f4) * 4, acc[v]);
+        if (f4 < d4) row_epilogue<MODE>(ep, ((size_t)row * d4 + f4) * 4, acc[v], compact_off<MODE>(ep, row, d4, f4));
       }
     }
   }
@@ -295,7 +333,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
       if (f4 >= d4) continue;
       float4 t = part[wib * d4 + f4];
       for (int k = 1; k < nw; ++k) t = add4(t, part[(wib + k) * d4 + f4]);
-      row_epilogue<MODE>(ep, ((size_t)row * d4 + f4) * 4, t);
+      row_epilogue<MODE>(ep, ((size_t)row * d4 + f4) * 4, t, compact_off<MODE>(ep, row, d4, f4));
     }
   }
 }
@@ -438,24 +476,34 @@ int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float 
   GSS_REQUIRE(y, "spmm: y is null");
   if (m) {
     GSS_REQUIRE(h, "spmm: m given without h");
-    SpmmEpi ep{h, nullptr, nullptr, y, m, 0.f};
+    SpmmEpi ep{h, nullptr, nullptr, y, m, 0.f, nullptr};
     return launch_spmm<SPMM_FWD1>(a, d, x, ep, stream);
   }
-  SpmmEpi ep{nullptr, nullptr, nullptr, y, nullptr, 0.f};
+  SpmmEpi ep{nullptr, nullptr, nullptr, y, nullptr, 0.f, nullptr};
   return launch_spmm<SPMM_PLAIN>(a, d, x, ep, stream);
 }
 
 int spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
               float *u, float *t, void *stream) {
   GSS_REQUIRE(g_am && g_ax && x_in && ax && u && t, "spmm_bwd1: null operand");
-  SpmmEpi ep{g_ax, x_in, ax, u, t, 0.f};
+  SpmmEpi ep{g_ax, x_in, ax, u, t, 0.f, nullptr};
   return launch_spmm<SPMM_BWD1>(at, d, g_am, ep, stream);
 }
+
+int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,
+                     const float *x_in, const float *ax, float *u, float *t, void *stream) {
+  GSS_REQUIRE(g_am_b && g_ax_b && pos && x_in && ax && u && t, "spmm_bwd1_sparse: null operand");
+  GSS_REQUIRE(g_spmm_variant == 2, "spmm_bwd1_sparse needs the balanced SpMM (spmm_variant 2)");
+  SpmmEpi ep{g_ax_b, x_in, ax, u, t, 0.f, pos};
+  return launch_spmm<SPMM_BWD1S>(at, d, g_am_b, ep, stream);
+}
+
+bool spmm_sparse_available() { return g_spmm_variant == 2; }
 
 int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
               float *dp, float *gx_out, void *stream) {
   GSS_REQUIRE(u && t && p && dp, "spmm_bwd2: null operand");
-  SpmmEpi ep{t, p, res, dp, gx_out, c};
+  SpmmEpi ep{t, p, res, dp, gx_out, c, nullptr};
   return launch_spmm<SPMM_BWD2>(at, d, u, ep, stream);
 }
 
