@@ -173,9 +173,15 @@ def main():
         avg_s = ms / max(cnt, 1) * 1e-3
         alg = spmm_bytes(nnz, n, d)
         achieved = alg / avg_s / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "spmm_rows_kernel<PLAIN> (AM = A_hat . M, forward)",
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_spmm_pmc.json")
+        if args.workload == "whole_graph" and d == 128 and os.path.exists(pmc):
+            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this kernel on this workload, corrected as
+            # MI355X_MICROARCH.md prescribes (collected separately: counters cannot be read from inside bench.py)
+            traffic = json.load(open(pmc))["hbm_traffic"]["traffic_bytes_per_launch"]
+        out["roofline"] = {"bound": "hbm", "kernel": "spmm_balanced_kernel<PLAIN> (AM = A_hat . M, forward)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": None, "alg_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6, "launches": cnt}
+                           "traffic": traffic, "alg_bytes_per_launch": alg, "avg_launch_us": avg_s * 1e6, "launches": cnt}
         out["spmm_kernel_edges_per_s"] = nnz / avg_s
         out["kernel_us"] = {k: (v[0] / max(v[1], 1) * 1e3) for k, v in prof.items() if v[1]}
         out["kernel_ms_per_step"] = {k: v[0] / args.steps for k, v in prof.items() if v[1]}

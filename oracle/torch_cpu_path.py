@@ -47,7 +47,7 @@ class TorchCpuPath:
         self.opt.zero_grad()
         loss.backward()
         self.opt.step()
-        return emb.detach(), float(loss)
+        return emb.detach(), float(loss.detach())
 
     def time_steps(self, batches, beta, warmup=1):
         for b in batches[:warmup]:

@@ -146,3 +146,18 @@ def test_auc_helper_matches_sklearn():
     y = rng.rand(300) < 0.2
     s = np.round(rng.randn(300), 1)  # ties
     assert abs(O.roc_auc(y, s) - roc_auc_score(y, s)) < 1e-12
+
+
+def test_torch_cpu_path_matches_fixture(op_case):
+    """oracle/torch_cpu_path.py (bench.py's cpu_baseline 'port') reproduces the reference's trajectory"""
+    from oracle.torch_cpu_path import TorchCpuPath
+    name, g = op_case
+    n, d, L = (int(v) for v in g["meta"])
+    cpu = TorchCpuPath(O.to_fp32_csr(golden_csr(g, "Ahat")), g["X"], golden_params(g, "init"), L, float(g["decay"]),
+                       float(g["alpha"]), float(g["lr"]))
+    losses = []
+    for idx in golden_batches(g):
+        emb, loss = cpu.step(idx, float(g["beta"]))
+        losses.append(loss)
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-5, atol=1e-9)
+    assert rel(emb.numpy(), g["emb_last"]) < 1e-5
