@@ -40,6 +40,7 @@ SIGNATURES = {
     "gss_spmm": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P]),
     "gss_spmm_bwd1": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "gss_spmm_bwd2": (C.c_int, [_P, _I32, _P, _P, _P, _F, _P, _P, _P, _P]),
+    "gss_spmm_bwd1_sparse": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gss_dense_fwd": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
     "gss_dense_bwd_input": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "gss_wgrad_workspace_bytes": (_SZ, [_I32, _I32]),

@@ -35,7 +35,7 @@ int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b,
                     const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set, void *stream);
 int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, int32_t *pos_clear, void *stream);
 int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,
-                     const float *x_in, const float *ax, float *u, float *t, void *stream);
+                     const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream);
 bool spmm_sparse_available();
 int adam_step(int64_t count, float *param, const float *grad, float *m, float *v, int32_t step, float lr, float beta1,
               float beta2, float eps, float *wt, int32_t dim, void *stream);

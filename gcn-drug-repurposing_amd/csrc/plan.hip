@@ -280,7 +280,7 @@ int gss_plan_backward(gss_plan *p, const int32_t *idx, int32_t b, const float *d
         if (int rc = dense_bwd_input(b, D.d, p->dp_b, p->w1t, p->w2t, nullptr, p->gax_b, p->gam_b, stream)) return rc;
       }
       PROF(GSS_PROF_SPMM_BWD1);
-      if (int rc = spmm_bwd1_sparse(p->at, D.d, p->gam_b, p->gax_b, p->pos, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream))
+      if (int rc = spmm_bwd1_sparse(p->at, D.d, p->gam_b, p->gax_b, p->pos, p->pos, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream))
         return rc;
     } else {
       const size_t nd_bytes = sizeof(float) * (size_t)D.n * D.d;

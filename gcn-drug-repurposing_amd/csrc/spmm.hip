@@ -31,7 +31,8 @@ struct SpmmEpi {
   const float *a0, *a1, *a2;
   float *o0, *o1;
   float c;
-  const int32_t *pos;  // SPMM_BWD1S: node -> row of the compact operands, -1 if the node is not in the batch
+  const int32_t *pos;      // SPMM_BWD1S: column id -> row of the compact operands, -1 if not a batch row
+  const int32_t *pos_row;  // SPMM_BWD1S: output row -> row of the compact g_ax, -1 if not a batch row
 };
 
 struct CsrView {
@@ -209,7 +210,7 @@ constexpr int kBalWaves = kBalThreads / 64;
 template <int MODE>
 __device__ __forceinline__ long compact_off(const SpmmEpi &ep, int row, int d4, int f4) {
   if (MODE != SPMM_BWD1S) return -1;
-  const int pr = ep.pos[row];
+  const int pr = ep.pos_row[row];
   return pr >= 0 ? ((long)pr * d4 + f4) * 4 : -1;
 }
 
@@ -476,25 +477,25 @@ int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float 
   GSS_REQUIRE(y, "spmm: y is null");
   if (m) {
     GSS_REQUIRE(h, "spmm: m given without h");
-    SpmmEpi ep{h, nullptr, nullptr, y, m, 0.f, nullptr};
+    SpmmEpi ep{h, nullptr, nullptr, y, m, 0.f, nullptr, nullptr};
     return launch_spmm<SPMM_FWD1>(a, d, x, ep, stream);
   }
-  SpmmEpi ep{nullptr, nullptr, nullptr, y, nullptr, 0.f, nullptr};
+  SpmmEpi ep{nullptr, nullptr, nullptr, y, nullptr, 0.f, nullptr, nullptr};
   return launch_spmm<SPMM_PLAIN>(a, d, x, ep, stream);
 }
 
 int spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
               float *u, float *t, void *stream) {
   GSS_REQUIRE(g_am && g_ax && x_in && ax && u && t, "spmm_bwd1: null operand");
-  SpmmEpi ep{g_ax, x_in, ax, u, t, 0.f, nullptr};
+  SpmmEpi ep{g_ax, x_in, ax, u, t, 0.f, nullptr, nullptr};
   return launch_spmm<SPMM_BWD1>(at, d, g_am, ep, stream);
 }
 
 int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,
-                     const float *x_in, const float *ax, float *u, float *t, void *stream) {
-  GSS_REQUIRE(g_am_b && g_ax_b && pos && x_in && ax && u && t, "spmm_bwd1_sparse: null operand");
+                     const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream) {
+  GSS_REQUIRE(g_am_b && g_ax_b && pos && pos_row && x_in && ax && u && t, "spmm_bwd1_sparse: null operand");
   GSS_REQUIRE(g_spmm_variant == 2, "spmm_bwd1_sparse needs the balanced SpMM (spmm_variant 2)");
-  SpmmEpi ep{g_ax_b, x_in, ax, u, t, 0.f, pos};
+  SpmmEpi ep{g_ax_b, x_in, ax, u, t, 0.f, pos, pos_row};
   return launch_spmm<SPMM_BWD1S>(at, d, g_am_b, ep, stream);
 }
 
@@ -503,7 +504,7 @@ bool spmm_sparse_available() { return g_spmm_variant == 2; }
 int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
               float *dp, float *gx_out, void *stream) {
   GSS_REQUIRE(u && t && p && dp, "spmm_bwd2: null operand");
-  SpmmEpi ep{t, p, res, dp, gx_out, c, nullptr};
+  SpmmEpi ep{t, p, res, dp, gx_out, c, nullptr, nullptr};
   return launch_spmm<SPMM_BWD2>(at, d, u, ep, stream);
 }
 
@@ -645,6 +646,10 @@ int gss_spmm(const gss_csr *a, int32_t d, const float *x, float *y, const float 
 int gss_spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
                   float *u, float *t, void *stream) {
   return spmm_bwd1(at, d, g_am, g_ax, x_in, ax, u, t, stream);
+}
+int gss_spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos_col,
+                         const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream) {
+  return spmm_bwd1_sparse(at, d, g_am_b, g_ax_b, pos_col, pos_row, x_in, ax, u, t, stream);
 }
 int gss_spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
                   float *dp, float *gx_out, void *stream) {

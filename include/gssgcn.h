@@ -64,6 +64,12 @@ int gss_spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *
                   const float *ax, float *u, float *t, void *stream);
 int gss_spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c,
                   const float *res, float *dp, float *gx_out, void *stream);
+/* gss_spmm_bwd1 for row-sparse gradients (the top layer: dLoss/dE is non-zero on the B batch rows only):
+ * g_am_b / g_ax_b are compact [B][d]; pos_col[c] is the compact row of column id c (or -1), pos_row[r] the
+ * compact row of output row r (or -1).  Neighbours with pos_col < 0 are skipped. */
+int gss_spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b,
+                         const int32_t *pos_col, const int32_t *pos_row, const float *x_in, const float *ax,
+                         float *u, float *t, void *stream);
 
 /* ---- K3/K4  nn.Linear x2 + add + F.elu + residual, modules/model.py:165,170-173,201-203 -------
  * p = ax W1^T + b1 + am W2^T + b2;  o = elu(p);  x_next = p_prev ? p_prev + decay*o : o.

@@ -1,0 +1,92 @@
+"""CPU: the node-range-sharded step (gcn_drug_repurposing_amd/dist.py) with world_size 2 and 3 over gloo,
+numpy op backend -- partitioning, padded all-gathers, batch-row exchange and gradient all-reduce must
+reproduce the single-process oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import golden_batches, golden_csr, golden_params, load_golden
+from oracle import gss_oracle as O
+
+torch = pytest.importorskip("torch")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from cpu_ops import NumpyOps
+        from gcn_drug_repurposing_amd.dist import ShardedEngine, TorchComm
+        g = load_golden(case)
+        n, d, L = (int(v) for v in g["meta"])
+        params = golden_params(g, "init")
+        eng = ShardedEngine(golden_csr(g, "A"), g["X"], params, num_layers=L, layer_decay=float(g["decay"]), alpha=float(g["alpha"]),
+                            lr=float(g["lr"]), comm=TorchComm(), ops=NumpyOps(), device=torch.device("cpu"))
+        losses = []
+        for idx in golden_batches(g):
+            eng.step(torch.from_numpy(idx.astype(np.int32)), float(g["beta"]))
+            losses.append(float(eng.loss.item()))
+        emb = eng.gather_embeddings().numpy()
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), losses=np.array(losses), emb=emb, lo=eng.lo, hi=eng.hi,
+                 **{k: p.numpy() for k, p in zip(("W1", "b1", "W2", "b2"), eng.params)})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "edge_n600_d128_L2"), (3, "knn_n200_d16_L2"), (2, "knn_n2000_d64_L3")])
+def test_sharded_step_matches_reference_trajectory(tmp_path, world, case):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    g = load_golden(case)
+    outs = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    assert outs[0]["lo"] == 0 and outs[-1]["hi"] == int(g["meta"][0])
+    for r in range(1, world):
+        assert outs[r]["lo"] == outs[r - 1]["hi"]
+        for k in ("losses", "emb", "W1", "b1", "W2", "b2"):     # replicated state stays identical across ranks
+            np.testing.assert_array_equal(outs[r][k], outs[0][k])
+    np.testing.assert_allclose(outs[0]["losses"], g["losses"], rtol=2e-4, atol=1e-8)
+    assert np.abs(outs[0]["emb"] - g["emb_last"]).max() / np.abs(g["emb_last"]).max() < 2e-3
+    for k in ("W1", "W2"):
+        assert np.abs(outs[0][k] - g["final_" + k]).max() < 2.5 * float(g["lr"])
+
+
+def test_partition_and_padded_ids():
+    from gcn_drug_repurposing_amd.dist import Partition, nnz_balanced_ranges, shard_csr
+    rng = np.random.RandomState(0)
+    a = sp.random(500, 500, density=0.02, random_state=rng, format="csr")
+    a[7, :] = 1.0   # a hub row
+    a = sp.csr_matrix(a)
+    b = nnz_balanced_ranges(a.indptr, 4)
+    assert b[0] == 0 and b[-1] == 500 and np.all(np.diff(b) >= 0)
+    per = [a.indptr[b[i + 1]] - a.indptr[b[i]] for i in range(4)]
+    assert max(per) < 2.2 * (a.nnz / 4)
+    part = Partition(b)
+    ids = np.arange(500)
+    pid = part.padded_id(ids)
+    assert len(set(pid.tolist())) == 500 and pid.max() < 4 * part.max_rows
+    # a gather from the padded layout reproduces the original rows
+    x = rng.randn(500, 3)
+    padded = np.zeros((4 * part.max_rows, 3))
+    for r in range(4):
+        lo, hi = part.rows(r)
+        padded[r * part.max_rows: r * part.max_rows + hi - lo] = x[lo:hi]
+    np.testing.assert_array_equal(padded[pid], x)
+    ip, ix, dv = shard_csr(a, part, 2)
+    lo, hi = part.rows(2)
+    sub = sp.csr_matrix((dv, ix, ip), shape=(hi - lo, 4 * part.max_rows))
+    np.testing.assert_allclose(sub @ padded, (a[lo:hi] @ x), rtol=1e-5, atol=1e-5)
