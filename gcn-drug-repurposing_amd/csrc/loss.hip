@@ -25,15 +25,23 @@ constexpr int kLossWaves = 4;
 
 struct LossArgs {
   int d, b, js;  // js = grid.y
-  const float *e;
-  const int32_t *idx;
+  const float *e;  // contiguous E_B [b][d] (gathered by gather_rows_kernel)
   float beta, alpha;
   float *de_part;     // [js][b][d]
   double *loss_part;  // [grid.x * grid.y]
 };
 
-template <int NG>
-__global__ __launch_bounds__(64 * kLossWaves) void loss_fused_kernel(LossArgs g) {
+// E_B = e[idx] (modules/model.py:216-217) into a contiguous buffer, so the MFMA loop has no index indirection
+__global__ __launch_bounds__(256) void gather_rows_kernel(int b, int d4, const float *__restrict__ e, const int32_t *__restrict__ idx,
+                                                          float *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)b * d4) return;
+  const int r = (int)(i / d4), f4 = (int)(i % d4);
+  st4(out + i * 4, ld4(e + ((size_t)idx[r] * d4 + f4) * 4));
+}
+
+template <int NG, bool EXACT>  // EXACT: d == 64 NG, no feature masking anywhere
+__global__ __launch_bounds__(64 * kLossWaves, 2) void loss_fused_kernel(LossArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *red = reinterpret_cast<float4 *>(smem);  // [2 slots][NG*4 tiles][64 lanes]
   __shared__ double lsum[kLossWaves];
@@ -49,7 +57,7 @@ __global__ __launch_bounds__(64 * kLossWaves) void loss_fused_kernel(LossArgs g)
   const float coef = -g.alpha / ((float)B * (float)B);
   const float beta = g.beta;
 
-  const float *ei = g.e + (size_t)g.idx[min(B - 1, i0 + c)] * d + 4 * q;
+  const float *ei = g.e + (size_t)min(B - 1, i0 + c) * d + 4 * q;
   const bool i_ok = (i0 + c) < B;
   // the i-tile's operand fragments stay in registers for the whole j sweep when d <= 256
   constexpr bool HOLD_I = NG <= 4;
@@ -57,7 +65,7 @@ __global__ __launch_bounds__(64 * kLossWaves) void loss_fused_kernel(LossArgs g)
   float4 bi[HOLD_I ? NCH : 1];
   if (HOLD_I) {
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) bi[k] = (16 * k < d) ? ld4(ei + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < NCH; ++k) bi[k] = (EXACT || 16 * k < d) ? ld4(ei + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
   f32x4 acc[NG][4];
@@ -67,16 +75,44 @@ __global__ __launch_bounds__(64 * kLossWaves) void loss_fused_kernel(LossArgs g)
     for (int e = 0; e < 4; ++e) acc[G][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float lacc = 0.f;
 
+  float4 aj[HOLD_I ? NCH : 1];
+  if (HOLD_I && slot < nj) {
+    const float *ej0 = g.e + (size_t)min(B - 1, slot * 16 + c) * d + 4 * q;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) aj[k] = (EXACT || 16 * k < d) ? ld4(ej0 + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   for (int jt = slot; jt < nj; jt += nslots) {
     const int j0 = jt * 16;
     // ---- S'[j][i] = E_j . E_i  (A = E_j rows, B = E_i rows), k order kc + 4 q + e; two accumulators
-    // break the dependent MFMA chain
-    const float *ej = g.e + (size_t)g.idx[min(B - 1, j0 + c)] * d + 4 * q;
+    // break the dependent MFMA chain; the next j-tile's operands are requested before this tile's MFMAs
+    const float *ej = g.e + (size_t)min(B - 1, j0 + c) * d + 4 * q;
+    // operands of the second product (rows j0 + 4 q + r of E_B, features fbase + 64 G + 4 c ..): requested now,
+    // branch-free, so their latency hides under the 4 NCH MFMAs of the first product
+    float4 p2[4][NG];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float *er = g.e + (size_t)min(B - 1, j0 + 4 * q + r) * d;
+#pragma unroll
+      for (int G = 0; G < NG; ++G) {
+        const int f = fbase + 64 * G + 4 * c;
+        if (EXACT) {
+          p2[r][G] = ld4(er + f);
+        } else {
+          const bool in = f < d;
+          const float4 v = ld4(er + (in ? f : 0));
+          p2[r][G] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
     f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
     if (HOLD_I) {
-      float4 aj[NCH];
+      float4 an[NCH];
+      const int jn = jt + nslots;
+      const float *ejn = g.e + (size_t)min(B - 1, (jn < nj ? jn : jt) * 16 + c) * d + 4 * q;
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) aj[k] = (16 * k < d) ? ld4(ej + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < NCH; ++k) an[k] = (EXACT || 16 * k < d) ? ld4(ejn + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks every load next to its first use (one exposed
+                                          // round trip per 4 MFMAs); issue them all here, consume them later
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
         s0 = mfma16l(aj[k].x, bi[k].x, s0);
@@ -84,6 +120,8 @@ __global__ __launch_bounds__(64 * kLossWaves) void loss_fused_kernel(LossArgs g)
         s0 = mfma16l(aj[k].z, bi[k].z, s0);
         s1 = mfma16l(aj[k].w, bi[k].w, s1);
       }
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) aj[k] = an[k];
     } else {
       for (int kc = 0; kc < d; kc += 16) {
         const float4 a4 = ld4(ej + kc);
@@ -108,11 +146,9 @@ __global__ __launch_bounds__(64 * kLossWaves) void loss_fused_kernel(LossArgs g)
     // ---- dE_i[f] += sum_j G[i][j] E_j[f]:  A = E_j^T (feature rows), B = G, k slot q at step r is j0+4q+r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float *er = g.e + (size_t)g.idx[min(B - 1, j0 + 4 * q + r)] * d + fbase + 4 * c;
 #pragma unroll
       for (int G = 0; G < NG; ++G) {
-        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (fbase + 64 * G + 4 * c < d) a4 = ld4(er + 64 * G);
+        const float4 a4 = p2[r][G];
         acc[G][0] = mfma16l(a4.x, gv[r], acc[G][0]);
         acc[G][1] = mfma16l(a4.y, gv[r], acc[G][1]);
         acc[G][2] = mfma16l(a4.z, gv[r], acc[G][2]);
@@ -154,7 +190,7 @@ __global__ __launch_bounds__(64 * kLossWaves) void loss_fused_kernel(LossArgs g)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = fbase + 64 * G + 16 * q + 4 * r;
-        if (f < d) st4(out + f, make_float4(acc[G][0][r], acc[G][1][r], acc[G][2][r], acc[G][3][r]));
+        if (EXACT || f < d) st4(out + f, make_float4(acc[G][0][r], acc[G][1][r], acc[G][2][r], acc[G][3][r]));
       }
   }
   // ---- loss partial (only the z == 0 slab counts it)
@@ -205,7 +241,7 @@ size_t loss_workspace_bytes(int32_t b, int32_t d) {
   loss_geometry(b, d, ni, js, nz, ng);
   size_t de = sizeof(float) * (size_t)js * b * d;
   de = (de + 15) / 16 * 16;
-  return de + sizeof(double) * (size_t)ni * js;
+  return de + (sizeof(double) * (size_t)ni * js + 15) / 16 * 16 + sizeof(float) * (size_t)b * d;
 }
 
 int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha,
@@ -217,15 +253,29 @@ int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32
   loss_geometry(b, d, ni, js, nz, ng);
   size_t de_bytes = sizeof(float) * (size_t)js * b * d;
   de_bytes = (de_bytes + 15) / 16 * 16;
-  LossArgs g{d, b, js, e, idx, beta, alpha, (float *)ws, (double *)((char *)ws + de_bytes)};
+  const size_t lp_bytes = (sizeof(double) * (size_t)ni * js + 15) / 16 * 16;
+  float *e_b = (float *)((char *)ws + de_bytes + lp_bytes);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div((int64_t)b * d / 4, 256)), dim3(256), 0, st, b, d / 4, e, idx, e_b);
+  GSS_LAUNCH_CHECK("gather_rows_kernel");
+  LossArgs g{d, b, js, e_b, beta, alpha, (float *)ws, (double *)((char *)ws + de_bytes)};
   dim3 grid(ni, js, nz), block(64 * kLossWaves);
   const size_t lds = (size_t)2 * ng * 4 * 64 * sizeof(float4);
+  const bool exact = (d == 64 * ng) && nz == 1;
+#define GSS_LOSS_CASE(NGV)                                                              \
+  case NGV:                                                                             \
+    if (exact)                                                                          \
+      hipLaunchKernelGGL((loss_fused_kernel<NGV, true>), grid, block, lds, st, g);      \
+    else                                                                                \
+      hipLaunchKernelGGL((loss_fused_kernel<NGV, false>), grid, block, lds, st, g);     \
+    break;
   switch (ng) {
-    case 1: hipLaunchKernelGGL((loss_fused_kernel<1>), grid, block, lds, st, g); break;
-    case 2: hipLaunchKernelGGL((loss_fused_kernel<2>), grid, block, lds, st, g); break;
-    case 4: hipLaunchKernelGGL((loss_fused_kernel<4>), grid, block, lds, st, g); break;
-    default: hipLaunchKernelGGL((loss_fused_kernel<8>), grid, block, lds, st, g); break;
+    GSS_LOSS_CASE(1)
+    GSS_LOSS_CASE(2)
+    GSS_LOSS_CASE(4)
+    default:
+      GSS_LOSS_CASE(8)
   }
+#undef GSS_LOSS_CASE
   GSS_LAUNCH_CHECK("loss_fused_kernel");
   const int nb = ceil_div((int64_t)b * d / 4, 256);
   hipLaunchKernelGGL(loss_finish_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, b, d, js, ni * js, g.de_part, g.loss_part,

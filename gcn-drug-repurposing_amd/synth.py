@@ -48,9 +48,12 @@ def _sample_pairs(m, a_ids, a_p, b_ids, b_p, rng, same_set=False):
     return seen // nb, seen % nb
 
 
-def whole_graph_standin(seed=1, pathway_edges=False):
-    """-> (adj CSR fp64 [N, N] directed+weighted, node type array, names)"""
+def whole_graph_standin(seed=1, pathway_edges=False, scale=1):
+    """-> (adj CSR fp64 [N, N] directed+weighted, node type array, names); scale > 1 divides every node and
+    edge count (small graphs of the same shape for tests)"""
     rng = np.random.RandomState(seed)
+    N_DRUG, N_IND, N_PROT, N_PATH = (max(4, v // scale) for v in (1661, 840, 17660, 9798))
+    LAYERS = {k: max(8, v // scale) for k, v in globals()["LAYERS"].items()}
     o_drug, o_ind, o_prot, o_path = 0, N_DRUG, N_DRUG + N_IND, N_DRUG + N_IND + N_PROT
     covid = o_path + N_PATH
     n = covid + 1
@@ -74,7 +77,8 @@ def whole_graph_standin(seed=1, pathway_edges=False):
     child, parent = np.maximum(child, parent), np.minimum(child, parent)
     if pathway_edges:
         # config_gcn_pathway.json: 324 NodeCovid <-> pathway edges, w = 3/353 (predict_drug.py:182-196)
-        extra = rng.choice(path, 324, replace=False)
+        n_extra = min(324, len(path))
+        extra = rng.choice(path, n_extra, replace=False)
     ntype = np.empty(n, dtype=np.int8)   # 0 drug 1 indication 2 protein 3 pathway
     ntype[drug] = 0; ntype[ind] = 1; ntype[prot] = 2; ntype[path] = 3; ntype[covid] = 1
     src = np.concatenate([np.concatenate([a, b]) for a, b in und] + [child, parent])
@@ -90,9 +94,9 @@ def whole_graph_standin(seed=1, pathway_edges=False):
     np.add.at(cnt, (src, cls), 1)
     w = tw[cls] / cnt[src, cls]
     if pathway_edges:
-        src = np.concatenate([src, np.full(324, covid), extra])
-        dst = np.concatenate([dst, extra, np.full(324, covid)])
-        w = np.concatenate([w, np.full(648, 3.0 / 353.0)])
+        src = np.concatenate([src, np.full(n_extra, covid), extra])
+        dst = np.concatenate([dst, extra, np.full(n_extra, covid)])
+        w = np.concatenate([w, np.full(2 * n_extra, 3.0 / 353.0)])
     adj = sp.csr_matrix((w, (src, dst)), shape=(n, n))
     adj.sort_indices()
     names = ([f"DB{i:05d}" for i in range(N_DRUG)] + [f"C{i:07d}" for i in range(N_IND)] + [str(1000 + i) for i in range(N_PROT)]

@@ -1,0 +1,54 @@
+"""CPU: the embedding-consumer contract: ranking and per-indication ROC-AUC."""
+import numpy as np
+import pytest
+
+from oracle import gss_oracle as O
+
+
+def test_roc_auc_equals_sklearn_with_ties():
+    from sklearn.metrics import roc_auc_score
+
+    from gcn_drug_repurposing_amd import consumer
+    rng = np.random.RandomState(1)
+    for _ in range(5):
+        y = rng.rand(400) < 0.1
+        s = np.round(rng.randn(400), 1)
+        assert abs(consumer.roc_auc(y, s) - roc_auc_score(y, s)) < 1e-12
+        assert abs(consumer.roc_auc(y, s) - O.roc_auc(y, s)) < 1e-12
+    with pytest.raises(ValueError):
+        consumer.roc_auc(np.zeros(5), np.arange(5))
+
+
+def test_rank_by_query_follows_predict_drug_contract(tmp_path):
+    from sklearn.preprocessing import normalize
+
+    from gcn_drug_repurposing_amd import consumer, embio
+    rng = np.random.RandomState(0)
+    names = [f"DB{i}" for i in range(20)] + ["NodeCovid"] + [f"P{i}" for i in range(30)]
+    emb = rng.randn(len(names), 8) * 3.0     # not unit norm: the consumer normalises (predict_drug.py:53)
+    path = tmp_path / "graph_embs.txt"
+    embio.write_graph_embs(str(path), emb)
+    e = consumer.load_graph_embs(str(path))
+    np.testing.assert_allclose(e, normalize(np.loadtxt(str(path)), axis=1), rtol=1e-15)
+    ranked, scores = consumer.rank_by_query(e, names, "NodeCovid", names[:20])
+    ref = normalize(emb, axis=1)
+    prox = ref[:20] @ ref[20]
+    order = np.argsort(prox)[::-1]
+    assert ranked == [names[i] for i in order]
+    np.testing.assert_allclose(scores, prox[order], rtol=1e-12)
+    s2, o2 = O.rank_scores(emb, 20, np.arange(20))
+    assert np.array_equal(o2, order)
+
+
+def test_indication_aucs_and_tsv_reader(tmp_path):
+    from gcn_drug_repurposing_amd import consumer
+    tsv = tmp_path / "di.tsv"
+    tsv.write_text("drug\tdrug_name\tindication\tindication_name\nD0\tx\tC1\ty\nD1\tx\tC1\ty\nD2\tx\tC2\ty\nD9\tx\tC2\ty\n")
+    pos = consumer.read_drug_indication_tsv(str(tsv))
+    assert pos == {"C1": {"D0", "D1"}, "C2": {"D2", "D9"}}
+    names = ["D0", "D1", "D2", "D3", "C1", "C2", "C3"]
+    emb = np.eye(7)[:, :5] + 0.1
+    emb[4] = emb[0] + emb[1]          # C1 close to D0, D1
+    aucs, used = consumer.indication_aucs(emb, names, names[:4], ["C1", "C2", "C3", "C4"], pos)
+    assert used == ["C1", "C2"]       # C3 has no positives, C4 is not in the graph
+    assert aucs[0] == 1.0

@@ -6,4 +6,4 @@ cd /tmp; export TMPDIR=/tmp
 echo "== $tag [$ctrs]"
 timeout -k 5 120 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O -- python3 $R/"$1" "${@:2}" > $O/log.txt 2>&1
 echo "rc=$?"
-python3 $R/tools/pmc_summary.py $O spmm
+python3 $R/tools/pmc_summary.py $O ${PMC_FILTER:-spmm}
