@@ -577,14 +577,24 @@ size_t wgrad_workspace_bytes(int32_t n, int32_t d) {
   return sizeof(float) * (size_t)ns * ((size_t)d * 2 * d + d);
 }
 
-int dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, const float *am, const int32_t *rows,
-                     float *gw1, float *gw2, float *gb, float *gb2, int accumulate, void *ws, void *stream) {
+// stage 1: partial slabs of one (layer's) weight gradient into slices [slice0, slice0 + returned count) of ws
+int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const float *am, const int32_t *rows, void *ws,
+                  int total_slices, int slice0, int *nslices_out, void *stream) {
   if (int rc = check_d(d)) return rc;
-  GSS_REQUIRE(n >= 0 && dp && ax && am && gw1 && gw2 && gb && ws, "dense_bwd_weight: null operand");
+  GSS_REQUIRE(n >= 0 && dp && ax && am && ws && nslices_out, "wgrad_partial: null operand");
   hipStream_t st = as_stream(stream);
   int ns, rps;
   wgrad_geometry(n, d, ns, rps);
-  WgradArgs g{n, d, dp, ax, am, rows, (float *)ws, (float *)ws + (size_t)ns * d * 2 * d, rps};
+  GSS_REQUIRE(slice0 >= 0 && slice0 + ns <= total_slices, "wgrad_partial: slices [%d, %d) exceed %d", slice0, slice0 + ns, total_slices);
+  *nslices_out = ns;
+  float *pw = (float *)ws + (size_t)slice0 * d * 2 * d;
+  float *pb = (float *)ws + (size_t)total_slices * d * 2 * d + (size_t)slice0 * d;
+  WgradArgs g{n, d, dp, ax, am, rows, pw, pb, rps};
+  if (n == 0) {  // empty shard: its slices must still read as zero
+    GSS_HIP(hipMemsetAsync(pw, 0, sizeof(float) * (size_t)ns * d * 2 * d, st));
+    GSS_HIP(hipMemsetAsync(pb, 0, sizeof(float) * (size_t)ns * d, st));
+    return GSS_OK;
+  }
   if (d % 64 == 0) {
     const int tiles = (d / 64) * (2 * d / 64);
     hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns), dim3(64 * kWgWaves), 4 * 16 * 64 * sizeof(float4), st, g);
@@ -593,10 +603,34 @@ int dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, con
     hipLaunchKernelGGL(wgrad_simple_kernel, dim3(ceil_div((int64_t)d * 2 * d + d, 256), ns), dim3(256), 0, st, g);
     GSS_LAUNCH_CHECK("wgrad_simple_kernel");
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div((int64_t)d * 2 * d + d, 64)), dim3(256), 0, st, d, ns, g.part_w,
-                     g.part_b, gw1, gw2, gb, gb2, accumulate);
+  return GSS_OK;
+}
+
+// stage 2: fixed-order sum of slices [0, nslices) -> gw1, gw2, gb (and gb2)
+int wgrad_reduce(int32_t d, void *ws, int total_slices, int nslices, float *gw1, float *gw2, float *gb, float *gb2, int accumulate,
+                 void *stream) {
+  GSS_REQUIRE(ws && gw1 && gw2 && gb && nslices >= 0 && nslices <= total_slices, "wgrad_reduce: bad argument");
+  const float *pw = (const float *)ws;
+  const float *pb = (const float *)ws + (size_t)total_slices * d * 2 * d;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div((int64_t)d * 2 * d + d, 64)), dim3(256), 0, as_stream(stream), d, nslices, pw,
+                     pb, gw1, gw2, gb, gb2, accumulate);
   GSS_LAUNCH_CHECK("wgrad_reduce_kernel");
   return GSS_OK;
+}
+
+int wgrad_slices(int32_t n, int32_t d) {
+  int ns, rps;
+  wgrad_geometry(n, d, ns, rps);
+  return ns;
+}
+
+int dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, const float *am, const int32_t *rows,
+                     float *gw1, float *gw2, float *gb, float *gb2, int accumulate, void *ws, void *stream) {
+  GSS_REQUIRE(gw1 && gw2 && gb, "dense_bwd_weight: null operand");
+  const int total = wgrad_slices(n, d);
+  int ns = 0;
+  if (int rc = wgrad_partial(n, d, dp, ax, am, rows, ws, total, 0, &ns, stream)) return rc;
+  return wgrad_reduce(d, ws, total, ns, gw1, gw2, gb, gb2, accumulate, stream);
 }
 
 }  // namespace gss

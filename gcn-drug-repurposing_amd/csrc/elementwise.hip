@@ -114,6 +114,8 @@ __global__ __launch_bounds__(256) void adam_kernel(int64_t count, float *__restr
 struct Adam4 {
   AdamTensor t[4];
   int64_t start[5];
+  float *wt[4];  // optional transposed copies of the square tensors (the backward GEMM wants [in][out])
+  int dim;
 };
 
 // all four parameter tensors in one launch (the reference's optimizer.step() is one foreach call)
@@ -129,7 +131,12 @@ __global__ __launch_bounds__(256) void adam4_kernel(Adam4 a, float lr_over_bc1, 
   a.t[k].m[j] = mi;
   a.t[k].v[j] = vi;
   const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-  a.t[k].param[j] -= lr_over_bc1 * (mi / denom);
+  const float pn = a.t[k].param[j] - lr_over_bc1 * (mi / denom);
+  a.t[k].param[j] = pn;
+  if (a.wt[k]) {
+    const int r = (int)(j / a.dim), cidx = (int)(j % a.dim);
+    a.wt[k][(size_t)cidx * a.dim + r] = pn;
+  }
 }
 
 __global__ __launch_bounds__(256) void transpose2_kernel(int dim, const float *__restrict__ a, const float *__restrict__ b,
@@ -223,9 +230,15 @@ int adam_step(int64_t count, float *param, const float *grad, float *m, float *v
   return GSS_OK;
 }
 
-int adam_step4(const AdamTensor (&t)[4], int32_t step, float lr, float beta1, float beta2, float eps, void *stream) {
+int adam_step4(const AdamTensor (&t)[4], int32_t step, float lr, float beta1, float beta2, float eps, float *w1t, float *w2t,
+               int32_t dim, void *stream) {
   GSS_REQUIRE(step >= 1, "adam: step is 1-based");
   Adam4 a;
+  a.wt[0] = w1t;
+  a.wt[1] = nullptr;
+  a.wt[2] = w2t;
+  a.wt[3] = nullptr;
+  a.dim = dim > 0 ? dim : 1;
   a.start[0] = 0;
   for (int k = 0; k < 4; ++k) {
     GSS_REQUIRE(t[k].param && t[k].grad && t[k].m && t[k].v && t[k].count >= 0, "adam: null tensor %d", k);

@@ -223,6 +223,65 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(int b, int d, int js, 
   }
 }
 
+// plan path: loss_finish + the backward of F.normalize and F.elu on the batch rows in one launch.
+// One lane group per batch row: de = 2 sum_js de_part (the row of dLoss/dE_B), then
+// dx = (de - e (e . de)) * inv_den[node], dp = c * dx (.) elu'(p[node]); e rows come from the gathered E_B.
+template <int VPL>
+__global__ __launch_bounds__(256) void loss_finish_bwd_kernel(int b, int d4, int lpr_log2, int js, int nloss,
+                                                              const float *__restrict__ de_part, const double *__restrict__ loss_part,
+                                                              float alpha, const float *__restrict__ e_b, const int32_t *__restrict__ idx,
+                                                              const float *__restrict__ inv_den, const float *__restrict__ p, float c,
+                                                              float *__restrict__ dx_b, float *__restrict__ dp_b,
+                                                              int32_t *__restrict__ pos_set, float *__restrict__ loss_out) {
+  const int lane = threadIdx.x & 63;
+  const int lpr = 1 << lpr_log2;
+  const int rpw = 64 >> lpr_log2;
+  const int li = lane & (lpr - 1);
+  const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + (lane >> lpr_log2);
+  const bool ok = r < b;
+  const int node = ok ? idx[r] : 0;
+  float4 g[VPL], ev[VPL];
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int f4 = li + k * 64;
+    const bool in = ok && f4 < d4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in) {
+      const size_t off = ((size_t)r * d4 + f4) * 4;
+      s = ld4(de_part + off);
+      for (int t = 1; t < js; ++t) s = add4(s, ld4(de_part + (size_t)t * b * d4 * 4 + off));
+      s = scale4(2.f, s);
+    }
+    g[k] = s;
+    ev[k] = in ? ld4(e_b + ((size_t)r * d4 + f4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    dot += g[k].x * ev[k].x + g[k].y * ev[k].y + g[k].z * ev[k].z + g[k].w * ev[k].w;
+  }
+  for (int o = 1; o < lpr; o <<= 1) dot += __shfl_xor(dot, o, 64);
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    double t = 0.0;
+    for (int k = threadIdx.x; k < nloss; k += 64) t += loss_part[k];
+    t = wave_sum_d(t);
+    if (threadIdx.x == 0) loss_out[0] = (float)(-0.5 * (double)alpha * t / ((double)b * (double)b));
+  }
+  if (!ok) return;
+  if (pos_set && li == 0) pos_set[node] = r;
+  const float inv = inv_den[node];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int f4 = li + k * 64;
+    if (f4 >= d4) continue;
+    float4 dx;
+    dx.x = (g[k].x - ev[k].x * dot) * inv;
+    dx.y = (g[k].y - ev[k].y * dot) * inv;
+    dx.z = (g[k].z - ev[k].z * dot) * inv;
+    dx.w = (g[k].w - ev[k].w * dot) * inv;
+    st4(dx_b + ((size_t)r * d4 + f4) * 4, dx);
+    const float4 pg = elu_grad4(ld4(p + ((size_t)node * d4 + f4) * 4));
+    st4(dp_b + ((size_t)r * d4 + f4) * 4, scale4(c, mul4(dx, pg)));
+  }
+}
+
 static void loss_geometry(int32_t b, int32_t d, int &ni, int &js, int &nz, int &ng) {
   ni = ceil_div(b, 16);
   const int nj = ni;
@@ -244,23 +303,28 @@ size_t loss_workspace_bytes(int32_t b, int32_t d) {
   return de + (sizeof(double) * (size_t)ni * js + 15) / 16 * 16 + sizeof(float) * (size_t)b * d;
 }
 
-int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha,
-                 float *loss_out, float *de_b, void *ws, void *stream) {
-  if (int rc = check_d(d)) return rc;
-  GSS_REQUIRE(n > 0 && b > 0 && e && idx && loss_out && de_b && ws, "loss_fwd_bwd: null operand or empty batch");
-  hipStream_t st = as_stream(stream);
+struct LossLaunch {
   int ni, js, nz, ng;
-  loss_geometry(b, d, ni, js, nz, ng);
-  size_t de_bytes = sizeof(float) * (size_t)js * b * d;
+  float *de_part;
+  double *loss_part;
+  float *e_b;
+};
+
+static int loss_main(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha, void *ws,
+                     hipStream_t st, LossLaunch &L) {
+  loss_geometry(b, d, L.ni, L.js, L.nz, L.ng);
+  size_t de_bytes = sizeof(float) * (size_t)L.js * b * d;
   de_bytes = (de_bytes + 15) / 16 * 16;
-  const size_t lp_bytes = (sizeof(double) * (size_t)ni * js + 15) / 16 * 16;
-  float *e_b = (float *)((char *)ws + de_bytes + lp_bytes);
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div((int64_t)b * d / 4, 256)), dim3(256), 0, st, b, d / 4, e, idx, e_b);
+  const size_t lp_bytes = (sizeof(double) * (size_t)L.ni * L.js + 15) / 16 * 16;
+  L.de_part = (float *)ws;
+  L.loss_part = (double *)((char *)ws + de_bytes);
+  L.e_b = (float *)((char *)ws + de_bytes + lp_bytes);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div((int64_t)b * d / 4, 256)), dim3(256), 0, st, b, d / 4, e, idx, L.e_b);
   GSS_LAUNCH_CHECK("gather_rows_kernel");
-  LossArgs g{d, b, js, e_b, beta, alpha, (float *)ws, (double *)((char *)ws + de_bytes)};
-  dim3 grid(ni, js, nz), block(64 * kLossWaves);
-  const size_t lds = (size_t)2 * ng * 4 * 64 * sizeof(float4);
-  const bool exact = (d == 64 * ng) && nz == 1;
+  LossArgs g{d, b, L.js, L.e_b, beta, alpha, L.de_part, L.loss_part};
+  dim3 grid(L.ni, L.js, L.nz), block(64 * kLossWaves);
+  const size_t lds = (size_t)2 * L.ng * 4 * 64 * sizeof(float4);
+  const bool exact = (d == 64 * L.ng) && L.nz == 1;
 #define GSS_LOSS_CASE(NGV)                                                              \
   case NGV:                                                                             \
     if (exact)                                                                          \
@@ -268,7 +332,7 @@ int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32
     else                                                                                \
       hipLaunchKernelGGL((loss_fused_kernel<NGV, false>), grid, block, lds, st, g);     \
     break;
-  switch (ng) {
+  switch (L.ng) {
     GSS_LOSS_CASE(1)
     GSS_LOSS_CASE(2)
     GSS_LOSS_CASE(4)
@@ -277,10 +341,48 @@ int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32
   }
 #undef GSS_LOSS_CASE
   GSS_LAUNCH_CHECK("loss_fused_kernel");
+  return GSS_OK;
+}
+
+int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha,
+                 float *loss_out, float *de_b, void *ws, void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(n > 0 && b > 0 && e && idx && loss_out && de_b && ws, "loss_fwd_bwd: null operand or empty batch");
+  hipStream_t st = as_stream(stream);
+  LossLaunch L;
+  if (int rc = loss_main(n, d, e, idx, b, beta, alpha, ws, st, L)) return rc;
   const int nb = ceil_div((int64_t)b * d / 4, 256);
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, b, d, js, ni * js, g.de_part, g.loss_part,
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, b, d, L.js, L.ni * L.js, L.de_part, L.loss_part,
                      alpha, de_b, loss_out);
   GSS_LAUNCH_CHECK("loss_finish_kernel");
+  return GSS_OK;
+}
+
+// loss + the backward of F.normalize / F.elu on the batch rows (what gss_plan_loss_backward needs next), 3 launches
+int loss_fwd_bwd_fused(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha, float *loss_out,
+                       const float *inv_den, const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set, void *ws,
+                       void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(n > 0 && b > 0 && e && idx && loss_out && inv_den && p && dx_b && dp_b && ws, "loss_fwd_bwd_fused: null operand");
+  hipStream_t st = as_stream(stream);
+  LossLaunch L;
+  if (int rc = loss_main(n, d, e, idx, b, beta, alpha, ws, st, L)) return rc;
+  const int d4 = d / 4;
+  int lg = 2;
+  while ((1 << lg) < d4 && lg < 6) ++lg;
+  const int vpl = d4 <= 64 ? 1 : d4 <= 128 ? 2 : 4;
+  dim3 grid(ceil_div(b, 4 * (64 >> lg))), block(256);
+#define GSS_FIN(V)                                                                                                              \
+  hipLaunchKernelGGL((loss_finish_bwd_kernel<V>), grid, block, 0, st, b, d4, lg, L.js, L.ni * L.js, L.de_part, L.loss_part, alpha, \
+                     L.e_b, idx, inv_den, p, c, dx_b, dp_b, pos_set, loss_out)
+  if (vpl == 1)
+    GSS_FIN(1);
+  else if (vpl == 2)
+    GSS_FIN(2);
+  else
+    GSS_FIN(4);
+#undef GSS_FIN
+  GSS_LAUNCH_CHECK("loss_finish_bwd_kernel");
   return GSS_OK;
 }
 

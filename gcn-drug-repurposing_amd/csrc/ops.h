@@ -30,6 +30,11 @@ int dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t, con
 size_t wgrad_workspace_bytes(int32_t n, int32_t d);
 int dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, const float *am, const int32_t *rows,
                      float *gw1, float *gw2, float *gb, float *gb2, int accumulate, void *ws, void *stream);
+int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const float *am, const int32_t *rows, void *ws,
+                  int total_slices, int slice0, int *nslices_out, void *stream);
+int wgrad_reduce(int32_t d, void *ws, int total_slices, int nslices, float *gw1, float *gw2, float *gb, float *gb2, int accumulate,
+                 void *stream);
+int wgrad_slices(int32_t n, int32_t d);
 int rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, void *stream);
 int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b, const float *e, const float *inv_den,
                     const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set, void *stream);
@@ -45,7 +50,11 @@ struct AdamTensor {
   float *m, *v;
   int64_t count;
 };
-int adam_step4(const AdamTensor (&t)[4], int32_t step, float lr, float beta1, float beta2, float eps, void *stream);
+int adam_step4(const AdamTensor (&t)[4], int32_t step, float lr, float beta1, float beta2, float eps, float *w1t, float *w2t,
+               int32_t dim, void *stream);
+int loss_fwd_bwd_fused(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha, float *loss_out,
+                       const float *inv_den, const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set, void *ws,
+                       void *stream);
 int transpose2(int32_t dim, const float *a, const float *b, float *at, float *bt, void *stream);
 size_t loss_workspace_bytes(int32_t b, int32_t d);
 int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha,

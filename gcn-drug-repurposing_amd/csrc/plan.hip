@@ -29,6 +29,8 @@ struct gss_plan {
   void *loss_ws, *wgrad_ws;
   int32_t step;
   bool layer1_valid;
+  bool wt_valid;      // w1t/w2t match w1/w2 (maintained by the fused Adam inside gss_plan_step only)
+  int wg_total;       // slices of the shared weight-gradient partial buffer
   // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
   bool prof_on;
   std::vector<hipEvent_t> ev;      // pairs: 2 k = start, 2 k + 1 = stop
@@ -124,8 +126,8 @@ void carve(gss_plan *p, Carver &c) {
     p->adam_v[k] = c.take<float>(cnt[k]);
   }
   p->loss_ws = c.take<char>(loss_workspace_bytes(D.max_batch, D.d));
-  const size_t wg_n = wgrad_workspace_bytes(D.n, D.d), wg_b = wgrad_workspace_bytes(D.max_batch, D.d);
-  p->wgrad_ws = c.take<char>(wg_n > wg_b ? wg_n : wg_b);
+  const int wg_total = wgrad_slices(D.max_batch, D.d) + (L - 1) * wgrad_slices(D.n, D.d);
+  p->wgrad_ws = c.take<char>(sizeof(float) * (size_t)wg_total * ((size_t)D.d * 2 * D.d + D.d));
 }
 }  // namespace
 
@@ -161,6 +163,8 @@ int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a,
   p->grad[3] = io->gb2;
   p->step = 0;
   p->layer1_valid = false;
+  p->wt_valid = false;
+  p->wg_total = wgrad_slices(desc->max_batch, desc->d) + (desc->num_layers - 1) * wgrad_slices(desc->n, desc->d);
   p->prof_on = false;
   p->ev_used = 0;
   for (int k = 0; k < GSS_PROF_CLASSES; ++k) {
@@ -204,7 +208,7 @@ void gss_plan_destroy(gss_plan *p) {
   delete p;
 }
 
-int gss_plan_forward(gss_plan *p, void *stream) {
+static int plan_forward_impl(gss_plan *p, void *stream) {
   GSS_REQUIRE(p, "plan_forward: null plan");
   const gss_plan_desc &D = p->desc;
   const int L = D.num_layers;
@@ -234,18 +238,27 @@ int gss_plan_forward(gss_plan *p, void *stream) {
   return rownorm_fwd(D.n, D.d, p->x_last, p->emb, p->inv_den, stream);
 }
 
-int gss_plan_loss_backward(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
+static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const float *de_rows, bool top_done, bool wt_ok,
+                              void *stream);
+
+static int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta, bool wt_ok, void *stream) {
   GSS_REQUIRE(p && idx, "plan_loss_backward: null argument");
   const gss_plan_desc &D = p->desc;
   GSS_REQUIRE(b >= 1 && b <= D.max_batch, "plan_loss_backward: batch %d out of [1, %d]", b, D.max_batch);
+  const int L = D.num_layers;
   {
+    // loss, dLoss/dE_B and the backward of F.normalize / F.elu on the batch rows in three launches
     PROF(GSS_PROF_LOSS);
-    if (int rc = loss_fwd_bwd(D.n, D.d, p->emb, idx, b, beta, D.alpha, p->loss, p->de_b, p->loss_ws, stream)) return rc;
+    const bool sparse_top = L > 1 && spmm_sparse_available();
+    if (int rc = loss_fwd_bwd_fused(D.n, D.d, p->emb, idx, b, beta, D.alpha, p->loss, p->inv_den, p->p[L - 1],
+                                    L > 1 ? D.layer_decay : 1.f, p->dx_b, p->dp_b, sparse_top ? p->pos : nullptr, p->loss_ws, stream))
+      return rc;
   }
-  return gss_plan_backward(p, idx, b, nullptr, stream);
+  return plan_backward_impl(p, idx, b, nullptr, true, wt_ok, stream);
 }
 
-int gss_plan_backward(gss_plan *p, const int32_t *idx, int32_t b, const float *de_rows, void *stream) {
+static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const float *de_rows, bool top_done, bool wt_ok,
+                              void *stream) {
   GSS_REQUIRE(p && idx, "plan_backward: null argument");
   const gss_plan_desc &D = p->desc;
   GSS_REQUIRE(b >= 1 && b <= D.max_batch, "plan_backward: %d rows out of [1, %d]", b, D.max_batch);
@@ -255,20 +268,22 @@ int gss_plan_backward(gss_plan *p, const int32_t *idx, int32_t b, const float *d
   // top layer, batch rows only
   const float c_top = L > 1 ? D.layer_decay : 1.f;
   const bool sparse_top = L > 1 && spmm_sparse_available();
-  {
+  if (!top_done) {
     PROF(GSS_PROF_ELEMENTWISE);
     if (int rc = rownorm_elu_bwd(D.d, de_b, idx, b, p->emb, p->inv_den, p->p[L - 1], c_top, p->dx_b, p->dp_b,
                                  sparse_top ? p->pos : nullptr, stream))
       return rc;
   }
+  // every layer's partial slabs go to consecutive slices of one buffer; one fixed-order reduce at the end
+  int wg_used = 0, wg_n = 0;
   {
     PROF(GSS_PROF_WGRAD_BATCH);
-    if (int rc = dense_bwd_weight(b, D.d, p->dp_b, p->ax[L - 1], p->am[L - 1], idx, p->grad[0], p->grad[2], p->grad[1], p->grad[3], 0,
-                                  p->wgrad_ws, stream))
+    if (int rc = wgrad_partial(b, D.d, p->dp_b, p->ax[L - 1], p->am[L - 1], idx, p->wgrad_ws, p->wg_total, wg_used, &wg_n, stream))
       return rc;
+    wg_used += wg_n;
   }
   if (L > 1) {
-    {
+    if (!wt_ok) {
       PROF(GSS_PROF_ELEMENTWISE);
       if (int rc = transpose2(D.d, p->w1, p->w2, p->w1t, p->w2t, stream)) return rc;
     }
@@ -310,9 +325,9 @@ int gss_plan_backward(gss_plan *p, const int32_t *idx, int32_t b, const float *d
       }
       {
         PROF(GSS_PROF_WGRAD);
-        if (int rc = dense_bwd_weight(D.n, D.d, p->dp, p->ax[lp], p->am[lp], nullptr, p->grad[0], p->grad[2], p->grad[1], p->grad[3], 1,
-                                      p->wgrad_ws, stream))
+        if (int rc = wgrad_partial(D.n, D.d, p->dp, p->ax[lp], p->am[lp], nullptr, p->wgrad_ws, p->wg_total, wg_used, &wg_n, stream))
           return rc;
+        wg_used += wg_n;
       }
       if (lp >= 1) {
         {
@@ -326,10 +341,11 @@ int gss_plan_backward(gss_plan *p, const int32_t *idx, int32_t b, const float *d
   }
   // b1 and b2 enter the sum p = ... + b1 + ... + b2 symmetrically (model.py:165,170,172): the reduce kernel
   // writes the same column sums to both bias gradients
-  return GSS_OK;
+  PROF(GSS_PROF_WGRAD);
+  return wgrad_reduce(D.d, p->wgrad_ws, p->wg_total, wg_used, p->grad[0], p->grad[2], p->grad[1], p->grad[3], 0, stream);
 }
 
-int gss_plan_adam(gss_plan *p, void *stream) {
+static int plan_adam_impl(gss_plan *p, void *stream) {
   GSS_REQUIRE(p, "plan_adam: null plan");
   const gss_plan_desc &D = p->desc;
   p->step += 1;
@@ -338,13 +354,36 @@ int gss_plan_adam(gss_plan *p, void *stream) {
   const int64_t cnt[4] = {(int64_t)D.d * D.d, D.d, (int64_t)D.d * D.d, D.d};
   AdamTensor t[4];
   for (int k = 0; k < 4; ++k) t[k] = AdamTensor{params[k], p->grad[k], p->adam_m[k], p->adam_v[k], cnt[k]};
-  return adam_step4(t, p->step, D.lr, D.beta1, D.beta2, D.eps, stream);
+  const bool wt = D.num_layers > 1;
+  return adam_step4(t, p->step, D.lr, D.beta1, D.beta2, D.eps, wt ? p->w1t : nullptr, wt ? p->w2t : nullptr, D.d, stream);
 }
 
+// ---- public entry points.  The separate phases make no assumption about who changed the weights in between, so
+// they always re-transpose; gss_plan_step owns the whole iteration and reuses the transposes its own Adam wrote.
+int gss_plan_forward(gss_plan *p, void *stream) {
+  if (p) p->wt_valid = false;
+  return plan_forward_impl(p, stream);
+}
+int gss_plan_loss_backward(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
+  if (p) p->wt_valid = false;
+  return plan_loss_backward_impl(p, idx, b, beta, false, stream);
+}
+int gss_plan_backward(gss_plan *p, const int32_t *rows, int32_t b, const float *de_rows, void *stream) {
+  if (p) p->wt_valid = false;
+  return plan_backward_impl(p, rows, b, de_rows, false, false, stream);
+}
+int gss_plan_adam(gss_plan *p, void *stream) {
+  const int rc = plan_adam_impl(p, stream);
+  if (p) p->wt_valid = false;
+  return rc;
+}
 int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
-  if (int rc = gss_plan_forward(p, stream)) return rc;
-  if (int rc = gss_plan_loss_backward(p, idx, b, beta, stream)) return rc;
-  return gss_plan_adam(p, stream);
+  GSS_REQUIRE(p, "plan_step: null plan");
+  if (int rc = plan_forward_impl(p, stream)) return rc;
+  if (int rc = plan_loss_backward_impl(p, idx, b, beta, p->wt_valid, stream)) return rc;
+  if (int rc = plan_adam_impl(p, stream)) return rc;
+  p->wt_valid = p->desc.num_layers > 1;
+  return GSS_OK;
 }
 
 const float *gss_plan_activation(const gss_plan *p, int layer, int which) {
