@@ -23,7 +23,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-enum GemmEpi { EPI_FWD = 0, EPI_SPLIT = 1 };
+enum GemmEpi { EPI_FWD = 0, EPI_SPLIT = 1, EPI_FWD_NORM = 2 };
 
 struct GemmArgs {
   int n;              // node rows
@@ -41,6 +41,8 @@ struct GemmArgs {
   float decay;
   // EPI_SPLIT
   const int32_t *rows;  // scatter map for the output row (nullable)
+  int debug_noepi;      // timing experiment: skip epilogue loads/stores
+  float *inv_den;       // EPI_FWD_NORM: 1 / max(||x_row||, eps) per node (x_next then receives the unit-norm rows)
 };
 
 template <int FT, int EPI>
@@ -225,24 +227,14 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
 #pragma unroll
     for (int u = 0; u < NT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int c = 0; c < PF && c < nchunk; ++c) stage(c);
-  for (int ci = 0; ci < nchunk; ++ci) {
-    // chunk ci has landed once at most min(PF-1, nchunk-1-ci) younger chunks of this wave are outstanding
-    const int younger = min(PF - 1, nchunk - 1 - ci);
-    if (younger >= 2)
-      wait_vmcnt<2 * G>();
-    else if (younger == 1)
-      wait_vmcnt<G>();
-    else
-      wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // every wave's share of chunk ci is in LDS; buffer (ci-1)%NBUF is free again
+  auto read_frags = [&](int ci, float4 (&b)[MT], float4 (&a)[NT]) {
     const float *cur = lds + (ci % NBUF) * BUF;
-    float4 b[MT], a[NT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) b[t] = *reinterpret_cast<const float4 *>(cur + (MT * w + t) * 256 + lane * 4);
 #pragma unroll
     for (int u = 0; u < NT; ++u) a[u] = *reinterpret_cast<const float4 *>(cur + XT + u * 256 + lane * 4);
-    if (ci + PF < nchunk) stage(ci + PF);  // into buffer (ci-1)%NBUF, last read before the barrier above
+  };
+  auto mma = [&](const float4 (&b)[MT], const float4 (&a)[NT]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -255,14 +247,53 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
         }
       }
     }
+  };
+  // One iteration: fragments of chunk ci are (being) read into `fa`; wait for them, make sure chunk ci+1 has landed
+  // for every wave (counted vmcnt + barrier), start reading its fragments into `fb`, issue the DMA of chunk ci+PF
+  // into the buffer chunk ci-1 used (its reads completed before this barrier), then run the MFMAs of chunk ci
+  // while both the LDS reads and the DMA are in flight.
+  auto iteration = [&](int ci, float4 (&fb_b)[MT], float4 (&fb_a)[NT], const float4 (&fa_b)[MT], const float4 (&fa_a)[NT]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (ci + 1 < nchunk) {
+      if (ci + 2 < nchunk)
+        wait_vmcnt<G>();
+      else
+        wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (ci + 1 < nchunk) read_frags(ci + 1, fb_b, fb_a);
+    if (ci + PF < nchunk) stage(ci + PF);
+    mma(fa_b, fa_a);
     __builtin_amdgcn_sched_barrier(0);  // keep the MFMA cluster inside its iteration
+  };
+
+  for (int c = 0; c < PF && c < nchunk; ++c) stage(c);
+  {
+    const int younger = min(PF - 1, nchunk - 1);
+    if (younger >= 2)
+      wait_vmcnt<2 * G>();
+    else if (younger == 1)
+      wait_vmcnt<G>();
+    else
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
   }
+  float4 f0b[MT], f0a[NT], f1b[MT], f1a[NT];
+  read_frags(0, f0b, f0a);
+  int ci = 0;
+  for (; ci + 2 <= nchunk; ci += 2) {
+    iteration(ci, f1b, f1a, f0b, f0a);
+    iteration(ci + 1, f0b, f0a, f1b, f1a);
+  }
+  if (ci < nchunk) iteration(ci, f1b, f1a, f0b, f0a);
+  wait_vmcnt<0>();
 
   // epilogue: lane (r, q) holds OUT[node_base + 16 (MT w + t) + r][j0 + 16 u + 4 q + 0..3]
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int nd = node_base + 16 * (MT * w + t) + r;
     if (nd >= g.n) continue;
+    if (g.debug_noepi && acc[t][0][0] != 12345.678f) continue;
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
       const int j = j0 + 16 * u + 4 * q;
@@ -275,7 +306,7 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
         float4 o = make_float4(elu1(pv.x), elu1(pv.y), elu1(pv.z), elu1(pv.w));
         if (g.p_prev) o = add4(ld4(g.p_prev + off), scale4(g.decay, o));
         st4(g.x_next + off, o);
-      } else {
+      } else if (EPI == EPI_SPLIT) {
         const int orow = g.rows ? g.rows[nd] : nd;
         if (jh == 0)
           st4(g.out0 + (size_t)orow * g.ld_out0 + j, v);
@@ -284,9 +315,42 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
       }
     }
   }
+  if (EPI == EPI_FWD_NORM) {
+    // last layer: F.normalize (modules/model.py:205) fused here.  BN == d, so the 4 lanes (q = 0..3) that share a
+    // node hold its whole row across their NT tiles; the sum of squares is reduced with two xor-shuffles.
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int nd = node_base + 16 * (MT * w + t) + r;
+      const int ndc = min(nd, g.n - 1);
+      float4 xv[NT];
+      float ss = 0.f;
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int j = 16 * u + 4 * q;
+        const float4 bb = add4(ld4(g.b1 + j), ld4(g.b2 + j));
+        const float4 pv = add4(make_float4(acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]), bb);
+        const size_t off = (size_t)ndc * g.ld_out0 + j;
+        if (nd < g.n) st4(g.out0 + off, pv);
+        float4 o = make_float4(elu1(pv.x), elu1(pv.y), elu1(pv.z), elu1(pv.w));
+        if (g.p_prev) o = add4(ld4(g.p_prev + off), scale4(g.decay, o));
+        xv[u] = o;
+        ss += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+      }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+      if (nd < g.n) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) st4(g.x_next + (size_t)nd * g.ld_out0 + 16 * u + 4 * q, scale4(inv, xv[u]));
+        if (q == 0) g.inv_den[nd] = inv;
+      }
+    }
+  }
 }
 
 int g_gemm_variant = 2;
+int g_gemm_noepi = 0;
+int g_gemm_lds_pad = 0;
 
 template <int EPI>
 static int launch_gemm(const GemmArgs &g, int d, hipStream_t st) {
@@ -297,7 +361,8 @@ static int launch_gemm(const GemmArgs &g, int d, hipStream_t st) {
     // W-staging redundancy of small tiles costs more than that buys (measured, tools/gemm_bench.py)
     const int mt = g_gemm_variant == 3 ? 2 : g_gemm_variant == 4 ? 1 : (d >= 256 ? 2 : 1);
     dim3 grid(ceil_div(g.n, 64 * mt), g.J / (16 * nt));
-    const size_t lds = 4 * (size_t)(64 * mt * 16 + 16 * nt * 16) * sizeof(float);
+    size_t lds = 4 * (size_t)(64 * mt * 16 + 16 * nt * 16) * sizeof(float);
+    if (g_gemm_lds_pad > 0) lds = (size_t)g_gemm_lds_pad;  // experiment: cap co-resident workgroups per CU
 #define GSS_GEMM_CASE(NTV)                                                                              \
   case NTV:                                                                                             \
     if (mt == 2)                                                                                        \
@@ -316,6 +381,7 @@ static int launch_gemm(const GemmArgs &g, int d, hipStream_t st) {
     GSS_LAUNCH_CHECK("gemm_nt_lds_kernel");
     return GSS_OK;
   }
+  if (EPI == EPI_FWD_NORM) return fail(GSS_EINVAL, "fused normalise epilogue needs gemm_variant >= 2");
   const int ft = (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
   dim3 grid(ceil_div(g.n, 128), g.J / (16 * ft));
   if (ft == 4)
@@ -354,7 +420,39 @@ int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const floa
   g.x_next = x_next;
   g.decay = decay;
   g.rows = nullptr;
+  g.debug_noepi = g_gemm_noepi;
   return launch_gemm<EPI_FWD>(g, d, as_stream(stream));
+}
+
+// last layer: P as usual, but the residual mix is row-normalised on the fly: e = normalize(p_prev + decay elu(p))
+bool dense_fwd_norm_available(int32_t d) { return g_gemm_variant >= 2 && (d == 128 || d == 64 || d == 32 || d == 16); }
+
+int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
+                   const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(n >= 0 && ax && am && w1 && b1 && w2 && b2 && p && e && inv_den, "dense_fwd_norm: null operand");
+  GSS_REQUIRE(dense_fwd_norm_available(d), "dense_fwd_norm: needs d in {16, 32, 64, 128} and the LDS-staged GEMM");
+  GemmArgs g{};
+  g.n = n;
+  g.K = 2 * d;
+  g.ksplit = d;
+  g.J = d;
+  g.jsplit = d;
+  g.in0 = ax;
+  g.in1 = am;
+  g.ld_in0 = g.ld_in1 = d;
+  g.w[0][0] = w1;
+  g.w[0][1] = w2;
+  g.ld_w = d;
+  g.out0 = p;
+  g.ld_out0 = g.ld_out1 = d;
+  g.b1 = b1;
+  g.b2 = b2;
+  g.p_prev = p_prev;
+  g.x_next = e;
+  g.decay = decay;
+  g.inv_den = inv_den;
+  return launch_gemm<EPI_FWD_NORM>(g, d, as_stream(stream));
 }
 
 int dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t, const float *w2t, const int32_t *rows,

@@ -25,6 +25,9 @@ int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, cons
               float *dp, float *gx_out, void *stream);
 int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
               const float *b2, const float *p_prev, float decay, float *p, float *x_next, void *stream);
+bool dense_fwd_norm_available(int32_t d);
+int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
+                   const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream);
 int dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t, const float *w2t, const int32_t *rows,
                     float *g_ax, float *g_am, void *stream);
 size_t wgrad_workspace_bytes(int32_t n, int32_t d);

@@ -228,8 +228,13 @@ static int plan_forward_impl(gss_plan *p, void *stream) {
       }
       if (l == 0) p->layer1_valid = true;
     }
-    float *xn = (l == L - 1) ? p->x_last : p->xin[l + 1];
     PROF(GSS_PROF_DENSE_FWD);
+    if (l == L - 1 && dense_fwd_norm_available(D.d)) {
+      // last layer: F.normalize fused into the GEMM epilogue (no x_last round trip, no extra launch)
+      return dense_fwd_norm(D.n, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr, D.layer_decay,
+                            p->p[l], p->emb, p->inv_den, stream);
+    }
+    float *xn = (l == L - 1) ? p->x_last : p->xin[l + 1];
     if (int rc = dense_fwd(D.n, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr,
                            D.layer_decay, p->p[l], xn, stream))
       return rc;

@@ -366,6 +366,8 @@ static int launch_spmm_t(const gss_csr *a, int d4, const float *x, const SpmmEpi
 
 int g_spmm_variant = 2;
 extern int g_gemm_variant;
+extern int g_gemm_noepi;
+extern int g_gemm_lds_pad;
 
 // Segment descriptors for the balanced kernel, built on first use for a given groups-per-wave count.
 static int build_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks) {
@@ -630,6 +632,14 @@ int gss_debug_set_option(const char *name, int value) {
   if (strcmp(name, "spmm_variant") == 0) {
     GSS_REQUIRE(value == 1 || value == 2, "spmm_variant must be 1 or 2");
     g_spmm_variant = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "gemm_lds_pad") == 0) {
+    g_gemm_lds_pad = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "gemm_noepi") == 0) {
+    g_gemm_noepi = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_variant") == 0) {
