@@ -52,6 +52,7 @@ SIGNATURES = {
     "gss_scatter_add_rows": (C.c_int, [_I32, _P, _P, _I32, _P, _P]),
     "gss_adam_step": (C.c_int, [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P, _I32, _P]),
     "gss_percentile": (C.c_int, [_I32, _I32, _P, _D, C.POINTER(_F), _P]),
+    "gss_knn_topk": (C.c_int, [_I32, _I32, _P, _I32, _P, _P, _P]),
     "gss_plan_create": (C.c_int, [C.POINTER(_P), C.POINTER(PlanDesc), _P, _P, C.POINTER(PlanIO)]),
     "gss_plan_destroy": (None, [_P]),
     "gss_plan_forward": (C.c_int, [_P, _P]),

@@ -47,6 +47,44 @@ def knn_descriptor_adj(X, k=5, chunk=4096):
     return adj
 
 
+def _symmetrise_topk(top_idx, top_val, n):
+    """helper.py:46-53 on (row, top-k) pairs: x_adj[i, top] = v, x_adj[top, i] = v in a loop over i (the later
+    iteration wins), zero diagonal, exact zeros dropped"""
+    k = top_idx.shape[1]
+    rows = np.repeat(np.arange(n), k)
+    cols = top_idx.reshape(-1).astype(np.int64)
+    vals = top_val.reshape(-1)
+    keep = (rows != cols) & (cols >= 0)
+    rows, cols, vals = rows[keep], cols[keep], vals[keep]
+    r = np.concatenate([rows, cols]); c = np.concatenate([cols, rows])
+    v = np.concatenate([vals, vals]); it = np.concatenate([rows, rows])
+    key = r.astype(np.int64) * n + c
+    order = np.lexsort((it, key))
+    ks = key[order]
+    last = order[np.r_[ks[1:] != ks[:-1], True]] if len(ks) else order
+    adj = sp.csr_matrix((v[last], (r[last], c[last])), shape=(n, n))
+    adj.eliminate_zeros()
+    adj.sort_indices()
+    return adj
+
+
+def knn_descriptor_adj_device(X, k=5, device="cuda"):
+    """gen_graph's kNN adjacency with the N x N similarity and the top-k selection on the GPU (gss_knn_topk, fp64
+    MFMA).  X: [N, d] fp64 (d is zero-padded to a multiple of 8).  Same result as knn_descriptor_adj up to the
+    order of fp64 summation."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, d = X.shape
+    k = min(k, n)
+    if d % 8:
+        X = np.concatenate([X, np.zeros((n, 8 - d % 8))], axis=1)
+    lib = _lib.load()
+    xd = torch.from_numpy(X).to(device)
+    tv = torch.empty(n, k, dtype=torch.float64, device=device)
+    ti = torch.empty(n, k, dtype=torch.int32, device=device)
+    _lib.check(lib.gss_knn_topk(n, X.shape[1], xd.data_ptr(), k, tv.data_ptr(), ti.data_ptr(), _lib.current_stream()), "gss_knn_topk")
+    return _symmetrise_topk(ti.cpu().numpy(), tv.cpu().numpy(), n)
+
+
 def edgelist_adj(src, dst, w, n):
     """directed weighted edgelist -> CSR; a repeated (u, v) keeps the last weight (DiGraph.add_edge)."""
     key = np.asarray(src, np.int64) * n + np.asarray(dst, np.int64)

@@ -19,7 +19,7 @@ from torch.utils.data import DataLoader, Dataset
 
 from . import embio
 from .engine import GssEngine
-from .graph import GssGraph, edgelist_adj, knn_descriptor_adj
+from .graph import GssGraph, edgelist_adj, knn_descriptor_adj_device
 from .model import ResidualGraphConvolutionalNetwork
 
 
@@ -108,7 +108,7 @@ def main(argv=None):
         src, dst, w, _ = embio.read_edgelist(args.adj_file, names)
         adj = edgelist_adj(src, dst, w, n)
     else:
-        adj = knn_descriptor_adj(X, args.k)                   # train.py:93 -> helper.py:39-53
+        adj = knn_descriptor_adj_device(X, args.k, device=dev)   # train.py:93 -> helper.py:39-53, similarity + top-k on device
     graph = GssGraph(adj, device=dev, need_transpose=args.num_layers > 1)   # train.py:100-101
     print('Created G with [k={}] [shape=[{}, {}]] [nnz(A_hat)={}] in {:.2f}s'.format(args.k, n, n, graph.nnz, time.time() - t0))
 

@@ -125,6 +125,12 @@ int gss_adam_step(int64_t count, float *param, const float *grad, float *exp_avg
  * 3-pass radix select on device.  Result to h_out (host float), synchronises the stream. */
 int gss_percentile(int32_t n, int32_t d, const float *e, double q, float *h_out, void *stream);
 
+/* ---- a1  gen_graph's similarity + top-k, helpers/helper.py:39-44 --------------------------------------
+ * x: [n][d] fp64 features (the reference works in fp64 here).  For every row the k largest inner products
+ * x_i . x_j over all j (self included, as np.argpartition(x_sim, -k, 1)[:, -k:] returns them; order within the
+ * k is unspecified) -> top_val [n][k] fp64, top_idx [n][k] int32.  fp64 MFMA; d multiple of 8, k <= 64. */
+int gss_knn_topk(int32_t n, int32_t d, const double *x, int32_t k, double *top_val, int32_t *top_idx, void *stream);
+
 /* ---- whole training step (train.py:158-184) ---------------------------------------------------
  * A plan owns every activation/gradient buffer of one replica so that a step is ONE host call that
  * enqueues all kernels.  a / at: CSR(A_hat) and CSR(A_hat^T) (at may be NULL for num_layers == 1). */

@@ -327,3 +327,28 @@ def test_bad_arguments_fail_loudly(G):
         G._lib.check(G.lib.gss_rownorm_fwd(10, 20, x.data_ptr(), x.data_ptr(), x.data_ptr(), G.st()))
     with pytest.raises(G._lib.GssError):
         G._lib.check(G.lib.gss_dense_fwd(10, 16, None, None, None, None, None, None, None, 0.3, None, None, G.st()))
+
+
+# ---------------------------------------------------------------- a1 (kNN graph on device)
+@pytest.mark.parametrize("name", ["knn_n200_d16_L2", "knn_n2000_d64_L3"])
+def test_knn_graph_device_matches_reference_gen_graph(G, name):
+    g = load_golden(name)
+    ref = golden_csr(g, "A")
+    adj = G.graph.knn_descriptor_adj_device(g["X"].astype(np.float64), 5)
+    assert np.array_equal(adj.indptr, ref.indptr) and np.array_equal(adj.indices, ref.indices)
+    np.testing.assert_allclose(adj.data, ref.data, rtol=1e-12)
+
+
+def test_knn_topk_values_and_odd_sizes(G):
+    rng = np.random.RandomState(3)
+    for n, d, k in ((333, 24, 7), (65, 8, 64), (1000, 128, 5)):
+        x = rng.randn(n, d)
+        xd = cu(x)
+        tv = torch.empty(n, k, dtype=torch.float64, device="cuda")
+        ti = torch.empty(n, k, dtype=torch.int32, device="cuda")
+        G._lib.check(G.lib.gss_knn_topk(n, d, xd.data_ptr(), k, tv.data_ptr(), ti.data_ptr(), G.st()))
+        sim = x @ x.T
+        ref_idx = np.argpartition(sim, -k, 1)[:, -k:]
+        got_idx = ti.cpu().numpy()
+        assert np.array_equal(np.sort(got_idx, 1), np.sort(ref_idx, 1))
+        np.testing.assert_allclose(np.sort(tv.cpu().numpy(), 1), np.sort(np.take_along_axis(sim, ref_idx, 1), 1), rtol=1e-12)
