@@ -216,7 +216,7 @@ __device__ __forceinline__ long compact_off(const SpmmEpi &ep, int row, int d4, 
 
 template <int MODE, int LPR_LOG2, int VPL>
 __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, const int4 *__restrict__ segs, int d4,
-                                                                   const float *__restrict__ x, SpmmEpi ep) {
+                                                                   const float *__restrict__ x, SpmmEpi ep, int rowstride_f) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *part = reinterpret_cast<float4 *>(smem);  // [16 waves][d4]
   constexpr int LPR = 1 << LPR_LOG2;
@@ -231,7 +231,13 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   const int plog = sd.w & 0xff;
   const bool multiwave = (sd.w & 0x100) != 0;  // workgroup-uniform: some row of this workgroup spans several waves
   const bool col_ok = (VPL > 1) || (li < d4);
-  const size_t rowstride = (size_t)d4 * 4;
+  // feature slicing (grid.y): this launch dimension walks d4-wide slices of rows that are rowstride_f floats long;
+  // y is the slow dispatch dimension, so slice s+1 starts when slice s drains and each L2 keeps twice (or four
+  // times) as many hot rows of the current slice
+  const size_t rowstride = (size_t)rowstride_f;
+  const int rs4 = rowstride_f >> 2;
+  const int slice_f4 = blockIdx.y * d4;
+  x += (size_t)slice_f4 * 4;
   float4 acc[VPL];
 #pragma unroll
   for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
         const int f4 = li + v * 64;
-        if (f4 < d4) row_epilogue<MODE>(ep, ((size_t)row * d4 + f4) * 4, acc[v], compact_off<MODE>(ep, row, d4, f4));
+        if (f4 < d4) row_epilogue<MODE>(ep, ((size_t)row * rs4 + slice_f4 + f4) * 4, acc[v], compact_off<MODE>(ep, row, rs4, slice_f4 + f4));
       }
     }
   }
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
       if (f4 >= d4) continue;
       float4 t = part[wib * d4 + f4];
       for (int k = 1; k < nw; ++k) t = add4(t, part[(wib + k) * d4 + f4]);
-      row_epilogue<MODE>(ep, ((size_t)row * d4 + f4) * 4, t, compact_off<MODE>(ep, row, d4, f4));
+      row_epilogue<MODE>(ep, ((size_t)row * rs4 + slice_f4 + f4) * 4, t, compact_off<MODE>(ep, row, rs4, slice_f4 + f4));
     }
   }
 }
@@ -434,28 +440,43 @@ static int build_segments(const gss_csr *a, int gpw_log2, const int4 **out, int 
   return GSS_OK;
 }
 
+int g_spmm_slices = 0;  // 0 = automatic (see launch_balanced)
+
 template <int MODE, int LPR_LOG2, int VPL>
-static int launch_balanced_t(const gss_csr *a, int d4, const float *x, const SpmmEpi &ep, hipStream_t st) {
+static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, const float *x, const SpmmEpi &ep, hipStream_t st) {
   const int4 *segs = nullptr;
   int nblk = 0;
   if (int rc = build_segments(a, 6 - LPR_LOG2, &segs, &nblk)) return rc;
   if (nblk == 0) return GSS_OK;
   CsrView v{a->rowptr, a->col, a->val, a->n_rows};
-  const size_t lds = (size_t)kBalWaves * d4 * sizeof(float4);
-  hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL>), dim3(nblk), dim3(kBalThreads), lds, st, v, segs, d4, x, ep);
+  const size_t lds = (size_t)kBalWaves * d4_slice * sizeof(float4);
+  hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL>), dim3(nblk, nslices), dim3(kBalThreads), lds, st, v, segs, d4_slice, x,
+                     ep, d4_slice * nslices * 4);
   GSS_LAUNCH_CHECK("spmm_balanced_kernel");
   return GSS_OK;
 }
 
 template <int MODE>
 static int launch_balanced(const gss_csr *a, int d4, const float *x, const SpmmEpi &ep, hipStream_t st) {
-  if (d4 <= 4) return launch_balanced_t<MODE, 2, 1>(a, d4, x, ep, st);
-  if (d4 <= 8) return launch_balanced_t<MODE, 3, 1>(a, d4, x, ep, st);
-  if (d4 <= 16) return launch_balanced_t<MODE, 4, 1>(a, d4, x, ep, st);
-  if (d4 <= 32) return launch_balanced_t<MODE, 5, 1>(a, d4, x, ep, st);
-  if (d4 <= 64) return launch_balanced_t<MODE, 6, 1>(a, d4, x, ep, st);
-  if (d4 <= 128) return launch_balanced_t<MODE, 6, 2>(a, d4, x, ep, st);
-  return launch_balanced_t<MODE, 6, 4>(a, d4, x, ep, st);
+  int ns = g_spmm_slices;
+  if (ns == 0) {
+    // automatic: cut the features into time-separated slices (>= 256 B wide) until one slice of the operand is
+    // <= 16 MB -- below that the gather rate is flat (measured: d = 256 at N = 29,960 gains 15-19 %, d = 128
+    // nothing); operands that stay far beyond the L2s even as 256-B slices (RMAT scale) are left whole
+    ns = 1;
+    const double row_bytes = 16.0 * d4;
+    while (d4 % (2 * ns) == 0 && d4 / (2 * ns) >= 16 && (double)a->n_cols * row_bytes / ns > 16.0 * 1024 * 1024) ns *= 2;
+    if ((double)a->n_cols * row_bytes / ns > 16.0 * 1024 * 1024) ns = 1;
+  }
+  if (ns < 1 || d4 % ns != 0 || (d4 / ns) < 4 || MODE == SPMM_BWD1S) ns = 1;  // the sparse mode gathers few rows anyway
+  const int ds = d4 / ns;
+  if (ds <= 4) return launch_balanced_t<MODE, 2, 1>(a, ds, ns, x, ep, st);
+  if (ds <= 8) return launch_balanced_t<MODE, 3, 1>(a, ds, ns, x, ep, st);
+  if (ds <= 16) return launch_balanced_t<MODE, 4, 1>(a, ds, ns, x, ep, st);
+  if (ds <= 32) return launch_balanced_t<MODE, 5, 1>(a, ds, ns, x, ep, st);
+  if (ds <= 64) return launch_balanced_t<MODE, 6, 1>(a, ds, ns, x, ep, st);
+  if (ds <= 128) return launch_balanced_t<MODE, 6, 2>(a, ds, ns, x, ep, st);
+  return launch_balanced_t<MODE, 6, 4>(a, ds, ns, x, ep, st);
 }
 
 template <int MODE>
@@ -632,6 +653,11 @@ int gss_debug_set_option(const char *name, int value) {
   if (strcmp(name, "spmm_variant") == 0) {
     GSS_REQUIRE(value == 1 || value == 2, "spmm_variant must be 1 or 2");
     g_spmm_variant = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "spmm_slices") == 0) {
+    GSS_REQUIRE(value >= 0 && value <= 8, "spmm_slices must be in [0, 8] (0 = automatic)");
+    g_spmm_slices = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_lds_pad") == 0) {

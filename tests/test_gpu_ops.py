@@ -88,11 +88,14 @@ def test_spmm_row_sums_within_1e5(G, op_case):
 
 
 # ---------------------------------------------------------------- K1 / K2 / K9
-@pytest.fixture(params=[1, 2])
+@pytest.fixture(params=[1, 2, 22, 42])
 def spmm_variant(request, G):
-    G._lib.check(G.lib.gss_debug_set_option(b"spmm_variant", request.param))
+    """1 = row-per-wave, 2 = nnz-balanced (auto slicing), 22 / 42 = nnz-balanced with 2 / 4 forced feature slices"""
+    G._lib.check(G.lib.gss_debug_set_option(b"spmm_variant", min(request.param, 2) if request.param < 10 else 2))
+    G._lib.check(G.lib.gss_debug_set_option(b"spmm_slices", request.param // 10))
     yield request.param
     G._lib.check(G.lib.gss_debug_set_option(b"spmm_variant", 2))
+    G._lib.check(G.lib.gss_debug_set_option(b"spmm_slices", 0))
 
 
 @pytest.mark.parametrize("d", [16, 48, 64, 128, 256, 512, 1024])

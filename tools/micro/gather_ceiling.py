@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""ceiling of the SpMM gather on this GPU: stream the graph's col[] array and gather 512-B rows, nothing else.
+Compiles a tiny HIP kernel with hipcc at run time (tools only, not shipped)."""
+import ctypes as C, os, subprocess, sys, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from gcn_drug_repurposing_amd import synth
+import scipy.sparse as sp
+SRC = r'''
+#include <hip/hip_runtime.h>
+// each half-wave (32 lanes x float4 = 512 B) gathers one row per step; UNROLL rows in flight per lane
+template <int UNROLL>
+__global__ __launch_bounds__(256) void gather(const int* __restrict__ col, long nnz, const float* __restrict__ x, float* out, int d4) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, li = lane & 31;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * 4;
+  float4 acc = make_float4(0, 0, 0, 0);
+  for (long base = wave * 64; base < nnz; base += nwaves * 64) {
+    const long e = base + lane;
+    const int c = e < nnz ? col[e] : 0;
+    for (int t = 0; t < 64; t += 2 * UNROLL) {
+      float4 v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int cc = __shfl(c, t + 2 * u + half, 64);
+        v[u] = *reinterpret_cast<const float4*>(x + ((size_t)cc * d4 + li) * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+  }
+  if (acc.x == 12345.f) out[threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
+}
+extern "C" void run(const int* col, long nnz, const float* x, float* out, int d4, int blocks, int unroll, void* st) {
+  if (unroll == 8) gather<8><<<blocks, 256, 0, (hipStream_t)st>>>(col, nnz, x, out, d4);
+  else gather<4><<<blocks, 256, 0, (hipStream_t)st>>>(col, nnz, x, out, d4);
+}
+'''
+tmp = tempfile.mkdtemp()
+open(os.path.join(tmp, "g.hip"), "w").write(SRC)
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", os.path.join(tmp, "g.hip"), "-o", os.path.join(tmp, "g.so")])
+lib = C.CDLL(os.path.join(tmp, "g.so"))
+lib.run.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+adj, _, _ = synth.whole_graph_standin(1)
+a = (adj + sp.eye(adj.shape[0], format="csr")).tocsr(); a.sort_indices()
+n, nnz, d = a.shape[0], a.nnz, 128
+x = torch.randn(n, d, device="cuda"); out = torch.zeros(256, device="cuda")
+rng = np.random.RandomState(0)
+streams = {"graph col[] (CSR order)": a.indices.astype(np.int32),
+           "uniform random": rng.randint(0, n, nnz).astype(np.int32),
+           "graph col[] shuffled": rng.permutation(a.indices).astype(np.int32),
+           "sequential": (np.arange(nnz) % n).astype(np.int32)}
+for name, cols in streams.items():
+    cd = torch.from_numpy(cols).cuda()
+    for blocks in (2048,):
+        for unroll in (4, 8):
+            st = torch.cuda.current_stream().cuda_stream
+            for _ in range(3): lib.run(cd.data_ptr(), nnz, x.data_ptr(), out.data_ptr(), d // 4, blocks, unroll, st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20): lib.run(cd.data_ptr(), nnz, x.data_ptr(), out.data_ptr(), d // 4, blocks, unroll, st)
+            e1.record(); torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 20 * 1e3
+            print(f"{name:28s} blocks={blocks} unroll={unroll}: {us:7.1f} us  gather {nnz * d * 4 / us / 1e6:6.2f} TB/s")
