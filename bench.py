@@ -108,7 +108,12 @@ def main():
     params_host = {"W1": w.astype(np.float32), "b1": np.zeros(d, np.float32), "W2": w.astype(np.float32).copy(),
                    "b2": np.zeros(d, np.float32)}
 
-    if world == 1:
+    sharded = world > 1 or os.environ.get("GSS_FORCE_SHARDED") == "1"   # the env knob lets a 1-GPU box exercise the RCCL path
+    if sharded and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    if not sharded:
         from gcn_drug_repurposing_amd.engine import GssEngine
         graph = GssGraph(adj, need_transpose=L > 1)
         nnz = graph.nnz
@@ -164,7 +169,7 @@ def main():
     }
 
     # ---- roofline leg: HIP events around every kernel class over the same steps (rank 0, single GPU) ----
-    if world == 1:
+    if not sharded:
         engine.profile(True)
         run(args.warmup, args.warmup + args.steps)
         prof = engine.profile_read()
@@ -205,7 +210,7 @@ def main():
             out["ms_per_step_layer1_cached"] = (time.perf_counter() - t1) / args.steps * 1e3
 
     # ---- CPU baseline leg (rank 0, N=1 only): the reference's torch-CPU op sequence on the host cores ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not sharded and not args.no_cpu_baseline:
         from oracle import gss_oracle as O
         from oracle.torch_cpu_path import TorchCpuPath
         a_hat, _ = O.preprocess_graph(adj)
@@ -223,7 +228,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -54,3 +54,26 @@ def test_sharded_hip_matches_reference(world, case):
     assert np.abs(emb - g["emb_last"]).max() / np.abs(g["emb_last"]).max() < 2e-3
     for k, p in zip(("W1", "b1", "W2", "b2"), params):
         assert np.abs(p - g["final_" + k]).max() < 2.5 * float(g["lr"]), k
+
+
+def test_bench_sharded_path_over_rccl_single_rank(tmp_path):
+    """bench.py's multi-GPU branch (torch.distributed 'nccl' == RCCL, TorchComm, ShardedEngine) with one rank, launched
+    the way the driver launches it; must agree with the single-GPU plan's loss after the same steps."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSS_FORCE_SHARDED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    sharded = json.loads(line)
+    assert "node-range shards" in sharded["config"]["parallelism"]
+    ref = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600)
+    assert ref.returncode == 0, ref.stderr[-2000:]
+    single = json.loads([l for l in ref.stdout.splitlines() if l.startswith("{")][-1])
+    assert abs(sharded["config"]["final_loss"] - single["config"]["final_loss"]) < 2e-4 * abs(single["config"]["final_loss"])
