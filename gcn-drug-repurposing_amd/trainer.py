@@ -11,6 +11,7 @@ kNN graph), --out, --cache-layer1, --batch-file (replay recorded batches), --log
 from __future__ import annotations
 
 import argparse
+import os
 import time
 
 import numpy as np
@@ -54,6 +55,9 @@ def build_parser():
     p.add_argument('--cache-layer1', action='store_true', help="keep layer 1's two SpMM results across steps (inputs are constant)")
     p.add_argument('--batch-file', type=str, default=None, help='.npz with batches/batch_sizes to replay instead of sampling')
     p.add_argument('--log-loss', action='store_true', help='print the last loss of every epoch')
+    p.add_argument('--ngpus', type=int, default=None,
+                   help='node-range shards over N GPUs of this node; launch with `python -m torch.distributed.run '
+                        '--nproc-per-node N train.py ...` (defaults to WORLD_SIZE)')
     return p
 
 
@@ -91,8 +95,21 @@ def main(argv=None):
         raise Exception("--graph-mode ransac/approx_ransac need the image-retrieval RANSAC graphs the reference never ships")
     if not torch.cuda.is_available():
         raise RuntimeError("no GPU visible: this trainer has no CPU path (the reference's CPU path is the oracle, not the product)")
-    dev = torch.device('cuda', args.gpu_id if args.gpu_id is not None else 0)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.ngpus is not None and args.ngpus != world:
+        raise Exception(f"--ngpus {args.ngpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run "
+                        f"--nproc-per-node {args.ngpus} --master-addr 127.0.0.1 train.py ...")
+    sharded = world > 1 or os.environ.get("GSS_FORCE_SHARDED") == "1"
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device('cuda', args.gpu_id if (args.gpu_id is not None and world == 1) else local)
     torch.cuda.set_device(dev)
+    if sharded:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29519")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.seed:                       # seed 0 / None leaves the RNGs unseeded, like train.py:74-76
         torch.manual_seed(args.seed)
@@ -109,17 +126,39 @@ def main(argv=None):
         adj = edgelist_adj(src, dst, w, n)
     else:
         adj = knn_descriptor_adj_device(X, args.k, device=dev)   # train.py:93 -> helper.py:39-53, similarity + top-k on device
-    graph = GssGraph(adj, device=dev, need_transpose=args.num_layers > 1)   # train.py:100-101
-    print('Created G with [k={}] [shape=[{}, {}]] [nnz(A_hat)={}] in {:.2f}s'.format(args.k, n, n, graph.nnz, time.time() - t0))
+    graph = None
+    if not sharded:
+        graph = GssGraph(adj, device=dev, need_transpose=args.num_layers > 1)   # train.py:100-101
+        print('Created G with [k={}] [shape=[{}, {}]] [nnz(A_hat)={}] in {:.2f}s'.format(args.k, n, n, graph.nnz, time.time() - t0))
 
     bsz = args.batch_size if args.batch_size > 0 else n
     model = ResidualGraphConvolutionalNetwork(train_batch_size=bsz, val_batch_size=n, num_layers=args.num_layers,
                                               hidden_units=args.hidden_units, init_weights=args.init_weights,
                                               layer_decay=args.layer_decay).to(dev)   # train.py:111-121
-    feats = torch.tensor(X, dtype=torch.float32).to(dev)      # method/dataset.py:13
-    params = [p.data for p in model._params()]
-    engine = GssEngine(graph, feats, params, num_layers=args.num_layers, layer_decay=args.layer_decay, alpha=args.alpha,
-                       lr=args.lr, max_batch=min(bsz, n), cache_layer1=args.cache_layer1)
+    if sharded:
+        # one process per GPU, node-range shards, RCCL all-gather per SpMM hop (dist.py); same step semantics
+        from .dist import ShardedEngine
+        from . import _lib
+        host_params = {k: p.detach().cpu().numpy() for k, p in zip(("W1", "b1", "W2", "b2"), model._params())}
+        engine = ShardedEngine(adj, X.astype(np.float32), host_params, num_layers=args.num_layers, layer_decay=args.layer_decay,
+                               alpha=args.alpha, lr=args.lr, max_batch=min(bsz, n), device=dev)
+
+        def full_embeddings():
+            return engine.gather_embeddings().contiguous()
+
+        def percentile(q):
+            import ctypes as C
+            e = full_embeddings()
+            out = C.c_float()
+            _lib.check(_lib.load().gss_percentile(n, d, e.data_ptr(), float(q), C.byref(out), _lib.current_stream()), "gss_percentile")
+            return float(out.value)
+    else:
+        feats = torch.tensor(X, dtype=torch.float32).to(dev)      # method/dataset.py:13
+        params = [p.data for p in model._params()]
+        engine = GssEngine(graph, feats, params, num_layers=args.num_layers, layer_decay=args.layer_decay, alpha=args.alpha,
+                           lr=args.lr, max_batch=min(bsz, n), cache_layer1=args.cache_layer1)
+        full_embeddings = lambda: engine.emb          # noqa: E731
+        percentile = engine.percentile
     loader = DataLoader(_IndexDataset(n), batch_size=bsz, shuffle=True, num_workers=0, drop_last=False)
 
     replay = None
@@ -140,12 +179,15 @@ def main(argv=None):
             batches = epoch_batches(loader)
         sizes = [int(b.numel()) for b in batches]
         idx32 = torch.cat(batches).to(torch.int32).to(dev)
+        if sharded and world > 1:
+            import torch.distributed as dist
+            dist.broadcast(idx32, src=0)     # every rank trains on rank 0's batches even when no --seed is given
         off = 0
         for batch_id, b in enumerate(sizes):
             if itr == 0 and batch_id == 0:
                 engine.forward()                              # train.py:158-161
                 if args.beta_percentile is not None:
-                    beta_score = engine.percentile(args.beta_percentile)   # train.py:165-167
+                    beta_score = percentile(args.beta_percentile)   # train.py:165-167
                     print(f"selected beta:{beta_score}")
                 engine.loss_backward(idx32, beta_score, count=b, offset=off)   # train.py:175,183
                 engine.adam()                                 # train.py:184
@@ -160,7 +202,12 @@ def main(argv=None):
             print(f"iter {itr}")
     torch.cuda.synchronize()
     # embeddings of the last forward, i.e. before the last optimizer step (train.py:158,193)
-    embio.write_graph_embs(args.out, engine.emb.cpu().numpy())
+    final = full_embeddings().cpu().numpy()
+    if rank == 0:
+        embio.write_graph_embs(args.out, final)
+    if sharded and world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     return engine
 
 

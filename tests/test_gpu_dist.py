@@ -77,3 +77,25 @@ def test_bench_sharded_path_over_rccl_single_rank(tmp_path):
     assert ref.returncode == 0, ref.stderr[-2000:]
     single = json.loads([l for l in ref.stdout.splitlines() if l.startswith("{")][-1])
     assert abs(sharded["config"]["final_loss"] - single["config"]["final_loss"]) < 2e-4 * abs(single["config"]["final_loss"])
+
+
+def test_trainer_cli_sharded_mode_writes_the_same_embeddings(tmp_path):
+    """train.py under the RCCL sharded engine (one rank) vs the single-GPU plan: same graph_embs.txt"""
+    import os
+    import subprocess
+    import sys
+    g = load_golden("train_py_n200_d16")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    emb_path = tmp_path / "in.embs.txt"
+    emb_path.write_bytes(bytes(g["in_embs_txt"]))
+    outs = []
+    for mode, env_extra in (("single", {}), ("sharded", {"GSS_FORCE_SHARDED": "1", "MASTER_PORT": "29541"})):
+        out = tmp_path / f"{mode}.txt"
+        cmd = [sys.executable, os.path.join(root, "train.py"), "--emb-file", str(emb_path), "--num-layers", "2", "--hidden-units", "16",
+               "--k", "5", "--epochs", "3", "--lr", "0.0003", "--beta-percentile", "98", "--batch-size", "64", "--seed", "7", "--out", str(out)]
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **env_extra), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.loadtxt(str(out)))
+    assert np.abs(outs[0] - outs[1]).max() < 1e-5
+    ref = np.loadtxt(bytes(g["graph_embs_txt"]).decode().splitlines())
+    assert np.abs(outs[1] - ref).max() < 5e-3
