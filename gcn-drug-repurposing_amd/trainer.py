@@ -131,16 +131,29 @@ def main(argv=None):
         graph = GssGraph(adj, device=dev, need_transpose=args.num_layers > 1)   # train.py:100-101
         print('Created G with [k={}] [shape=[{}, {}]] [nnz(A_hat)={}] in {:.2f}s'.format(args.k, n, n, graph.nnz, time.time() - t0))
 
+    # the kernels want a feature width that is a multiple of 16; the reference takes any --hidden-units.  Zero
+    # padding is exact: padded columns of X, W (rows and columns) and b are zero, so AX, AM, P, ELU(P), the row
+    # norms, every gradient and every Adam update are identically zero there; they are stripped on output.
+    d_pad = (d + 15) // 16 * 16
     bsz = args.batch_size if args.batch_size > 0 else n
     model = ResidualGraphConvolutionalNetwork(train_batch_size=bsz, val_batch_size=n, num_layers=args.num_layers,
                                               hidden_units=args.hidden_units, init_weights=args.init_weights,
                                               layer_decay=args.layer_decay).to(dev)   # train.py:111-121
+    host_params = {k: p.detach().cpu().numpy() for k, p in zip(("W1", "b1", "W2", "b2"), model._params())}
+    X32 = X.astype(np.float32)
+    if d_pad != d:
+        X32 = np.concatenate([X32, np.zeros((n, d_pad - d), np.float32)], axis=1)
+        for k in ("W1", "W2"):
+            w = np.zeros((d_pad, d_pad), np.float32)
+            w[:d, :d] = host_params[k]
+            host_params[k] = w
+        for k in ("b1", "b2"):
+            host_params[k] = np.concatenate([host_params[k], np.zeros(d_pad - d, np.float32)])
     if sharded:
         # one process per GPU, node-range shards, RCCL all-gather per SpMM hop (dist.py); same step semantics
         from .dist import ShardedEngine
         from . import _lib
-        host_params = {k: p.detach().cpu().numpy() for k, p in zip(("W1", "b1", "W2", "b2"), model._params())}
-        engine = ShardedEngine(adj, X.astype(np.float32), host_params, num_layers=args.num_layers, layer_decay=args.layer_decay,
+        engine = ShardedEngine(adj, X32, host_params, num_layers=args.num_layers, layer_decay=args.layer_decay,
                                alpha=args.alpha, lr=args.lr, max_batch=min(bsz, n), device=dev)
 
         def full_embeddings():
@@ -150,11 +163,11 @@ def main(argv=None):
             import ctypes as C
             e = full_embeddings()
             out = C.c_float()
-            _lib.check(_lib.load().gss_percentile(n, d, e.data_ptr(), float(q), C.byref(out), _lib.current_stream()), "gss_percentile")
+            _lib.check(_lib.load().gss_percentile(n, d_pad, e.data_ptr(), float(q), C.byref(out), _lib.current_stream()), "gss_percentile")
             return float(out.value)
     else:
-        feats = torch.tensor(X, dtype=torch.float32).to(dev)      # method/dataset.py:13
-        params = [p.data for p in model._params()]
+        feats = torch.from_numpy(X32).to(dev)                    # method/dataset.py:13
+        params = [torch.from_numpy(host_params[k]).to(dev) for k in ("W1", "b1", "W2", "b2")]
         engine = GssEngine(graph, feats, params, num_layers=args.num_layers, layer_decay=args.layer_decay, alpha=args.alpha,
                            lr=args.lr, max_batch=min(bsz, n), cache_layer1=args.cache_layer1)
         full_embeddings = lambda: engine.emb          # noqa: E731
@@ -202,7 +215,7 @@ def main(argv=None):
             print(f"iter {itr}")
     torch.cuda.synchronize()
     # embeddings of the last forward, i.e. before the last optimizer step (train.py:158,193)
-    final = full_embeddings().cpu().numpy()
+    final = full_embeddings().cpu().numpy()[:, :d]
     if rank == 0:
         embio.write_graph_embs(args.out, final)
     if sharded and world > 1:
