@@ -227,14 +227,24 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
 #pragma unroll
     for (int u = 0; u < NT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto read_frags = [&](int ci, float4 (&b)[MT], float4 (&a)[NT]) {
+  for (int c = 0; c < PF && c < nchunk; ++c) stage(c);
+  for (int ci = 0; ci < nchunk; ++ci) {
+    // chunk ci has landed once at most min(PF-1, nchunk-1-ci) younger chunks of this wave are outstanding
+    const int younger = min(PF - 1, nchunk - 1 - ci);
+    if (younger >= 2)
+      wait_vmcnt<2 * G>();
+    else if (younger == 1)
+      wait_vmcnt<G>();
+    else
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // every wave's share of chunk ci is in LDS; buffer (ci-1)%NBUF is free again
     const float *cur = lds + (ci % NBUF) * BUF;
+    float4 b[MT], a[NT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) b[t] = *reinterpret_cast<const float4 *>(cur + (MT * w + t) * 256 + lane * 4);
 #pragma unroll
     for (int u = 0; u < NT; ++u) a[u] = *reinterpret_cast<const float4 *>(cur + XT + u * 256 + lane * 4);
-  };
-  auto mma = [&](const float4 (&b)[MT], const float4 (&a)[NT]) {
+    if (ci + PF < nchunk) stage(ci + PF);  // into buffer (ci-1)%NBUF, last read before the barrier above
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -247,46 +257,8 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
         }
       }
     }
-  };
-  // One iteration: fragments of chunk ci are (being) read into `fa`; wait for them, make sure chunk ci+1 has landed
-  // for every wave (counted vmcnt + barrier), start reading its fragments into `fb`, issue the DMA of chunk ci+PF
-  // into the buffer chunk ci-1 used (its reads completed before this barrier), then run the MFMAs of chunk ci
-  // while both the LDS reads and the DMA are in flight.
-  auto iteration = [&](int ci, float4 (&fb_b)[MT], float4 (&fb_a)[NT], const float4 (&fa_b)[MT], const float4 (&fa_a)[NT]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (ci + 1 < nchunk) {
-      if (ci + 2 < nchunk)
-        wait_vmcnt<G>();
-      else
-        wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    if (ci + 1 < nchunk) read_frags(ci + 1, fb_b, fb_a);
-    if (ci + PF < nchunk) stage(ci + PF);
-    mma(fa_b, fa_a);
     __builtin_amdgcn_sched_barrier(0);  // keep the MFMA cluster inside its iteration
-  };
-
-  for (int c = 0; c < PF && c < nchunk; ++c) stage(c);
-  {
-    const int younger = min(PF - 1, nchunk - 1);
-    if (younger >= 2)
-      wait_vmcnt<2 * G>();
-    else if (younger == 1)
-      wait_vmcnt<G>();
-    else
-      wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
   }
-  float4 f0b[MT], f0a[NT], f1b[MT], f1a[NT];
-  read_frags(0, f0b, f0a);
-  int ci = 0;
-  for (; ci + 2 <= nchunk; ci += 2) {
-    iteration(ci, f1b, f1a, f0b, f0a);
-    iteration(ci + 1, f0b, f0a, f1b, f1a);
-  }
-  if (ci < nchunk) iteration(ci, f1b, f1a, f0b, f0a);
-  wait_vmcnt<0>();
 
   // epilogue: lane (r, q) holds OUT[node_base + 16 (MT w + t) + r][j0 + 16 u + 4 q + 0..3]
 #pragma unroll
