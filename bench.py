@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--workload", default="whole_graph")
     ap.add_argument("--hidden-units", type=int, default=None)
     ap.add_argument("--cache-layer1", action="store_true", help="also report the step time with layer-1 SpMMs cached")
+    ap.add_argument("--pipeline", action="store_true", help="cross-step layer-1 software pipelining on a second HIP stream "
+                                                             "(measured: no gain, off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6)
     args = ap.parse_args()
@@ -119,8 +121,9 @@ def main():
         nnz = graph.nnz
         feats = torch.from_numpy(x_host).cuda()
         params = [torch.from_numpy(params_host[k].copy()).cuda() for k in ("W1", "b1", "W2", "b2")]
-        engine = GssEngine(graph, feats, params, num_layers=L, layer_decay=decay, alpha=alpha, lr=lr, max_batch=B)
-        parallelism = "single"
+        engine = GssEngine(graph, feats, params, num_layers=L, layer_decay=decay, alpha=alpha, lr=lr, max_batch=B,
+                           pipeline_layer1=args.pipeline)
+        parallelism = "single" if not args.pipeline else "single GPU; next step's layer-1 SpMMs on a 2nd HIP stream"
     else:
         from gcn_drug_repurposing_amd.dist import ShardedEngine
         engine = ShardedEngine(adj, x_host, params_host, num_layers=L, layer_decay=decay, alpha=alpha, lr=lr, max_batch=B)

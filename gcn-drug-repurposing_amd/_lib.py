@@ -21,7 +21,7 @@ class GssError(RuntimeError):
 class PlanDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("d", C.c_int32), ("num_layers", C.c_int32), ("max_batch", C.c_int32),
                 ("layer_decay", C.c_float), ("alpha", C.c_float), ("lr", C.c_float), ("beta1", C.c_float),
-                ("beta2", C.c_float), ("eps", C.c_float), ("cache_layer1", C.c_int32)]
+                ("beta2", C.c_float), ("eps", C.c_float), ("cache_layer1", C.c_int32), ("pipeline_layer1", C.c_int32)]
 
 
 class PlanIO(C.Structure):

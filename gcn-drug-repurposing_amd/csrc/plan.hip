@@ -29,6 +29,13 @@ struct gss_plan {
   void *loss_ws, *wgrad_ws;
   int32_t step;
   bool layer1_valid;
+  // software pipelining of layer 1 across steps (desc.pipeline_layer1): its two SpMMs read only constants (A_hat, X), so
+  // step t+1's run on `side` underneath step t's MFMA-bound kernels, into the other half of a double buffer
+  hipStream_t side;
+  hipEvent_t ev_main_ready, ev_side_done;
+  float *ax0[2], *am0[2], *m_side;
+  int cur0;
+  bool prefetched;
   bool wt_valid;      // w1t/w2t match w1/w2 (maintained by the fused Adam inside gss_plan_step only)
   int wg_total;       // slices of the shared weight-gradient partial buffer
   // optional per-kernel-class timing with HIP events on the caller's stream (bench.py roofline leg)
@@ -99,6 +106,12 @@ void carve(gss_plan *p, Carver &c) {
     p->xin[l] = l == 0 ? const_cast<float *>(p->x) : c.take<float>(nd);
   }
   p->m_tmp = c.take<float>(nd);
+  p->ax0[0] = p->ax[0];
+  p->am0[0] = p->am[0];
+  const bool pipe = D.pipeline_layer1 != 0;
+  p->ax0[1] = pipe ? c.take<float>(nd) : nullptr;
+  p->am0[1] = pipe ? c.take<float>(nd) : nullptr;
+  p->m_side = pipe ? c.take<float>(nd) : nullptr;
   p->x_last = c.take<float>(nd);
   p->inv_den = c.take<float>(D.n);
   if (L > 1) {
@@ -189,6 +202,20 @@ int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a,
   Carver real;
   real.base = p->slab;
   carve(p, real);
+  p->side = nullptr;
+  p->ev_main_ready = p->ev_side_done = nullptr;
+  p->cur0 = 0;
+  p->prefetched = false;
+  if (desc->pipeline_layer1) {
+    e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_main_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_side_done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      (void)hipFree(p->slab);
+      delete p;
+      return fail(GSS_EHIP, "plan_create: side stream/events -> %s", hipGetErrorString(e));
+    }
+  }
   if (p->pos) {
     e = hipMemset(p->pos, 0xff, sizeof(int32_t) * (size_t)desc->n);  // all -1
     if (e != hipSuccess) {
@@ -204,17 +231,56 @@ int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a,
 void gss_plan_destroy(gss_plan *p) {
   if (!p) return;
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+  if (p->side) {
+    (void)hipStreamSynchronize(p->side);
+    (void)hipStreamDestroy(p->side);
+  }
+  if (p->ev_main_ready) (void)hipEventDestroy(p->ev_main_ready);
+  if (p->ev_side_done) (void)hipEventDestroy(p->ev_side_done);
   if (p->slab) (void)hipFree(p->slab);
   delete p;
 }
 
-static int plan_forward_impl(gss_plan *p, void *stream) {
+// enqueue layer 1's SpMMs for the NEXT step on the side stream, to start once the main stream reaches this point
+static int plan_prefetch_layer1(gss_plan *p, void *main_stream) {
+  const gss_plan_desc &D = p->desc;
+  const int nxt = p->cur0 ^ 1;
+  // everything step t-1 read from buffer set `nxt` precedes this point of the main stream
+  GSS_HIP(hipEventRecord(p->ev_main_ready, as_stream(main_stream)));
+  GSS_HIP(hipStreamWaitEvent(p->side, p->ev_main_ready, 0));
+  {
+    void *stream = p->side;
+    {
+      PROF(GSS_PROF_SPMM_FWD_HAD);
+      if (int rc = spmm_fwd(p->a, D.d, p->x, p->ax0[nxt], p->x, p->m_side, stream)) return rc;
+    }
+    PROF(GSS_PROF_SPMM_FWD);
+    if (int rc = spmm_fwd(p->a, D.d, p->m_side, p->am0[nxt], nullptr, nullptr, stream)) return rc;
+  }
+  GSS_HIP(hipEventRecord(p->ev_side_done, p->side));
+  p->prefetched = true;
+  return GSS_OK;
+}
+
+static int plan_forward_impl(gss_plan *p, void *stream, bool pipelined = false) {
   GSS_REQUIRE(p, "plan_forward: null plan");
   const gss_plan_desc &D = p->desc;
   const int L = D.num_layers;
+  bool have_l0 = false;
+  if (p->prefetched) {
+    // layer 1 of this step was computed on the side stream during the previous step
+    GSS_HIP(hipStreamWaitEvent(as_stream(stream), p->ev_side_done, 0));
+    p->prefetched = false;
+    p->cur0 ^= 1;
+    p->ax[0] = p->ax0[p->cur0];
+    p->am[0] = p->am0[p->cur0];
+    have_l0 = true;
+  }
   for (int l = 0; l < L; ++l) {
     const float *xl = p->xin[l];
-    const bool cached = (l == 0 && D.cache_layer1 && p->layer1_valid);
+    const bool cached = (l == 0 && ((D.cache_layer1 && p->layer1_valid) || have_l0));
+    // the next step's layer-1 SpMMs go to the side stream when this stream reaches its last (MFMA-bound) GEMM
+    (void)pipelined;
     if (!cached) {
       // AX = A x ; M = AX (.) x      (model.py:163,168)
       {
@@ -384,7 +450,10 @@ int gss_plan_adam(gss_plan *p, void *stream) {
 }
 int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
   GSS_REQUIRE(p, "plan_step: null plan");
-  if (int rc = plan_forward_impl(p, stream)) return rc;
+  const bool pipe = p->desc.pipeline_layer1 && p->side && !p->prof_on && !p->desc.cache_layer1;
+  if (int rc = plan_forward_impl(p, stream, pipe)) return rc;
+  if (pipe)  // the side stream starts when this stream reaches the loss kernel (MFMA-bound, 1 MB working set)
+    if (int rc = plan_prefetch_layer1(p, stream)) return rc;
   if (int rc = plan_loss_backward_impl(p, idx, b, beta, p->wt_valid, stream)) return rc;
   if (int rc = plan_adam_impl(p, stream)) return rc;
   p->wt_valid = p->desc.num_layers > 1;

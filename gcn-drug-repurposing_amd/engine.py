@@ -18,7 +18,7 @@ PARAM_NAMES = ("W1", "b1", "W2", "b2")
 
 class GssEngine:
     def __init__(self, graph: GssGraph, x: torch.Tensor, params, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4,
-                 max_batch=None, cache_layer1=False, betas=(0.9, 0.999), eps=1e-8):
+                 max_batch=None, cache_layer1=False, betas=(0.9, 0.999), eps=1e-8, pipeline_layer1=False):
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
         n, d = x.shape
         assert n == graph.n, f"features have {n} rows, graph has {graph.n} nodes"
@@ -37,7 +37,8 @@ class GssEngine:
         self.grads = [torch.zeros(s, dtype=torch.float32, device=dev) for s in shapes]
         self.lib = _lib.load()
         self.desc = _lib.PlanDesc(n, d, self.num_layers, self.max_batch, float(layer_decay), float(alpha), float(lr),
-                                  float(betas[0]), float(betas[1]), float(eps), 1 if cache_layer1 else 0)
+                                  float(betas[0]), float(betas[1]), float(eps), 1 if cache_layer1 else 0,
+                                  1 if (pipeline_layer1 and not cache_layer1) else 0)
         io = _lib.PlanIO(x.data_ptr(), *[p.data_ptr() for p in self.params], self.emb.data_ptr(), self.loss.data_ptr(),
                          *[g.data_ptr() for g in self.grads])
         self._param_ptrs = [p.data_ptr() for p in self.params]

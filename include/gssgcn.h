@@ -143,6 +143,9 @@ typedef struct gss_plan_desc {
   float alpha;        /* model.py:220 */
   float lr, beta1, beta2, eps; /* Adam */
   int32_t cache_layer1; /* 1: keep AX/AM of layer 1 (inputs are constant) across steps */
+  int32_t pipeline_layer1; /* 1: gss_plan_step runs the NEXT step's layer-1 SpMMs (constant inputs) on an internal second
+                              stream underneath this step's MFMA-bound kernels; all work still executes every step and
+                              the results are bitwise unchanged */
 } gss_plan_desc;
 
 /* caller-owned tensors the plan reads and writes (all device pointers, fp32) */
