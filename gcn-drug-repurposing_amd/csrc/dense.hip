@@ -495,21 +495,34 @@ __global__ __launch_bounds__(64 * kWgWaves) void wgrad_tn_kernel(WgradArgs g) {
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 
 
-  for (int base = r0 + 4 * w; base < r1; base += 4 * kWgWaves) {
-    const int row = base + q;
-    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
-    if (row < r1) {
-      a4 = ld4(g.dp + (size_t)row * g.d + ac);
-      const int zr = g.rows ? g.rows[row] : row;
-      b4 = ld4(z + (size_t)zr * g.d + zc);
+  // four row-steps per trip: all 8 operand loads are issued first (branch-free: rows beyond the slice read a
+  // valid row and are multiplied by 0), then the 64 MFMAs run while the next trip's loads are in flight
+  constexpr int U = 4;
+  for (int base = r0 + 4 * w; base < r1; base += 4 * kWgWaves * U) {
+    float4 a4[U], b4[U];
+    float msk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = base + u * 4 * kWgWaves + q;
+      const bool ok = row < r1;
+      const int rc = ok ? row : r1 - 1;
+      msk[u] = ok ? 1.f : 0.f;
+      a4[u] = ld4(g.dp + (size_t)rc * g.d + ac);
+      const int zr = g.rows ? g.rows[rc] : rc;
+      b4[u] = ld4(z + (size_t)zr * g.d + zc);
     }
-    cs = add4(cs, a4);
-    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-    const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int u = 0; u < U; ++u) {
+      const float4 am = scale4(msk[u], a4[u]);
+      cs = add4(cs, am);
+      const float av[4] = {am.x, am.y, am.z, am.w};
+      const float bv[4] = {b4[u].x, b4[u].y, b4[u].z, b4[u].w};
 #pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) acc[e][e2] = mfma16(av[e], bv[e2], acc[e][e2]);
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) acc[e][e2] = mfma16(av[e], bv[e2], acc[e][e2]);
+    }
   }
 
   // tree reduction over the 8 waves (fixed order): 4..7 -> 0..3, 2..3 -> 0..1, 1 -> 0
