@@ -200,11 +200,11 @@ __global__ __launch_bounds__(kLongThreads) void spmm_long_kernel(CsrView a, cons
 // cover one feature row (32 lanes x float4 = 512 B at d = 128).  A row with s segments occupies an aligned
 // block of p = pow2ceil(s) consecutive groups of one 1024-thread workgroup (16 waves); rows too long for that
 // take the whole workgroup with longer segments.  Each group loads its segment's (col,val) pairs with one
-// coalesced access, broadcasts them with ds_bpermute and keeps 8 row gathers in flight.  Partial sums are
+// coalesced access, broadcasts them with ds_bpermute and keeps 4 row gathers in flight.  Partial sums are
 // combined with xor-shuffles inside a wave and through LDS across the waves of a row's block, always in the
 // same order -> bitwise reproducible, no atomics, no second pass.
 constexpr int kSegEdges = 32;
-constexpr int kBalThreads = 1024;  // 512-thread workgroups (with or without a 64-VGPR cap) measured 5-30 % slower
+constexpr int kBalThreads = 1024;  // 512-thread workgroups measured 5-30 % slower (hub rows get half the groups)
 constexpr int kBalWaves = kBalThreads / 64;
 
 template <int MODE>
@@ -274,11 +274,15 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
       }
       continue;
     }
-    for (int t = 0; __any(t < cnt); t += 8) {
-      float4 xv[8][VPL];
-      float wv[8];
+    // kFly row gathers in flight per lane group.  Measured at config 2 (d = 128): 16 -> 44.1 us, 8 -> 39.5 us,
+    // 4 -> 36.2 us, 2 -> 37.7 us.  Deeper queues only add L2 thrash; at 4 the kernel needs 48 VGPRs, so two
+    // 1024-thread workgroups share a CU (32 waves) instead of one.
+    constexpr int kFly = 4;
+    for (int t = 0; __any(t < cnt); t += kFly) {
+      float4 xv[kFly][VPL];
+      float wv[kFly];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kFly; ++u) {
         const int src = (g << LPR_LOG2) + ((t + u) & (LPR - 1));
         const int cc = __shfl(c, src, 64);
         wv[u] = __shfl(w, src, 64);
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
         }
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < kFly; ++u)
 #pragma unroll
         for (int v = 0; v < VPL; ++v) acc[v] = fma4(wv[u], xv[u][v], acc[v]);
     }

@@ -18,7 +18,7 @@ g = GssGraph(adj)
 n, nnz = g.n, g.nnz
 print(f"graph {which}: N={n} nnz={nnz} long_rows={(np.diff(g.a.h_indptr) > 512).sum()}")
 for d in [int(v) for v in (sys.argv[4:] or ["16", "32", "64", "128", "256"])]:
-  for variant in (2, 22, 42):
+  for variant in (1, 2):
     lib.gss_debug_set_option(b"spmm_variant", 2)
     lib.gss_debug_set_option(b"spmm_slices", max(1, variant // 10))
     x = torch.randn(n, d, device="cuda")
