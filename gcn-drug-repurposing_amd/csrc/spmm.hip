@@ -196,14 +196,15 @@ __global__ __launch_bounds__(kLongThreads) void spmm_long_kernel(CsrView a, cons
 // requests) and ran slower (111 us vs 90 us at d = 128) -- gathers must stay whole 128-B lines.
 //
 // Here the host cuts every row into segments of <= kSegEdges entries (build_segments, once per feature width)
-// and packs them into a descriptor list, one descriptor per lane group; a lane group is the LPR lanes that
+// and packs them into a descriptor list, one descriptor per lane group (kSegEdges = 32 by default); a lane group is the LPR lanes that
 // cover one feature row (32 lanes x float4 = 512 B at d = 128).  A row with s segments occupies an aligned
 // block of p = pow2ceil(s) consecutive groups of one 1024-thread workgroup (16 waves); rows too long for that
 // take the whole workgroup with longer segments.  Each group loads its segment's (col,val) pairs with one
 // coalesced access, broadcasts them with ds_bpermute and keeps 4 row gathers in flight.  Partial sums are
 // combined with xor-shuffles inside a wave and through LDS across the waves of a row's block, always in the
 // same order -> bitwise reproducible, no atomics, no second pass.
-constexpr int kSegEdges = 32;
+constexpr int kSegEdgesDefault = 32;
+int g_seg_edges = kSegEdgesDefault;  // debug knob "spmm_seg_edges" (applies to CSR handles created afterwards)
 constexpr int kBalThreads = 1024;  // 512-thread workgroups measured 5-30 % slower (hub rows get half the groups)
 constexpr int kBalWaves = kBalThreads / 64;
 
@@ -387,6 +388,7 @@ static int build_segments(const gss_csr *a, int gpw_log2, const int4 **out, int 
     *n_blocks = m->n_seg_blocks[gpw_log2];
     return GSS_OK;
   }
+  const int kSegEdges = g_seg_edges;
   const int gpw = 1 << gpw_log2;
   const int ngb = kBalWaves * gpw;  // groups per workgroup
   int ngb_log2 = 0;
@@ -657,6 +659,11 @@ int gss_debug_set_option(const char *name, int value) {
   if (strcmp(name, "spmm_variant") == 0) {
     GSS_REQUIRE(value == 1 || value == 2, "spmm_variant must be 1 or 2");
     g_spmm_variant = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "spmm_seg_edges") == 0) {
+    GSS_REQUIRE(value >= 4 && value <= 1024, "spmm_seg_edges must be in [4, 1024]");
+    g_seg_edges = value;
     return GSS_OK;
   }
   if (strcmp(name, "spmm_slices") == 0) {
