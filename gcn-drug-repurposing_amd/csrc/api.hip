@@ -1,11 +1,43 @@
-// api.hip -- ABI version and error text.
+// api.hip -- ABI version, error text and the tuning / A-B knobs.
 #include "common.h"
 
 namespace gss {
 thread_local char g_err[512] = "";
-}
+extern int g_spmm_variant;  // spmm.hip
+extern int g_spmm_slices;
+extern int g_seg_edges;
+extern int g_gemm_variant;  // dense.hip
+}  // namespace gss
+
+using namespace gss;
 
 extern "C" {
 int gss_abi_version(void) { return GSS_ABI_VERSION; }
 const char *gss_last_error(void) { return gss::g_err; }
+
+// Every knob selects between implementations that all produce correct results (the tests run them all).
+int gss_debug_set_option(const char *name, int value) {
+  GSS_REQUIRE(name, "debug_set_option: null name");
+  if (strcmp(name, "spmm_variant") == 0) {
+    GSS_REQUIRE(value == 1 || value == 2, "spmm_variant must be 1 (row per wave) or 2 (nnz-balanced segments)");
+    g_spmm_variant = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "spmm_slices") == 0) {
+    GSS_REQUIRE(value >= 0 && value <= 8, "spmm_slices must be in [0, 8] (0 = automatic)");
+    g_spmm_slices = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "spmm_seg_edges") == 0) {
+    GSS_REQUIRE(value >= 4 && value <= 1024, "spmm_seg_edges must be in [4, 1024]");
+    g_seg_edges = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "gemm_variant") == 0) {
+    GSS_REQUIRE(value >= 1 && value <= 4, "gemm_variant must be 1..4");
+    g_gemm_variant = value;
+    return GSS_OK;
+  }
+  return fail(GSS_EINVAL, "unknown option %s", name);
+}
 }

@@ -41,7 +41,6 @@ struct GemmArgs {
   float decay;
   // EPI_SPLIT
   const int32_t *rows;  // scatter map for the output row (nullable)
-  int debug_noepi;      // timing experiment: skip epilogue loads/stores
   float *inv_den;       // EPI_FWD_NORM: 1 / max(||x_row||, eps) per node (x_next then receives the unit-norm rows)
 };
 
@@ -265,7 +264,6 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
   for (int t = 0; t < MT; ++t) {
     const int nd = node_base + 16 * (MT * w + t) + r;
     if (nd >= g.n) continue;
-    if (g.debug_noepi && acc[t][0][0] != 12345.678f) continue;
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
       const int j = j0 + 16 * u + 4 * q;
@@ -321,8 +319,6 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
 }
 
 int g_gemm_variant = 2;
-int g_gemm_noepi = 0;
-int g_gemm_lds_pad = 0;
 
 template <int EPI>
 static int launch_gemm(const GemmArgs &g, int d, hipStream_t st) {
@@ -333,8 +329,7 @@ static int launch_gemm(const GemmArgs &g, int d, hipStream_t st) {
     // W-staging redundancy of small tiles costs more than that buys (measured, tools/gemm_bench.py)
     const int mt = g_gemm_variant == 3 ? 2 : g_gemm_variant == 4 ? 1 : (d >= 256 ? 2 : 1);
     dim3 grid(ceil_div(g.n, 64 * mt), g.J / (16 * nt));
-    size_t lds = 4 * (size_t)(64 * mt * 16 + 16 * nt * 16) * sizeof(float);
-    if (g_gemm_lds_pad > 0) lds = (size_t)g_gemm_lds_pad;  // experiment: cap co-resident workgroups per CU
+    const size_t lds = 4 * (size_t)(64 * mt * 16 + 16 * nt * 16) * sizeof(float);
 #define GSS_GEMM_CASE(NTV)                                                                              \
   case NTV:                                                                                             \
     if (mt == 2)                                                                                        \
@@ -392,7 +387,6 @@ int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const floa
   g.x_next = x_next;
   g.decay = decay;
   g.rows = nullptr;
-  g.debug_noepi = g_gemm_noepi;
   return launch_gemm<EPI_FWD>(g, d, as_stream(stream));
 }
 

@@ -376,9 +376,6 @@ static int launch_spmm_t(const gss_csr *a, int d4, const float *x, const SpmmEpi
 }
 
 int g_spmm_variant = 2;
-extern int g_gemm_variant;
-extern int g_gemm_noepi;
-extern int g_gemm_lds_pad;
 
 // Segment descriptors for the balanced kernel, built on first use for a given groups-per-wave count.
 static int build_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks) {
@@ -654,38 +651,6 @@ void gss_csr_destroy(gss_csr *a) {
   delete a;
 }
 
-int gss_debug_set_option(const char *name, int value) {
-  GSS_REQUIRE(name, "debug_set_option: null name");
-  if (strcmp(name, "spmm_variant") == 0) {
-    GSS_REQUIRE(value == 1 || value == 2, "spmm_variant must be 1 or 2");
-    g_spmm_variant = value;
-    return GSS_OK;
-  }
-  if (strcmp(name, "spmm_seg_edges") == 0) {
-    GSS_REQUIRE(value >= 4 && value <= 1024, "spmm_seg_edges must be in [4, 1024]");
-    g_seg_edges = value;
-    return GSS_OK;
-  }
-  if (strcmp(name, "spmm_slices") == 0) {
-    GSS_REQUIRE(value >= 0 && value <= 8, "spmm_slices must be in [0, 8] (0 = automatic)");
-    g_spmm_slices = value;
-    return GSS_OK;
-  }
-  if (strcmp(name, "gemm_lds_pad") == 0) {
-    g_gemm_lds_pad = value;
-    return GSS_OK;
-  }
-  if (strcmp(name, "gemm_noepi") == 0) {
-    g_gemm_noepi = value;
-    return GSS_OK;
-  }
-  if (strcmp(name, "gemm_variant") == 0) {
-    GSS_REQUIRE(value >= 1 && value <= 4, "gemm_variant must be 1..4");
-    g_gemm_variant = value;
-    return GSS_OK;
-  }
-  return fail(GSS_EINVAL, "unknown option %s", name);
-}
 
 int gss_spmm(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream) {
   return spmm_fwd(a, d, x, y, h, m, stream);

@@ -199,7 +199,8 @@ int gss_plan_profile(gss_plan *p, int enable);
 int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void *stream);
 /* tuning/debug knobs (A/B runs inside one process): "spmm_variant" = 1 (whole-row gather, wave per row) or
  * 2 (nnz-balanced segments, default); "spmm_slices" = 0 (automatic, default) or 1..8 time-separated feature
- * slices in the balanced SpMM; "gemm_variant" = 1 (operand fragments from L1/L2), 2 (LDS-DMA staged, node tile
+ * slices in the balanced SpMM; "spmm_seg_edges" = entries per SpMM segment (default 32; applies to gss_csr handles
+ * created afterwards); "gemm_variant" = 1 (operand fragments from L1/L2), 2 (LDS-DMA staged, node tile
  * chosen by width; default), 3 / 4 (LDS-DMA staged, 128- / 64-node tiles forced) */
 int gss_debug_set_option(const char *name, int value);
 /* plain device-to-device copy on `stream` (lets a ctypes host read plan-owned activations) */

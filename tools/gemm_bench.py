@@ -14,10 +14,8 @@ for d in [int(v) for v in (sys.argv[2:] or ["128", "256", "64"])]:
     p = torch.empty(n, d, device="cuda"); xn = torch.empty(n, d, device="cuda")
     res = {}
     for rnd in range(3):
-        for variant in (4, 14, 104, 114, 204):
-            lib.gss_debug_set_option(b"gemm_variant", variant % 10)
-            lib.gss_debug_set_option(b"gemm_noepi", 1 if (variant // 10) % 10 else 0)
-            lib.gss_debug_set_option(b"gemm_lds_pad", {0: 0, 1: 80 * 1024, 2: 160 * 1024}[variant // 100])
+        for variant in (1, 2, 3, 4):
+            lib.gss_debug_set_option(b"gemm_variant", variant)
             st = _lib.current_stream()
             def call():
                 lib.gss_dense_fwd(n, d, ax.data_ptr(), am.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
