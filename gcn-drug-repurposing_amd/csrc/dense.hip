@@ -15,6 +15,8 @@
 // output features of one node row -> float4 epilogue loads/stores.
 //
 // Roofline: MFMA fp32 (157 TFLOP/s).  flops fwd = 2 N (2d) d; bwd-input = 2 N d (2d); wgrad = 2 N d (2d).
+#include <algorithm>
+
 #include "ops.h"
 
 namespace gss {
@@ -597,10 +599,27 @@ __global__ __launch_bounds__(256) void wgrad_simple_kernel(WgradArgs g) {
   }
 }
 
+// Adam state for the fused reduce + optimizer step (gss_plan_step): parameter order w1, b1, w2, b2
+struct FusedAdam {
+  float *param[4], *m[4], *v[4];
+  float *w1t, *w2t;               // transposed copies of the updated square weights (nullable)
+  float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps;
+  int32_t *pos_clear;             // batch-position map to reset for the next step (nullable)
+  const int32_t *idx;
+  int b;
+  int enabled;
+};
+
+__device__ __forceinline__ float adam_update(float p, float g, float &m, float &v, const FusedAdam &a) {
+  m = m + (g - m) * (1.f - a.beta1);
+  v = v * a.beta2 + (1.f - a.beta2) * g * g;
+  return p - a.lr_over_bc1 * (m / (sqrtf(v) * a.inv_sqrt_bc2 + a.eps));
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int d, int nslices, const float *__restrict__ part_w,
                                                             const float *__restrict__ part_b, float *__restrict__ gw1,
                                                             float *__restrict__ gw2, float *__restrict__ gb, float *__restrict__ gb2,
-                                                            int accumulate) {
+                                                            int accumulate, FusedAdam ad) {
   // 64 consecutive outputs per workgroup; wave w sums slices w, w+4, ... (4 loads in flight), LDS adds the 4
   // wave sums in wave order -> fixed summation order
   __shared__ float red[4][64];
@@ -627,14 +646,40 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int d, int nslices, c
     const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     if (idx < nw) {
       const int f = idx / (2 * d), k = idx % (2 * d);
-      float *dst = k < d ? gw1 + (size_t)f * d + k : gw2 + (size_t)f * d + (k - d);
-      *dst = accumulate ? *dst + s : s;
+      const int which = k < d ? 0 : 2;
+      const size_t e = (size_t)f * d + (k < d ? k : k - d);
+      float *dst = (k < d ? gw1 : gw2) + e;
+      const float gval = accumulate ? *dst + s : s;
+      *dst = gval;
+      if (ad.enabled) {  // torch.optim.Adam on this element, in the same launch (train.py:184)
+        float m = ad.m[which][e], v = ad.v[which][e];
+        const float pn = adam_update(ad.param[which][e], gval, m, v, ad);
+        ad.m[which][e] = m;
+        ad.v[which][e] = v;
+        ad.param[which][e] = pn;
+        float *wt = which == 0 ? ad.w1t : ad.w2t;
+        if (wt) wt[(size_t)(k < d ? k : k - d) * d + f] = pn;
+      }
     } else {
       const int f = idx - nw;
-      const float v = accumulate ? gb[f] + s : s;
-      gb[f] = v;
-      if (gb2) gb2[f] = v;
+      const float gval = accumulate ? gb[f] + s : s;
+      gb[f] = gval;
+      if (gb2) gb2[f] = gval;
+      if (ad.enabled) {
+#pragma unroll
+        for (int which = 1; which <= 3; which += 2) {  // b1 and b2 share the gradient but have their own Adam state
+          float m = ad.m[which][f], v = ad.v[which][f];
+          ad.param[which][f] = adam_update(ad.param[which][f], gval, m, v, ad);
+          ad.m[which][f] = m;
+          ad.v[which][f] = v;
+        }
+      }
     }
+  }
+  // reset the batch-position map for the next step (it was last read by the backward SpMM before this kernel)
+  if (ad.enabled && ad.pos_clear) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < ad.b) ad.pos_clear[ad.idx[i]] = -1;
   }
 }
 
@@ -684,15 +729,51 @@ int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const 
 }
 
 // stage 2: fixed-order sum of slices [0, nslices) -> gw1, gw2, gb (and gb2)
-int wgrad_reduce(int32_t d, void *ws, int total_slices, int nslices, float *gw1, float *gw2, float *gb, float *gb2, int accumulate,
-                 void *stream) {
+static int wgrad_reduce_launch(int32_t d, void *ws, int total_slices, int nslices, float *gw1, float *gw2, float *gb, float *gb2,
+                               int accumulate, const FusedAdam &ad, void *stream) {
   GSS_REQUIRE(ws && gw1 && gw2 && gb && nslices >= 0 && nslices <= total_slices, "wgrad_reduce: bad argument");
   const float *pw = (const float *)ws;
   const float *pb = (const float *)ws + (size_t)total_slices * d * 2 * d;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div((int64_t)d * 2 * d + d, 64)), dim3(256), 0, as_stream(stream), d, nslices, pw,
-                     pb, gw1, gw2, gb, gb2, accumulate);
+  int nblk = ceil_div((int64_t)d * 2 * d + d, 64);
+  if (ad.enabled && ad.pos_clear) nblk = std::max(nblk, ceil_div(ad.b, 256));
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), d, nslices, pw, pb, gw1, gw2, gb, gb2,
+                     accumulate, ad);
   GSS_LAUNCH_CHECK("wgrad_reduce_kernel");
   return GSS_OK;
+}
+
+int wgrad_reduce(int32_t d, void *ws, int total_slices, int nslices, float *gw1, float *gw2, float *gb, float *gb2, int accumulate,
+                 void *stream) {
+  FusedAdam none{};
+  none.enabled = 0;
+  return wgrad_reduce_launch(d, ws, total_slices, nslices, gw1, gw2, gb, gb2, accumulate, none, stream);
+}
+
+// fixed-order reduce of the weight-gradient slabs AND the Adam step on all four tensors in one launch
+int wgrad_reduce_adam(int32_t d, void *ws, int total_slices, int nslices, float *const grad[4], float *const param[4],
+                      float *const m[4], float *const v[4], int32_t step, float lr, float beta1, float beta2, float eps, float *w1t,
+                      float *w2t, int32_t *pos_clear, const int32_t *idx, int32_t b, void *stream) {
+  GSS_REQUIRE(step >= 1, "adam: step is 1-based");
+  FusedAdam ad{};
+  for (int k = 0; k < 4; ++k) {
+    GSS_REQUIRE(grad[k] && param[k] && m[k] && v[k], "wgrad_reduce_adam: null tensor %d", k);
+    ad.param[k] = param[k];
+    ad.m[k] = m[k];
+    ad.v[k] = v[k];
+  }
+  ad.w1t = w1t;
+  ad.w2t = w2t;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  ad.lr_over_bc1 = (float)((double)lr / bc1);
+  ad.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  ad.beta1 = beta1;
+  ad.beta2 = beta2;
+  ad.eps = eps;
+  ad.pos_clear = pos_clear;
+  ad.idx = idx;
+  ad.b = b;
+  ad.enabled = 1;
+  return wgrad_reduce_launch(d, ws, total_slices, nslices, grad[0], grad[2], grad[1], grad[3], 0, ad, stream);
 }
 
 int wgrad_slices(int32_t n, int32_t d) {

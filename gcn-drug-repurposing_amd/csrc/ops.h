@@ -38,6 +38,9 @@ int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const 
 int wgrad_reduce(int32_t d, void *ws, int total_slices, int nslices, float *gw1, float *gw2, float *gb, float *gb2, int accumulate,
                  void *stream);
 int wgrad_slices(int32_t n, int32_t d);
+int wgrad_reduce_adam(int32_t d, void *ws, int total_slices, int nslices, float *const grad[4], float *const param[4],
+                      float *const m[4], float *const v[4], int32_t step, float lr, float beta1, float beta2, float eps, float *w1t,
+                      float *w2t, int32_t *pos_clear, const int32_t *idx, int32_t b, void *stream);
 int rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, void *stream);
 int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b, const float *e, const float *inv_den,
                     const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set, void *stream);
@@ -45,6 +48,8 @@ int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b
 int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,
                      const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream);
 bool spmm_sparse_available();
+int spmm_bwd2_sparse_res(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res_b,
+                         const int32_t *pos_row, float *dp, float *gx_out, void *stream);
 int adam_step(int64_t count, float *param, const float *grad, float *m, float *v, int32_t step, float lr, float beta1,
               float beta2, float eps, float *wt, int32_t dim, void *stream);
 struct AdamTensor {

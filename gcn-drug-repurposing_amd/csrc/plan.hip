@@ -310,9 +310,10 @@ static int plan_forward_impl(gss_plan *p, void *stream, bool pipelined = false) 
 }
 
 static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const float *de_rows, bool top_done, bool wt_ok,
-                              void *stream);
+                              void *stream, int *deferred_slices = nullptr);
 
-static int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta, bool wt_ok, void *stream) {
+static int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta, bool wt_ok, void *stream,
+                                   int *deferred_slices = nullptr) {
   GSS_REQUIRE(p && idx, "plan_loss_backward: null argument");
   const gss_plan_desc &D = p->desc;
   GSS_REQUIRE(b >= 1 && b <= D.max_batch, "plan_loss_backward: batch %d out of [1, %d]", b, D.max_batch);
@@ -325,11 +326,13 @@ static int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, f
                                     L > 1 ? D.layer_decay : 1.f, p->dx_b, p->dp_b, sparse_top ? p->pos : nullptr, p->loss_ws, stream))
       return rc;
   }
-  return plan_backward_impl(p, idx, b, nullptr, true, wt_ok, stream);
+  return plan_backward_impl(p, idx, b, nullptr, true, wt_ok, stream, deferred_slices);
 }
 
+// deferred_slices != NULL (gss_plan_step): the caller finishes with the fused reduce + Adam kernel, which also resets
+// the batch-position map; the residual of the top layer then rides in the backward SpMM's epilogue
 static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const float *de_rows, bool top_done, bool wt_ok,
-                              void *stream) {
+                              void *stream, int *deferred_slices) {
   GSS_REQUIRE(p && idx, "plan_backward: null argument");
   const gss_plan_desc &D = p->desc;
   GSS_REQUIRE(b >= 1 && b <= D.max_batch, "plan_backward: %d rows out of [1, %d]", b, D.max_batch);
@@ -386,11 +389,17 @@ static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const 
       const float c = lp == 0 ? 1.f : D.layer_decay;
       const float *res = (lp + 2 <= L - 1) ? p->gx[(lp + 2) & 1] : nullptr;
       float *gx_out = (lp >= 1 && L > 2) ? p->gx[(lp + 1) & 1] : nullptr;
+      const bool fold_res = deferred_slices && sparse_top && lp + 2 == L;
       {
         PROF(GSS_PROF_SPMM_BWD2);
-        if (int rc = spmm_bwd2(p->at, D.d, p->u, p->t, p->p[lp], c, res, p->dp, gx_out, stream)) return rc;
+        if (fold_res) {
+          // dP += dx_b on the batch rows inside the SpMM epilogue (no separate scatter-add launch)
+          if (int rc = spmm_bwd2_sparse_res(p->at, D.d, p->u, p->t, p->p[lp], c, p->dx_b, p->pos, p->dp, gx_out, stream)) return rc;
+        } else {
+          if (int rc = spmm_bwd2(p->at, D.d, p->u, p->t, p->p[lp], c, res, p->dp, gx_out, stream)) return rc;
+        }
       }
-      if (lp + 2 == L) {
+      if (lp + 2 == L && !fold_res) {
         PROF(GSS_PROF_ELEMENTWISE);
         if (int rc = scatter_add_rows(D.d, p->dx_b, idx, b, p->dp, sparse_top ? p->pos : nullptr, stream)) return rc;
       }
@@ -412,6 +421,10 @@ static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const 
   }
   // b1 and b2 enter the sum p = ... + b1 + ... + b2 symmetrically (model.py:165,170,172): the reduce kernel
   // writes the same column sums to both bias gradients
+  if (deferred_slices) {
+    *deferred_slices = wg_used;
+    return GSS_OK;
+  }
   PROF(GSS_PROF_WGRAD);
   return wgrad_reduce(D.d, p->wgrad_ws, p->wg_total, wg_used, p->grad[0], p->grad[2], p->grad[1], p->grad[3], 0, stream);
 }
@@ -454,8 +467,22 @@ int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *
   if (int rc = plan_forward_impl(p, stream, pipe)) return rc;
   if (pipe)  // the side stream starts when this stream reaches the loss kernel (MFMA-bound, 1 MB working set)
     if (int rc = plan_prefetch_layer1(p, stream)) return rc;
-  if (int rc = plan_loss_backward_impl(p, idx, b, beta, p->wt_valid, stream)) return rc;
-  if (int rc = plan_adam_impl(p, stream)) return rc;
+  int slices = 0;
+  if (int rc = plan_loss_backward_impl(p, idx, b, beta, p->wt_valid, stream, &slices)) return rc;
+  {
+    // weight-gradient reduce + Adam on the four tensors (+ transposed weights for the next backward, + reset of the
+    // batch-position map) in one launch
+    const gss_plan_desc &D = p->desc;
+    p->step += 1;
+    PROF(GSS_PROF_ADAM);
+    float *params[4] = {p->w1, p->b1, p->w2, p->b2};
+    const bool wt = D.num_layers > 1;
+    const bool sparse_top = wt && spmm_sparse_available();
+    if (int rc = wgrad_reduce_adam(D.d, p->wgrad_ws, p->wg_total, slices, p->grad, params, p->adam_m, p->adam_v, p->step, D.lr, D.beta1,
+                                   D.beta2, D.eps, wt ? p->w1t : nullptr, wt ? p->w2t : nullptr, sparse_top ? p->pos : nullptr, idx, b,
+                                   stream))
+      return rc;
+  }
   p->wt_valid = p->desc.num_layers > 1;
   return GSS_OK;
 }

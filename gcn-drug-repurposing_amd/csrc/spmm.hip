@@ -25,7 +25,7 @@ constexpr int kLongRow = 512;   // rows with more stored entries go to the long-
 constexpr int kRowsPerBlock = 16;
 constexpr int kLongThreads = 1024;
 
-enum SpmmMode { SPMM_PLAIN = 0, SPMM_FWD1 = 1, SPMM_BWD1 = 2, SPMM_BWD2 = 3, SPMM_BWD1S = 4 };
+enum SpmmMode { SPMM_PLAIN = 0, SPMM_FWD1 = 1, SPMM_BWD1 = 2, SPMM_BWD2 = 3, SPMM_BWD1S = 4, SPMM_BWD2S = 5 };
 
 struct SpmmEpi {
   const float *a0, *a1, *a2;
@@ -117,6 +117,13 @@ __device__ __forceinline__ void row_epilogue(const SpmmEpi &ep, size_t off, floa
     if (coff >= 0) u = add4(u, ld4(ep.a0 + coff));
     st4(ep.o0 + off, u);
     st4(ep.o1 + off, mul4(acc, ld4(ep.a2 + off)));
+  } else if (MODE == SPMM_BWD2S) {
+    // as SPMM_BWD2 with the residual gradient held compactly on the batch rows (coff < 0: not a batch row)
+    const float4 gx = add4(ld4(ep.a0 + off), acc);
+    float4 dp = scale4(ep.c, mul4(gx, elu_grad4(ld4(ep.a1 + off))));
+    if (coff >= 0) dp = add4(dp, ld4(ep.a2 + coff));
+    st4(ep.o0 + off, dp);
+    if (ep.o1) st4(ep.o1 + off, gx);
   } else {
     // gx = t + A u ; dp = c * gx (.) elu'(p) (+ res)
     const float4 gx = add4(ld4(ep.a0 + off), acc);
@@ -210,7 +217,7 @@ constexpr int kBalWaves = kBalThreads / 64;
 
 template <int MODE>
 __device__ __forceinline__ long compact_off(const SpmmEpi &ep, int row, int d4, int f4) {
-  if (MODE != SPMM_BWD1S) return -1;
+  if (MODE != SPMM_BWD1S && MODE != SPMM_BWD2S) return -1;
   const int pr = ep.pos_row[row];
   return pr >= 0 ? ((long)pr * d4 + f4) * 4 : -1;
 }
@@ -523,6 +530,14 @@ int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const fl
   GSS_REQUIRE(g_spmm_variant == 2, "spmm_bwd1_sparse needs the balanced SpMM (spmm_variant 2)");
   SpmmEpi ep{g_ax_b, x_in, ax, u, t, 0.f, pos, pos_row};
   return launch_spmm<SPMM_BWD1S>(at, d, g_am_b, ep, stream);
+}
+
+int spmm_bwd2_sparse_res(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res_b,
+                         const int32_t *pos_row, float *dp, float *gx_out, void *stream) {
+  GSS_REQUIRE(u && t && p && res_b && pos_row && dp, "spmm_bwd2_sparse_res: null operand");
+  GSS_REQUIRE(g_spmm_variant == 2, "spmm_bwd2_sparse_res needs the balanced SpMM (spmm_variant 2)");
+  SpmmEpi ep{t, p, res_b, dp, gx_out, c, nullptr, pos_row};
+  return launch_spmm<SPMM_BWD2S>(at, d, u, ep, stream);
 }
 
 bool spmm_sparse_available() { return g_spmm_variant == 2; }
