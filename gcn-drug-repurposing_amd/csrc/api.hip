@@ -5,6 +5,7 @@ namespace gss {
 thread_local char g_err[512] = "";
 extern int g_spmm_variant;  // spmm.hip
 extern int g_spmm_slices;
+extern int g_spmm_pin;
 extern int g_seg_edges;
 extern int g_gemm_variant;  // dense.hip
 }  // namespace gss
@@ -21,6 +22,11 @@ int gss_debug_set_option(const char *name, int value) {
   if (strcmp(name, "spmm_variant") == 0) {
     GSS_REQUIRE(value == 1 || value == 2, "spmm_variant must be 1 (row per wave) or 2 (nnz-balanced segments)");
     g_spmm_variant = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "spmm_pin") == 0) {
+    GSS_REQUIRE(value == 0 || value == 1, "spmm_pin must be 0 or 1");
+    g_spmm_pin = value;
     return GSS_OK;
   }
   if (strcmp(name, "spmm_slices") == 0) {

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(kLongThreads) void spmm_long_kernel(CsrView a, cons
 // so the row-per-wave mapping above ends on a few overloaded waves: rocprofv3 shows its waves alive for 46k
 // cycles on average in a 190k-cycle kernel.  Measured dead end, for the record: cutting the feature dimension
 // into 64-byte slices pinned to one XCD's L2 balances perfectly but triples the L2 request count (64-B
-// requests) and ran slower (111 us vs 90 us at d = 128) -- gathers must stay whole 128-B lines.
+// requests) and ran slower (111 us vs 90 us at d = 128) -- gathers must stay whole 128-B lines.  256-byte slices
+// pinned to XCDs are what pays (launch_balanced below).
 //
 // Here the host cuts every row into segments of <= kSegEdges entries (build_segments, once per feature width)
 // and packs them into a descriptor list, one descriptor per lane group (kSegEdges = 32 by default); a lane group is the LPR lanes that
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(kLongThreads) void spmm_long_kernel(CsrView a, cons
 // take the whole workgroup with longer segments.  Each group loads its segment's (col,val) pairs with one
 // coalesced access, broadcasts them with ds_bpermute and keeps 4 row gathers in flight.  Partial sums are
 // combined with xor-shuffles inside a wave and through LDS across the waves of a row's block, always in the
-// same order -> bitwise reproducible, no atomics, no second pass.
+// same order -> bitwise reproducible, no atomics, no second pass.  Workgroups run in the sorted order (hub rows
+// first, leaf rows last); interleaving heavy and light workgroups in dispatch order measured 10-25 % slower.
 constexpr int kSegEdgesDefault = 32;
 int g_seg_edges = kSegEdgesDefault;  // debug knob "spmm_seg_edges" (applies to CSR handles created afterwards)
 constexpr int kBalThreads = 1024;  // 512-thread workgroups measured 5-30 % slower (hub rows get half the groups)
@@ -224,27 +226,31 @@ __device__ __forceinline__ long compact_off(const SpmmEpi &ep, int row, int d4, 
 
 template <int MODE, int LPR_LOG2, int VPL>
 __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, const int4 *__restrict__ segs, int d4,
-                                                                   const float *__restrict__ x, SpmmEpi ep, int rowstride_f) {
+                                                                   const float *__restrict__ x, SpmmEpi ep, int rowstride_f, int pin_ns) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *part = reinterpret_cast<float4 *>(smem);  // [16 waves][d4]
+  // pin_ns > 0: 1-D grid, slice = blockIdx.x % pin_ns.  Workgroups go to the XCDs round-robin by linear id, so XCD k
+  // only ever gathers slice k % pin_ns and its L2 holds 1/pin_ns of the operand
+  const int sblk = pin_ns > 0 ? (int)blockIdx.x / pin_ns : (int)blockIdx.x;
+  const int sidx = pin_ns > 0 ? (int)blockIdx.x % pin_ns : (int)blockIdx.y;
   constexpr int LPR = 1 << LPR_LOG2;
   constexpr int GPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int g = lane >> LPR_LOG2;
   const int li = lane & (LPR - 1);
-  const int4 sd = segs[((size_t)blockIdx.x * kBalWaves + wib) * GPW + g];  // {row, first edge, edge count, flags | log2 p}
+  const int4 sd = segs[((size_t)sblk * kBalWaves + wib) * GPW + g];  // {row, first edge, edge count, flags | log2 p}
   const int row = sd.x;
   const int e0 = sd.y, e1 = sd.y + sd.z;
   const int plog = sd.w & 0xff;
   const bool multiwave = (sd.w & 0x100) != 0;  // workgroup-uniform: some row of this workgroup spans several waves
   const bool col_ok = (VPL > 1) || (li < d4);
-  // feature slicing (grid.y): this launch dimension walks d4-wide slices of rows that are rowstride_f floats long;
-  // y is the slow dispatch dimension, so slice s+1 starts when slice s drains and each L2 keeps twice (or four
-  // times) as many hot rows of the current slice
+  // feature slicing: this workgroup walks one d4-wide slice of rows that are rowstride_f floats long.  Either
+  // time-separated (grid.y, the slow dispatch dimension: slice s+1 starts when slice s drains) or pinned to XCDs
+  // (pin_ns, above); launch_balanced picks
   const size_t rowstride = (size_t)rowstride_f;
   const int rs4 = rowstride_f >> 2;
-  const int slice_f4 = blockIdx.y * d4;
+  const int slice_f4 = sidx * d4;
   x += (size_t)slice_f4 * 4;
   float4 acc[VPL];
 #pragma unroll
@@ -451,17 +457,18 @@ static int build_segments(const gss_csr *a, int gpw_log2, const int4 **out, int 
 }
 
 int g_spmm_slices = 0;  // 0 = automatic (see launch_balanced)
+int g_spmm_pin = 0;     // with a manual "spmm_slices": slices pinned to XCDs (1) or time-separated (0)
 
 template <int MODE, int LPR_LOG2, int VPL>
-static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, const float *x, const SpmmEpi &ep, hipStream_t st) {
+static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool pin, const float *x, const SpmmEpi &ep, hipStream_t st) {
   const int4 *segs = nullptr;
   int nblk = 0;
   if (int rc = build_segments(a, 6 - LPR_LOG2, &segs, &nblk)) return rc;
   if (nblk == 0) return GSS_OK;
   CsrView v{a->rowptr, a->col, a->val, a->n_rows};
   const size_t lds = (size_t)kBalWaves * d4_slice * sizeof(float4);
-  hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL>), dim3(nblk, nslices), dim3(kBalThreads), lds, st, v, segs, d4_slice, x,
-                     ep, d4_slice * nslices * 4);
+  hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL>), pin ? dim3(nblk * nslices) : dim3(nblk, nslices), dim3(kBalThreads), lds,
+                     st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0);
   GSS_LAUNCH_CHECK("spmm_balanced_kernel");
   return GSS_OK;
 }
@@ -469,24 +476,35 @@ static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, const 
 template <int MODE>
 static int launch_balanced(const gss_csr *a, int d4, const float *x, const SpmmEpi &ep, hipStream_t st) {
   int ns = g_spmm_slices;
+  bool pin = g_spmm_pin != 0;
   if (ns == 0) {
-    // automatic: cut the features into time-separated slices (>= 256 B wide) until one slice of the operand is
-    // <= 16 MB -- below that the gather rate is flat (measured: d = 256 at N = 29,960 gains 15-19 %, d = 128
-    // nothing); operands that stay far beyond the L2s even as 256-B slices (RMAT scale) are left whole
+    // automatic: cut the features into 256-B slices when the gathered operand is well beyond one XCD's 4 MB L2.
+    //  * small operands (<= 64 MB, the Infinity Cache holds them whole): slices pinned to XCDs -- slice = workgroup
+    //    id % ns and workgroups go to the XCDs round-robin, so every L2 caches 1/ns of the table.  Measured at
+    //    N = 29,960: d = 128 36.0 -> 31.9 us, d = 256 90 -> 63 us, d = 512 212 -> 122 us (time-separated slices:
+    //    37.6 / 68 / 129 us).
+    //  * larger operands (RMAT scale): time-separated slices -- grid.y is the slow dispatch dimension, so the caches
+    //    hold one slice of the table at a time.  N = 250k: d = 128 319 -> 260 us, d = 256 768 -> 568 us; N = 1M:
+    //    d = 128 1.74 -> 1.50 ms, d = 256 3.09 -> 2.76 ms; pinning is 2-7 % behind there.
+    const double table = 16.0 * d4 * (double)a->n_cols;
     ns = 1;
-    const double row_bytes = 16.0 * d4;
-    while (d4 % (2 * ns) == 0 && d4 / (2 * ns) >= 16 && (double)a->n_cols * row_bytes / ns > 16.0 * 1024 * 1024) ns *= 2;
-    if ((double)a->n_cols * row_bytes / ns > 16.0 * 1024 * 1024) ns = 1;
+    pin = false;
+    if (d4 >= 32 && d4 % 16 == 0 && table > 8.0 * 1024 * 1024) {
+      ns = d4 / 16 > 8 ? 8 : d4 / 16;
+      while (d4 % ns != 0) --ns;
+      pin = table <= 64.0 * 1024 * 1024;
+    }
   }
   if (ns < 1 || d4 % ns != 0 || (d4 / ns) < 4 || MODE == SPMM_BWD1S) ns = 1;  // the sparse mode gathers few rows anyway
+  pin = pin && ns > 1;
   const int ds = d4 / ns;
-  if (ds <= 4) return launch_balanced_t<MODE, 2, 1>(a, ds, ns, x, ep, st);
-  if (ds <= 8) return launch_balanced_t<MODE, 3, 1>(a, ds, ns, x, ep, st);
-  if (ds <= 16) return launch_balanced_t<MODE, 4, 1>(a, ds, ns, x, ep, st);
-  if (ds <= 32) return launch_balanced_t<MODE, 5, 1>(a, ds, ns, x, ep, st);
-  if (ds <= 64) return launch_balanced_t<MODE, 6, 1>(a, ds, ns, x, ep, st);
-  if (ds <= 128) return launch_balanced_t<MODE, 6, 2>(a, ds, ns, x, ep, st);
-  return launch_balanced_t<MODE, 6, 4>(a, ds, ns, x, ep, st);
+  if (ds <= 4) return launch_balanced_t<MODE, 2, 1>(a, ds, ns, pin, x, ep, st);
+  if (ds <= 8) return launch_balanced_t<MODE, 3, 1>(a, ds, ns, pin, x, ep, st);
+  if (ds <= 16) return launch_balanced_t<MODE, 4, 1>(a, ds, ns, pin, x, ep, st);
+  if (ds <= 32) return launch_balanced_t<MODE, 5, 1>(a, ds, ns, pin, x, ep, st);
+  if (ds <= 64) return launch_balanced_t<MODE, 6, 1>(a, ds, ns, pin, x, ep, st);
+  if (ds <= 128) return launch_balanced_t<MODE, 6, 2>(a, ds, ns, pin, x, ep, st);
+  return launch_balanced_t<MODE, 6, 4>(a, ds, ns, pin, x, ep, st);
 }
 
 template <int MODE>

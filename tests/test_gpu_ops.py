@@ -88,14 +88,18 @@ def test_spmm_row_sums_within_1e5(G, op_case):
 
 
 # ---------------------------------------------------------------- K1 / K2 / K9
-@pytest.fixture(params=[1, 2, 22, 42])
+@pytest.fixture(params=[1, 2, 22, 42, 122, 142])
 def spmm_variant(request, G):
-    """1 = row-per-wave, 2 = nnz-balanced (auto slicing), 22 / 42 = nnz-balanced with 2 / 4 forced feature slices"""
-    G._lib.check(G.lib.gss_debug_set_option(b"spmm_variant", min(request.param, 2) if request.param < 10 else 2))
-    G._lib.check(G.lib.gss_debug_set_option(b"spmm_slices", request.param // 10))
-    yield request.param
+    """1 = row-per-wave, 2 = nnz-balanced (automatic slicing), 22 / 42 = nnz-balanced with 2 / 4 forced time-separated
+    feature slices, 122 / 142 = the same slices pinned to XCDs"""
+    v = request.param
+    G._lib.check(G.lib.gss_debug_set_option(b"spmm_variant", min(v, 2) if v < 10 else 2))
+    G._lib.check(G.lib.gss_debug_set_option(b"spmm_slices", (v % 100) // 10))
+    G._lib.check(G.lib.gss_debug_set_option(b"spmm_pin", 1 if v >= 100 else 0))
+    yield v
     G._lib.check(G.lib.gss_debug_set_option(b"spmm_variant", 2))
     G._lib.check(G.lib.gss_debug_set_option(b"spmm_slices", 0))
+    G._lib.check(G.lib.gss_debug_set_option(b"spmm_pin", 0))
 
 
 @pytest.mark.parametrize("d", [16, 48, 64, 128, 256, 512, 1024])

@@ -77,7 +77,15 @@ rng = np.random.RandomState(0)
 streams = {"graph col[] (CSR order)": a.indices.astype(np.int32),
            "uniform random": rng.randint(0, n, nnz).astype(np.int32),
            "graph col[] shuffled": rng.permutation(a.indices).astype(np.int32),
-           "sequential": (np.arange(nnz) % n).astype(np.int32)}
+           "sequential": (np.arange(nnz) % n).astype(np.int32),
+           # perfect time alignment: concurrently running waves read the same narrow column band
+           "graph col[] sorted by column": np.sort(a.indices).astype(np.int32),
+           "graph col[] sorted within 16 bands of rows": None}
+# rows cut into 16 bands (what one co-resident set of workgroups would own); inside a band the stream is in column order
+rb = np.repeat(np.arange(n), np.diff(a.indptr)) * 16 // n
+streams["graph col[] sorted within 16 bands of rows"] = a.indices[np.lexsort((a.indices, rb))].astype(np.int32)
+if True:
+    pass
 for name, cols in streams.items():
     cd = torch.from_numpy(cols).cuda()
     for blocks in (2048,):
