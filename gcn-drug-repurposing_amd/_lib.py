@@ -24,6 +24,15 @@ class PlanDesc(C.Structure):
                 ("beta2", C.c_float), ("eps", C.c_float), ("cache_layer1", C.c_int32), ("pipeline_layer1", C.c_int32)]
 
 
+class PprDesc(C.Structure):
+    _fields_ = ([("n", C.c_int32), ("k", C.c_int32), ("kpad", C.c_int32), ("nnz", C.c_int64)]
+                + [(k, C.c_void_p) for k in ("h_rowptr", "t_rowptr", "t_col", "t_val", "start", "start_dangling")]
+                + [("n_z", C.c_int32), ("z_rows", C.c_void_p), ("n_ovr", C.c_int64)]
+                + [(k, C.c_void_p) for k in ("ovr_col", "ovr_row", "ovr_ratio", "zero_ptr", "zero_ovr")]
+                + [("n_sel", C.c_int64)]
+                + [(k, C.c_void_p) for k in ("sel_col", "sel_row", "sel_val", "keep_ptr", "keep_row", "keep_val")])
+
+
 class PlanIO(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("x", "w1", "b1", "w2", "b2", "emb", "loss", "gw1", "gb1", "gw2", "gb2")]
 
@@ -68,6 +77,11 @@ SIGNATURES = {
     "gss_plan_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), _P]),
     "gss_debug_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "gss_memcpy_d2d": (C.c_int, [_P, _P, _SZ, _P]),
+    "gss_ppr_create": (C.c_int, [C.POINTER(_P), C.POINTER(PprDesc)]),
+    "gss_ppr_destroy": (None, [_P]),
+    "gss_ppr_device_bytes": (_SZ, [_P]),
+    "gss_ppr_run": (C.c_int, [_P, _D, _D, _I32, _P, _P, _P]),
+    "gss_ppr_spmm": (C.c_int, [_P, _P, _P, _P]),
 }
 
 

@@ -18,6 +18,8 @@ struct gss_csr {
 };
 
 namespace gss {
+// nnz-balanced segment descriptors of a CSR for 2^gpw_log2 lane groups per wave (spmm.hip; cached in the handle)
+int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks);
 int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream);
 int spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
               float *u, float *t, void *stream);

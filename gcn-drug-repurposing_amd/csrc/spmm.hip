@@ -391,7 +391,7 @@ static int launch_spmm_t(const gss_csr *a, int d4, const float *x, const SpmmEpi
 int g_spmm_variant = 2;
 
 // Segment descriptors for the balanced kernel, built on first use for a given groups-per-wave count.
-static int build_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks) {
+int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks) {
   gss_csr *m = const_cast<gss_csr *>(a);  // lazily filled cache; a gss_csr is used from one host thread
   if (m->d_segs[gpw_log2]) {
     *out = (const int4 *)m->d_segs[gpw_log2];
@@ -463,7 +463,7 @@ template <int MODE, int LPR_LOG2, int VPL>
 static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool pin, const float *x, const SpmmEpi &ep, hipStream_t st) {
   const int4 *segs = nullptr;
   int nblk = 0;
-  if (int rc = build_segments(a, 6 - LPR_LOG2, &segs, &nblk)) return rc;
+  if (int rc = csr_segments(a, 6 - LPR_LOG2, &segs, &nblk)) return rc;
   if (nblk == 0) return GSS_OK;
   CsrView v{a->rowptr, a->col, a->val, a->n_rows};
   const size_t lds = (size_t)kBalWaves * d4_slice * sizeof(float4);

@@ -1,0 +1,216 @@
+"""Diffusion profiles (the reference's 'diffusion' comparator) on the device SpMM -- SURVEY.md section 8-f4.
+
+Mirror of multiscale/diff_prof/diffusion_profiles.py: class DiffusionProfiles with the reference's constructor, file
+naming (:92-98: '<clean name>_p_visit_array.npy', np.save of the fp64 vector) and loader (:158-171), so
+evaluate_auc.py:97-111,156-161 / predict_drug.py:98-113 read the result unchanged.  The reference runs one scipy power
+iteration per drug / indication in a process pool (:125-156); here all start nodes are columns of one fp64 matrix and an
+iteration is one batched SpMM through libgssgcn.so (gss_ppr_*, csrc/ppr.hip).  No CPU fallback.
+
+Host side (this file): what the reference also does on the host with scipy -- the weighted adjacency, its row sums
+(:49-56) and, per start node, which rows of x need special treatment (:30-47) -- as index lists, not as a matrix copy
+per start node."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pickle
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+
+
+def _row_sum_without(data: np.ndarray, skip: int) -> float:
+    """row sum in storage order with one entry replaced by 0.0 (what scipy's M.sum(axis=1) gives after M[p, s] = 0)"""
+    s = 0.0
+    for i, v in enumerate(data):
+        s += 0.0 if i == skip else float(v)
+    return s
+
+
+class PprProblem:
+    """index lists for gss_ppr_create from (raw weighted adjacency, start nodes, {drug/indication: its proteins})"""
+
+    def __init__(self, m0: sp.csr_matrix, starts, proteins_of: dict):
+        m0 = sp.csr_matrix(m0, dtype=np.float64)
+        m0.sort_indices()
+        n = m0.shape[0]
+        starts = np.asarray(starts, dtype=np.int64)
+        indptr, indices, data = m0.indptr, m0.indices, m0.data
+        rowsum = np.asarray(m0.sum(axis=1)).flatten()                 # diffusion_profiles.py:51 for an untouched row
+        # the shared matrix: every drug / indication row in its "not selected" form -- edges to its proteins cut (:38-46)
+        cut = m0.copy()
+        for t, prots in proteins_of.items():
+            lo, hi = indptr[t], indptr[t + 1]
+            hit = np.isin(indices[lo:hi], np.fromiter((int(p) for p in prots), dtype=np.int64, count=len(prots)))
+            cut.data[lo:hi][hit] = 0.0
+        cut_sum = np.asarray(cut.sum(axis=1)).flatten()               # :51 (the cut entries stay stored as 0.0, as in the reference)
+        s_cut = cut_sum.copy()
+        s_cut[s_cut != 0] = 1.0 / s_cut[s_cut != 0]                   # :52
+        mprime = (sp.diags(s_cut, 0, format="csr") @ cut).tocsr()      # :53-54
+        mprime.eliminate_zeros()
+        mt = mprime.T.tocsr()
+        mt.sort_indices()
+        ovr_col, ovr_row, ovr_ratio, zero_ptr, zero_ovr = [], [], [], [0], []
+        sel_col, sel_row, sel_val = [], [], []
+        keep_ptr, keep_row, keep_val = [0], [], []
+        mpc = mprime.tocsc()
+        start_dangling = np.zeros(len(starts), dtype=np.int32)
+        for c, s in enumerate(starts):
+            s = int(s)
+            prots = set(int(p) for p in proteins_of[s])
+            for p in sorted(prots):                                   # :33-36: M[p, s] = 0, then row p renormalised
+                lo, hi = indptr[p], indptr[p + 1]
+                j = lo + np.searchsorted(indices[lo:hi], s)
+                if j >= hi or indices[j] != s or s_cut[p] == 0:
+                    continue
+                new = _row_sum_without(cut.data[lo:hi], j - lo)
+                ratio = 0.0 if new == 0 else (1.0 / new) / s_cut[p]
+                if ratio == 0.0:
+                    zero_ovr.append(len(ovr_col))
+                ovr_col.append(c); ovr_row.append(p); ovr_ratio.append(ratio)
+            zero_ptr.append(len(zero_ovr))
+            # the start node's own row is whole in M_s: its "not selected" form must not act in this column ...
+            if s_cut[s] != 0:
+                ovr_col.append(c); ovr_row.append(s); ovr_ratio.append(0.0)
+            # ... and its "selected" form (all out-edges over their sum) does
+            if rowsum[s] != 0:
+                inv = 1.0 / rowsum[s]
+                for j, w in zip(indices[indptr[s]:indptr[s + 1]], data[indptr[s]:indptr[s + 1]]):
+                    if w != 0 and int(j) != s:
+                        sel_col.append(c); sel_row.append(int(j)); sel_val.append(float(inv * w))
+            else:
+                start_dangling[c] = 1
+            lo, hi = mpc.indptr[s], mpc.indptr[s + 1]                 # in-edges of s that are not cut
+            for i, w in zip(mpc.indices[lo:hi], mpc.data[lo:hi]):
+                if int(i) not in prots and int(i) != s:
+                    keep_row.append(int(i)); keep_val.append(float(w))
+            if rowsum[s] != 0 and m0[s, s] != 0:                      # a self loop of the start node
+                keep_row.append(s); keep_val.append(float(m0[s, s] / rowsum[s]))
+            keep_ptr.append(len(keep_row))
+        self.n, self.k = n, len(starts)
+        self.kpad = max(64, -(-self.k // 64) * 64)
+        self.mt = mt
+        self.starts = starts.astype(np.int32)
+        self.start_dangling = start_dangling
+        self.z_rows = np.flatnonzero(s_cut == 0).astype(np.int32)     # :77 is_dangling, for rows no start node changes
+        self.ovr_col = np.asarray(ovr_col, np.int32); self.ovr_row = np.asarray(ovr_row, np.int32)
+        self.ovr_ratio = np.asarray(ovr_ratio, np.float64)
+        self.zero_ptr = np.asarray(zero_ptr, np.int32); self.zero_ovr = np.asarray(zero_ovr, np.int32)
+        self.sel_col = np.asarray(sel_col, np.int32); self.sel_row = np.asarray(sel_row, np.int32)
+        self.sel_val = np.asarray(sel_val, np.float64)
+        self.keep_ptr = np.asarray(keep_ptr, np.int32); self.keep_row = np.asarray(keep_row, np.int32)
+        self.keep_val = np.asarray(keep_val, np.float64)
+
+
+class PprEngine:
+    """device handle (gss_ppr) for one PprProblem"""
+
+    def __init__(self, prob: PprProblem, device="cuda"):
+        import torch
+        self.lib = _lib.load()
+        self.prob = prob
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise _lib.GssError("diffusion profiles run on the GPU only (no CPU fallback)")
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        mt = prob.mt
+        self.h_rowptr = np.ascontiguousarray(mt.indptr.astype(np.int32))
+        self.bufs = dict(t_rowptr=t(self.h_rowptr), t_col=t(mt.indices.astype(np.int32)), t_val=t(mt.data.astype(np.float64)),
+                         start=t(prob.starts), start_dangling=t(prob.start_dangling), z_rows=t(prob.z_rows),
+                         ovr_col=t(prob.ovr_col), ovr_row=t(prob.ovr_row), ovr_ratio=t(prob.ovr_ratio), zero_ptr=t(prob.zero_ptr),
+                         zero_ovr=t(prob.zero_ovr), sel_col=t(prob.sel_col), sel_row=t(prob.sel_row), sel_val=t(prob.sel_val),
+                         keep_ptr=t(prob.keep_ptr), keep_row=t(prob.keep_row), keep_val=t(prob.keep_val))
+        d = _lib.PprDesc()
+        d.n, d.k, d.kpad, d.nnz = prob.n, prob.k, prob.kpad, int(mt.nnz)
+        d.h_rowptr = self.h_rowptr.ctypes.data
+        d.n_z, d.n_ovr, d.n_sel = len(prob.z_rows), len(prob.ovr_col), len(prob.sel_col)
+        for name, buf in self.bufs.items():
+            setattr(d, name, buf.data_ptr() if buf.numel() else None)
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.gss_ppr_create(C.byref(self.handle), C.byref(d)), "gss_ppr_create")
+        self.x = torch.empty(prob.n, prob.kpad, dtype=torch.float64, device=dev)
+
+    def run(self, alpha: float, tol: float, max_iter: int):
+        """-> (x device tensor [n][kpad] (column c = start node c), iterations [k])"""
+        iters = np.zeros(self.prob.k, dtype=np.int32)
+        rc = self.lib.gss_ppr_run(self.handle, float(alpha), float(tol), int(max_iter), self.x.data_ptr(), iters.ctypes.data,
+                                  _lib.current_stream())
+        if rc == -34:  # GSS_ENOTCONV; the reference raises here (diffusion_profiles.py:90)
+            raise RuntimeError("power iteration failed to converge in %d iterations" % max_iter)
+        _lib.check(rc, "gss_ppr_run")
+        return self.x, iters
+
+    def spmm(self, x, y):
+        _lib.check(self.lib.gss_ppr_spmm(self.handle, x.data_ptr(), y.data_ptr(), _lib.current_stream()), "gss_ppr_spmm")
+
+    def device_bytes(self) -> int:
+        return int(self.lib.gss_ppr_device_bytes(self.handle))
+
+    def __del__(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.gss_ppr_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+def diffusion_profiles(m0, starts, proteins_of, alpha, max_iter, tol, device="cuda", max_columns=4096):
+    """p_visit vectors of the given start nodes -> (profiles [K][N] fp64, iterations [K]).
+    m0[u, v] = weight of edge u -> v (nx.to_scipy_sparse_matrix of the weighted MSI, diffusion_profiles.py:22-28)."""
+    starts = np.asarray(starts, dtype=np.int64)
+    out = np.empty((len(starts), m0.shape[0]), dtype=np.float64)
+    its = np.empty(len(starts), dtype=np.int32)
+    for lo in range(0, len(starts), max_columns):
+        sub = starts[lo:lo + max_columns]
+        eng = PprEngine(PprProblem(m0, sub, proteins_of), device)
+        x, it = eng.run(alpha, tol, max_iter)
+        out[lo:lo + len(sub)] = x[:, :len(sub)].t().contiguous().cpu().numpy()
+        its[lo:lo + len(sub)] = it
+        del eng
+    return out, its
+
+
+class DiffusionProfiles:
+    """diffusion_profiles.py:12-171.  `msi` is a gcn_drug_repurposing_amd.msi.MsiGraph (loaded, not yet weighted)."""
+
+    def __init__(self, alpha, max_iter, tol, weights, num_cores, save_load_file_path):
+        self.alpha = alpha
+        self.max_iter = max_iter
+        self.tol = tol
+        self.weights = weights
+        self.num_cores = num_cores     # kept for signature compatibility; the batch runs on one GPU
+        self.save_load_file_path = save_load_file_path
+
+    def clean_file_name(self, file_name):   # :92-93
+        return "".join([c for c in file_name if c.isalpha() or c.isdigit() or c == ' ' or c == "_"]).rstrip()
+
+    def save_diffusion_profile(self, diffusion_profile, selected_drug_or_indication):   # :95-97
+        f = os.path.join(self.save_load_file_path, self.clean_file_name(selected_drug_or_indication) + "_p_visit_array.npy")
+        np.save(f, diffusion_profile)
+
+    def calculate_diffusion_profiles(self, msi, device="cuda"):   # :125-156
+        os.makedirs(self.save_load_file_path, exist_ok=True)
+        names = msi.names
+        node2idx = {n: i for i, n in enumerate(names)}
+        with open(os.path.join(self.save_load_file_path, "node2idx.pkl"), "wb") as f:   # msi.save_node2idx (msi.py:180-184)
+            pickle.dump(node2idx, f)
+        msi.weight_graph(self.weights)
+        m0, _, _ = msi.to_csr()
+        start_names = msi.drugs_in_graph + msi.indications_in_graph
+        proteins_of = {node2idx[s]: [node2idx[p] for p in msi.drug_or_indication2proteins[s]] for s in start_names}
+        prof, iters = diffusion_profiles(m0, [node2idx[s] for s in start_names], proteins_of, self.alpha, self.max_iter, self.tol, device)
+        for s, v in zip(start_names, prof):
+            self.save_diffusion_profile(v, s)
+        self.iterations = dict(zip(start_names, iters.tolist()))
+        return prof
+
+    def load_diffusion_profiles(self, drugs_and_indications):   # :158-171
+        assert self.save_load_file_path is not None
+        out = {}
+        for s in drugs_and_indications:
+            path = os.path.join(self.save_load_file_path, self.clean_file_name(s) + "_p_visit_array.npy")
+            if os.path.exists(path):
+                out[s] = np.load(path)
+            else:
+                print("Loading failed at " + str(s) + " | " + str(path))
+        self.drug_or_indication2diffusion_profile = out

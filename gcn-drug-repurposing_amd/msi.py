@@ -44,6 +44,7 @@ class MsiGraph:
         self.type = {}
         self.up = {}         # pathway -> set of parents (node_1 -> node_2 rows of the GO table)
         self.down = {}
+        self.drug_or_indication2proteins = {}   # MSI.load_drug_or_indication2proteins (msi.py:192-205)
 
     # -- MSI.load_graph ------------------------------------------------------------------------------------
     def _add_edge(self, u, v):
@@ -66,6 +67,8 @@ class MsiGraph:
                 self._add_edge(u, v)
                 self.type[u] = t_from
                 self.type[v] = t_to
+                if name in ("drug_to_protein", "indication_to_protein"):
+                    self.drug_or_indication2proteins.setdefault(u, set()).add(v)
                 if name == "functional_pathway_to_functional_pathway":
                     self.up.setdefault(u, set()).add(v)
                     self.down.setdefault(v, set()).add(u)
@@ -109,6 +112,14 @@ class MsiGraph:
     @property
     def names(self):
         return list(self.adj)
+
+    @property
+    def drugs_in_graph(self):        # msi.py:186-187 (order there is a set's; here graph order)
+        return [n for n in self.adj if self.type[n] == DRUG]
+
+    @property
+    def indications_in_graph(self):  # msi.py:189-190
+        return [n for n in self.adj if self.type[n] == INDICATION and n in self.drug_or_indication2proteins]
 
     def write_weighted_edgelist(self, path):
         """nx.write_weighted_edgelist text: 'u v w' per directed edge, in node / adjacency order"""

@@ -30,6 +30,7 @@ extern "C" {
 #define GSS_EINVAL (-22)   /* bad argument (shape, null pointer, unsupported d) */
 #define GSS_ENOMEM (-12)   /* hipMalloc failed */
 #define GSS_EHIP (-5)      /* a HIP call or kernel launch failed */
+#define GSS_ENOTCONV (-34)  /* gss_ppr_run: max_iter reached */
 
 typedef struct gss_csr gss_csr;   /* a CSR operand plus its launch schedule (row bins) */
 typedef struct gss_plan gss_plan; /* activations + workspace of one training replica/shard */
@@ -130,6 +131,57 @@ int gss_percentile(int32_t n, int32_t d, const float *e, double q, float *h_out,
  * x_i . x_j over all j (self included, as np.argpartition(x_sim, -k, 1)[:, -k:] returns them; order within the
  * k is unspecified) -> top_val [n][k] fp64, top_idx [n][k] int32.  fp64 MFMA; d multiple of 8, k <= 64. */
 int gss_knn_topk(int32_t n, int32_t d, const double *x, int32_t k, double *top_val, int32_t *top_idx, void *stream);
+
+/* ---- f4  diffusion profiles, multiscale/diff_prof/diffusion_profiles.py:30-90 ---------------------------
+ * Personalised PageRank from every drug / indication, all start nodes at once: column c of the fp64 matrix
+ * x[n][kpad] is the visit-probability vector of start node start[c].  The reference builds one matrix M_s per start
+ * node s (edges from every other drug / indication to its proteins cut, edges from s's proteins into s cut, rows
+ * renormalised; :30-56) and runs  x <- alpha (x M_s + dangling(x) e_s) + (1 - alpha) e_s  until
+ * ||x - x_last||_1 < n tol (:65-90).  Here ONE shared matrix M' -- every drug / indication row in its "not selected"
+ * form, i.e. cut and renormalised (normally empty: a pure sink) -- is multiplied into all columns by one fp64 SpMM per
+ * iteration; what differs per start node is applied around the product:
+ *   - ovr_*: entry (ovr_row[e], column ovr_col[e]) of x is multiplied by ovr_ratio[e] for the product.  Proteins of
+ *     the start node: their row of M_s is renormalised without the cut edge (ratio 0 = the row became empty; listed in
+ *     zero_* and counted as dangling).  The start node's own entry gets ratio 0 (not dangling) when its "not
+ *     selected" row is not empty, so that row does not act in its own column;
+ *   - sel_*: the start node's row in its "selected" form (all its out-edges over their sum):
+ *     y[sel_row[e]][sel_col[e]] += sel_val[e] * x[start][sel_col[e]];
+ *   - keep_*: in-edges of a start node that survive the cut (none in the plain MSI, where drugs and indications only
+ *     touch proteins): value M'[keep_row][start[c]]; the product's own value at (start[c], c) is replaced by their sum;
+ *   - z_rows: the empty rows of M' (sinks, isolated nodes): dangling in every column except, for the start node's
+ *     own row, its column (start_dangling[c] = 1 if even its "selected" row is empty).
+ * Columns converge independently and are frozen at the iteration the reference would have returned them.
+ * All pointers are device pointers except h_rowptr.  kpad (the row stride of x) must be a multiple of 64. */
+typedef struct gss_ppr gss_ppr;
+typedef struct gss_ppr_desc {
+  int32_t n, k, kpad;
+  int64_t nnz;
+  const int32_t *h_rowptr;                 /* host copy of t_rowptr */
+  const int32_t *t_rowptr, *t_col;         /* CSR of M'^T: row j lists in-neighbours i ascending */
+  const double *t_val;                     /* M'[i][j] */
+  const int32_t *start;                    /* [k] */
+  const int32_t *start_dangling;           /* [k] */
+  int32_t n_z;
+  const int32_t *z_rows;                   /* [n_z] ascending */
+  int64_t n_ovr;
+  const int32_t *ovr_col, *ovr_row;        /* [n_ovr] */
+  const double *ovr_ratio;                 /* [n_ovr] */
+  const int32_t *zero_ptr, *zero_ovr;      /* [k+1], indices e of dangling overrides, grouped by column */
+  int64_t n_sel;
+  const int32_t *sel_col, *sel_row;        /* [n_sel], (row, column) pairs unique */
+  const double *sel_val;
+  const int32_t *keep_ptr, *keep_row;      /* [k+1], rows */
+  const double *keep_val;
+} gss_ppr_desc;
+int gss_ppr_create(gss_ppr **out, const gss_ppr_desc *desc);
+void gss_ppr_destroy(gss_ppr *p);
+size_t gss_ppr_device_bytes(const gss_ppr *p);
+/* x <- 1/n, then iterate.  iters_out: host [k], the iteration at which each column converged.  Returns
+ * GSS_ENOTCONV (x holds the last iterate) if some column needs more than max_iter iterations -- where the reference
+ * raises (:90).  Synchronises the stream once per iteration (reads the number of unconverged columns). */
+int gss_ppr_run(gss_ppr *p, double alpha, double tol, int32_t max_iter, double *x, int32_t *iters_out, void *stream);
+/* one product y = M'^T x on the handle's schedule (fp64; the kernel the iteration is built on) */
+int gss_ppr_spmm(gss_ppr *p, const double *x, double *y, void *stream);
 
 /* ---- whole training step (train.py:158-184) ---------------------------------------------------
  * A plan owns every activation/gradient buffer of one replica so that a step is ONE host call that

@@ -109,3 +109,43 @@ class NumpyOps:
             m[k].lerp_(grads[k], 1 - b1)
             v[k].mul_(b2).addcmul_(grads[k], grads[k], value=1 - b2)
             params[k].addcdiv_(m[k], (v[k].sqrt() / bc2 ** 0.5).add_(eps), value=-lr / bc1)
+
+
+def emulate_ppr(prob, alpha, tol, max_iter):
+    """numpy statement of what gss_ppr_run does on the device (csrc/ppr.hip), step for step, from a PprProblem:
+    used on CPU to check the problem's index lists against the oracle.  -> (x [n][k], iterations [k])"""
+    n, k = prob.n, prob.k
+    x = np.full((n, k), 1.0 / n)
+    done = np.zeros(k, dtype=bool)
+    iters = np.zeros(k, dtype=np.int32)
+    cols = np.arange(k)
+    for it in range(1, max_iter + 1):
+        held = x[prob.z_rows].copy()                                   # ppr_dangling_kernel
+        held[prob.z_rows[:, None] == prob.starts[None, :]] = 0.0
+        dsum = held.sum(0)
+        xs = x.copy()                                                  # ppr_ovr_scale_kernel
+        orig = xs[prob.ovr_row, prob.ovr_col].copy()
+        xs[prob.ovr_row, prob.ovr_col] = orig * prob.ovr_ratio
+        yself = np.zeros(k)
+        for c in range(k):                                             # ppr_column_kernel
+            for e in prob.zero_ovr[prob.zero_ptr[c]:prob.zero_ptr[c + 1]]:
+                dsum[c] += orig[e]
+            if prob.start_dangling[c]:
+                dsum[c] += xs[prob.starts[c], c]
+            lo, hi = prob.keep_ptr[c], prob.keep_ptr[c + 1]
+            yself[c] = (prob.keep_val[lo:hi] * xs[prob.keep_row[lo:hi], c]).sum()
+        y = prob.mt @ xs                                               # ppr_spmm_kernel
+        np.add.at(y, (prob.sel_row, prob.sel_col), prob.sel_val * x[prob.starts[prob.sel_col], prob.sel_col])   # ppr_sel_kernel
+        y[prob.starts, cols] = yself
+        p = np.zeros((n, k))
+        p[prob.starts, cols] = 1.0
+        xn = alpha * (y + dsum[None, :] * p) + (1.0 - alpha) * p       # ppr_update_kernel
+        err = np.abs(xn - x).sum(0)
+        upd = ~done
+        x[:, upd] = xn[:, upd]
+        newly = upd & (err < n * tol)                                  # ppr_finish_kernel
+        iters[newly] = it
+        done |= newly
+        if done.all():
+            return x, iters
+    raise RuntimeError("not converged")
