@@ -93,3 +93,26 @@ def indication_aucs(emb, names, drugs, indications, positives):
         aucs.append(roc_auc(ref, ed @ e[idx[ind]]))
         used.append(ind)
     return np.asarray(aucs), used
+
+
+def diffusion_indication_aucs(profiles, names, drugs, indications, positives):
+    """evaluate_auc.py:156-161 as written for method == 'diffusion': the score of drug d for an indication is the
+    indication's visit probability AT the drug node (profile[indication][idx[d]]), one ROC-AUC per indication.
+    profiles: {node: p_visit [N]} (DiffusionProfiles.drug_or_indication2diffusion_profile)."""
+    idx = {n: i for i, n in enumerate(names)}
+    drugs = [d for d in drugs if d in idx]
+    dpos = {d: k for k, d in enumerate(drugs)}
+    didx = [idx[d] for d in drugs]
+    aucs, used = [], []
+    for ind in indications:
+        if ind not in profiles:
+            continue
+        ref = np.zeros(len(drugs), dtype=int)
+        for d in positives.get(ind, ()):
+            if d in dpos:
+                ref[dpos[d]] = 1
+        if ref.sum() == 0 or ref.sum() == len(ref):
+            continue
+        aucs.append(roc_auc(ref, np.asarray(profiles[ind])[didx]))
+        used.append(ind)
+    return np.asarray(aucs), used

@@ -120,6 +120,21 @@ __global__ __launch_bounds__(kPprThreads) void ppr_spmm_kernel(const int32_t *__
   }
 }
 
+// sum of part[0..m)[c] in index order (the loads of a batch are issued together, the adds stay sequential)
+__device__ __forceinline__ double column_sum(const double *__restrict__ part, int m, int kpad, int c) {
+  double s = 0.0;
+  int j = 0;
+  for (; j + 16 <= m; j += 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = part[(size_t)(j + u) * kpad + c];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
+  for (; j < m; ++j) s += part[(size_t)j * kpad + c];
+  return s;
+}
+
 __global__ void ppr_init_kernel(double *x, size_t total, int kpad, int k, double v, int32_t *done, int32_t *iters) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total) x[i] = (int)(i % kpad) < k ? v : 0.0;
@@ -165,8 +180,7 @@ __global__ void ppr_column_kernel(const double *__restrict__ x, const double *__
                                   int k, int kpad, double *__restrict__ dsum, double *__restrict__ yself) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= k) return;
-  double s = 0.0;
-  for (int j = 0; j < n_chunks; ++j) s += part[(size_t)j * kpad + c];
+  double s = column_sum(part, n_chunks, kpad, c);
   for (int e = zero_ptr[c]; e < zero_ptr[c + 1]; ++e) s += stash_o[zero_ovr[e]];
   if (start_dangling[c]) s += x[(size_t)start[c] * kpad + c];
   dsum[c] = s;
@@ -220,8 +234,7 @@ __global__ void ppr_finish_kernel(const double *__restrict__ part, int n_blocks,
                                   int32_t *__restrict__ iters, int32_t *__restrict__ n_active) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= k || done[c]) return;
-  double err = 0.0;
-  for (int j = 0; j < n_blocks; ++j) err += part[(size_t)j * kpad + c];
+  const double err = column_sum(part, n_blocks, kpad, c);
   if (err < thr) {
     done[c] = 1;
     iters[c] = it;

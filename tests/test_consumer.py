@@ -52,3 +52,26 @@ def test_indication_aucs_and_tsv_reader(tmp_path):
     aucs, used = consumer.indication_aucs(emb, names, names[:4], ["C1", "C2", "C3", "C4"], pos)
     assert used == ["C1", "C2"]       # C3 has no positives, C4 is not in the graph
     assert aucs[0] == 1.0
+
+
+def test_diffusion_indication_aucs_match_sklearn_on_reference_profiles():
+    """evaluate_auc.py:156-161 on the reference's own diffusion profiles of the small MSI (golden fixture)"""
+    import os
+    from sklearn.metrics import roc_auc_score
+    from conftest import GOLDEN
+    from gcn_drug_repurposing_amd import consumer
+    z = np.load(os.path.join(GOLDEN, "diffusion_msi_small.npz"))
+    names = [str(v) for v in z["nodelist"]]
+    starts = [str(s) for s in z["starts"]]
+    profiles = dict(zip(starts, z["profiles"]))
+    drugs = [s for s in starts if s.startswith("DB")]
+    inds = [s for s in starts if not s.startswith("DB")]
+    rng = np.random.RandomState(0)
+    pos = {i: set(rng.choice(drugs, 3, replace=False)) for i in inds[:6]}
+    pos[inds[6]] = set()                       # no positive drug: skipped
+    aucs, used = consumer.diffusion_indication_aucs(profiles, names, drugs, inds + ["C9999999"], pos)
+    assert used == inds[:6]
+    didx = [names.index(d) for d in drugs]
+    for a, i in zip(aucs, used):
+        ref = np.array([1 if d in pos[i] else 0 for d in drugs])
+        assert abs(a - roc_auc_score(ref, profiles[i][didx])) < 1e-12
