@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """diffusion profiles of every drug and indication of the whole-graph stand-in (N = 29,960, 2,502 start nodes):
-device batch vs the CPU oracle on a sample (GPU box only).  usage: diffusion_bench.py [scale] [cpu_sample]"""
+time of the device batch and of its fp64 SpMM (GPU box only; the CPU comparison is bench.py --workload diffusion).
+usage: diffusion_bench.py [scale]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp, torch
@@ -8,7 +9,6 @@ from gcn_drug_repurposing_amd import synth
 from gcn_drug_repurposing_amd.diffusion import PprEngine, PprProblem
 
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-cpu_sample = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 adj, ntype, _ = synth.whole_graph_standin(seed=1, scale=scale)
 m0 = sp.csr_matrix(adj, dtype=np.float64)
 di = np.flatnonzero(ntype <= 1)
@@ -37,15 +37,3 @@ print(f"fp64 SpMM: {us:.0f} us/launch, algorithmic {alg / 1e6:.0f} MB -> {alg / 
       f"gathered {prob.mt.nnz * prob.kpad * 8 / us / 1e6:.1f} TB/s")
 xs = x[:, :prob.k].t().contiguous().cpu().numpy()
 print(f"column sums in [{xs.sum(1).min():.12f}, {xs.sum(1).max():.12f}]")
-if cpu_sample:
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from oracle import diffusion_oracle as O
-    pick = np.linspace(0, prob.k - 1, cpu_sample).astype(int)
-    t0 = time.time()
-    worst = 0.0
-    for c in pick:
-        ref, rit = O.diffusion_profile(m0, int(di[c]), prot, *hp)
-        worst = max(worst, np.abs(ref - xs[c]).max()); assert rit == it[c], (rit, it[c])
-    t_cpu = (time.time() - t0) / len(pick)
-    print(f"CPU oracle (scipy, 1 core): {t_cpu:.2f} s per start node -> {t_cpu * prob.k:.0f} s for all; max |diff| on the sample {worst:.2e}; "
-          f"device speed-up {t_cpu * prob.k / t_run:.0f}x")
