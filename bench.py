@@ -60,6 +60,13 @@ def build_workload(name, d_override=None):
     return adj, x, (d_override or d), L, B
 
 
+_RESULT_FD = 1
+
+
+def emit(result):
+    os.write(_RESULT_FD, (json.dumps(result) + "\n").encode())
+
+
 def bench_diffusion(args, rank, world, local_rank):
     """--workload diffusion: all diffusion profiles of the whole-graph stand-in.  A step = the
     complete batched power iteration for every drug and indication; start nodes are independent, so N ranks take
@@ -135,7 +142,7 @@ def bench_diffusion(args, rank, world, local_rank):
             out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "profiles/s", "cores": 1, "kind": "port",
                                    "sample": f"{len(pick)} of the {len(di)} start nodes, one scipy power iteration each "
                                              f"(oracle/diffusion_oracle.py), max |device - oracle| = {worst:.1e}"}
-        print(json.dumps(out))
+        emit(out)
 
 
 def main():
@@ -154,6 +161,13 @@ def main():
 
     import torch
     import torch.distributed as dist
+
+    # stdout carries exactly one JSON line.  RCCL prints a version banner to the C stdout when a communicator is
+    # created, so file descriptor 1 is pointed at stderr for the whole run and the result goes to the saved descriptor.
+    sys.stdout.flush()
+    global _RESULT_FD
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -314,7 +328,7 @@ def main():
                                "spmm_kernel_edges_per_s": nnz / t_spmm, "host_cpus": os.cpu_count()}
 
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if dist.is_initialized():
         dist.destroy_process_group()
 

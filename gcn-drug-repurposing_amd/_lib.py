@@ -59,6 +59,7 @@ SIGNATURES = {
     "gss_loss_fwd_bwd": (C.c_int, [_I32, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "gss_rownorm_elu_bwd": (C.c_int, [_I32, _P, _P, _I32, _P, _P, _P, _F, _P, _P, _P]),
     "gss_scatter_add_rows": (C.c_int, [_I32, _P, _P, _I32, _P, _P]),
+    "gss_shard_batch_maps": (C.c_int, [_P, _I32, _I32, _I32, _P, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     "gss_adam_step": (C.c_int, [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P, _I32, _P]),
     "gss_percentile": (C.c_int, [_I32, _I32, _P, _D, C.POINTER(_F), _P]),
     "gss_knn_topk": (C.c_int, [_I32, _I32, _P, _I32, _P, _P, _P]),

@@ -47,6 +47,8 @@ int rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, 
 int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b, const float *e, const float *inv_den,
                     const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set, void *stream);
 int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, int32_t *pos_clear, void *stream);
+int shard_batch_maps(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
+                     int32_t *rows_all, int32_t *rows_own, float *keep, int32_t *pos_col, int32_t *pos_row, void *stream);
 int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,
                      const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream);
 bool spmm_sparse_available();

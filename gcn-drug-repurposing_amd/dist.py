@@ -252,6 +252,17 @@ class HipOps:
         if b:
             _lib.check(self.lib.gss_scatter_add_rows(d, src.data_ptr(), rows.data_ptr(), b, dst.data_ptr(), self.st()), "gss_scatter_add_rows")
 
+    def batch_maps(self, idx32, lo, nl, bounds_dev, world, maxr):
+        """index maps of one batch on this shard (gss_shard_batch_maps) -> rows_all, rows_own, keep [b,1], pos_col, pos_row"""
+        b = idx32.numel()
+        rows_all, rows_own = self.empty(b, dtype=torch.int32), self.empty(b, dtype=torch.int32)
+        keep = self.empty(b, 1)
+        pos_col, pos_row = self.empty(world * maxr, dtype=torch.int32), self.empty(max(nl, 1), dtype=torch.int32)
+        _lib.check(self.lib.gss_shard_batch_maps(idx32.data_ptr(), b, int(lo), int(nl), bounds_dev.data_ptr(), int(world), int(maxr),
+                                                 rows_all.data_ptr(), rows_own.data_ptr(), keep.data_ptr(), pos_col.data_ptr(),
+                                                 pos_row.data_ptr(), self.st()), "gss_shard_batch_maps")
+        return rows_all, rows_own, keep, pos_col, pos_row
+
     def adam(self, params, grads, m, v, step, lr, betas, eps):
         for k in range(4):
             _lib.check(self.lib.gss_adam_step(params[k].numel(), params[k].data_ptr(), grads[k].data_ptr(), m[k].data_ptr(),
@@ -293,7 +304,12 @@ class ShardedEngine:
             self.at = ops.csr(ip, ix, dv, self.nl, world * self.maxr)
         self.x0 = ops.tensor(x_host[self.lo:self.hi].astype(np.float32))
         self.params = [ops.tensor(params_host[k].astype(np.float32)) for k in ("W1", "b1", "W2", "b2")]
-        self.grads = [torch.zeros_like(p) for p in self.params]
+        # the four gradients are views of one flat buffer: one all-reduce, no packing
+        self._grad_flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=self.params[0].device)
+        self.grads, o = [], 0
+        for p in self.params:
+            self.grads.append(self._grad_flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
         self.step_no = 0
@@ -302,6 +318,7 @@ class ShardedEngine:
         self._send = ops.zeros(self.maxr, d)                 # padded send buffer
         self._full = [ops.empty(world * self.maxr, d) for _ in range(2)]
         self._bounds_dev = ops.tensor(self.part.bounds, dtype=torch.int64)
+        self._x0_full = None
 
     @staticmethod
     def _normalize_host(adj):
@@ -329,7 +346,12 @@ class ShardedEngine:
         self.act = []
         x, p_prev = self.x0, None
         for l in range(L):
-            xf = self._gather(x, 0)
+            if l == 0:
+                if self._x0_full is None:                              # the input features never change: distribute them once
+                    self._x0_full = self._gather(x, 0).clone()
+                xf = self._x0_full
+            else:
+                xf = self._gather(x, 0)
             ax, m = ops.spmm(self.a, xf, h=x)                          # model.py:163,168
             mf = self._gather(m, 1)
             am, _ = ops.spmm(self.a, mf)                               # model.py:169
@@ -340,40 +362,28 @@ class ShardedEngine:
         return self.emb
 
     def loss_backward(self, idx32, beta, count=None, offset=0):
+        """Fixed-shape on purpose: every rank handles all b batch rows, with the rows it does not own masked to zero
+        (a clamped row index, zero gradient), so nothing here depends on a device value and the host never waits for
+        the GPU inside a step."""
         ops, L, d = self.ops, self.L, self.d
         b = int(count if count is not None else idx32.numel())
-        idx = idx32[offset:offset + b].long()
-        mine = (idx >= self.lo) & (idx < self.hi)
-        pos_b = torch.nonzero(mine).flatten()                          # batch positions owned by this rank
-        rows_loc = (idx[pos_b] - self.lo).to(torch.int32).contiguous()
+        rows_all, rows_own, keep, pos_col, pos_row = ops.batch_maps(idx32[offset:offset + b], self.lo, self.nl, self._bounds_dev,
+                                                                    self.comm.world, self.maxr)
         # E_B on every rank: each rank contributes its rows, one all-reduce (model.py:216-217)
-        e_b = ops.zeros(b, d)
-        if pos_b.numel():
-            e_b.index_copy_(0, pos_b, self.emb.index_select(0, rows_loc.long()))
+        e_b = self.emb.index_select(0, rows_all.long()) * keep
         self.comm.all_reduce_sum_(e_b)
         loss, de_b = ops.loss_fwd_bwd(e_b, beta, self.alpha)           # model.py:218-221 (+ autograd); same on every rank
         self.loss = loss
-        de_loc = de_b.index_select(0, pos_b).contiguous()
         top = self.act[L - 1]
         c_top = self.decay if L > 1 else 1.0
-        dx_b, dp_b = ops.rownorm_elu_bwd(de_loc, rows_loc, self.emb, self.inv_den, top["p"], c_top)
-        ops.wgrad(dp_b, top["ax"], top["am"], rows_loc, self.grads, accumulate=False)
+        dx_b, dp_b = ops.rownorm_elu_bwd(de_b * keep, rows_all, self.emb, self.inv_den, top["p"], c_top)   # zero rows where not owned
+        ops.wgrad(dp_b, top["ax"], top["am"], rows_all, self.grads, accumulate=False)
         if L > 1:
             w1t, w2t = self.params[0].t().contiguous(), self.params[2].t().contiguous()
-            gax_loc, gam_loc = ops.dgrad(dp_b, w1t, w2t)
-            # batch-row gradients of every rank, compact [B][d], by one all-reduce each
-            gax_b, gam_b = ops.zeros(b, d), ops.zeros(b, d)
-            if pos_b.numel():
-                gax_b.index_copy_(0, pos_b, gax_loc)
-                gam_b.index_copy_(0, pos_b, gam_loc)
+            gax_b, gam_b = ops.dgrad(dp_b, w1t, w2t)                    # [b][d] in batch order, zero where not owned
             both = torch.cat([gax_b, gam_b])
-            self.comm.all_reduce_sum_(both)
-            gax_b, gam_b = both[:b].contiguous(), both[b:].contiguous()
-            pos_col = torch.full((self.comm.world * self.maxr,), -1, dtype=torch.int32, device=both.device)
-            pos_col[self._padded_ids(idx)] = torch.arange(b, dtype=torch.int32, device=both.device)
-            pos_row = torch.full((max(self.nl, 1),), -1, dtype=torch.int32, device=both.device)
-            if pos_b.numel():
-                pos_row[rows_loc.long()] = pos_b.to(torch.int32)
+            self.comm.all_reduce_sum_(both)                            # batch-row gradients of every rank
+            gax_b, gam_b = both[:b], both[b:]
             u, t = ops.spmm_bwd1_sparse(self.at, gam_b, gax_b, pos_col, pos_row, top["x"], top["ax"])
             gx_prev = None       # g_x(lp + 2) as a dense local tensor, once lp + 2 <= L - 1
             for lp in range(L - 2, -1, -1):
@@ -382,19 +392,14 @@ class ShardedEngine:
                 uf = self._gather(u, 0)
                 dp, gx = ops.spmm_bwd2(self.at, uf, t, lay["p"], c, gx_prev if lp + 2 <= L - 1 else None, want_gx=lp >= 1)
                 if lp + 2 == L:
-                    ops.scatter_add_rows(dx_b, rows_loc, dp)
+                    ops.scatter_add_rows(dx_b, rows_own, dp)
                 ops.wgrad(dp, lay["ax"], lay["am"], None, self.grads, accumulate=True)
                 if lp >= 1:
                     gax, gam = ops.dgrad(dp, w1t, w2t)
                     gf = self._gather(gam, 1)
                     u, t = ops.spmm_bwd1(self.at, gf, gax, lay["x"], lay["ax"])
                 gx_prev = gx
-        flat = torch.cat([g.reshape(-1) for g in self.grads])
-        self.comm.all_reduce_sum_(flat)                               # C2: 2 (d^2 + d) floats
-        o = 0
-        for g in self.grads:
-            g.copy_(flat[o:o + g.numel()].view_as(g))
-            o += g.numel()
+        self.comm.all_reduce_sum_(self._grad_flat)                     # C2: 2 (d^2 + d) floats
 
     def adam(self):
         self.step_no += 1

@@ -111,8 +111,17 @@ int gss_loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, i
 int gss_rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b, const float *e,
                         const float *inv_den, const float *p, float c, float *dx_b, float *dp_b, void *stream);
 
-/* dst[rows[r]] += src[r] for r < b (rows unique) */
+/* dst[rows[r]] += src[r] for r < b (rows unique; a negative row is skipped -- a batch row another shard owns) */
 int gss_scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, void *stream);
+
+/* Node-range sharded trainer: the index maps one shard needs for one batch.  idx: [b] global node ids;
+ * this shard owns [lo, lo + nl); bounds: device int64 [world + 1] shard boundaries; operands gathered from all shards
+ * are laid out padded, shard o at rows [o * maxr, o * maxr + rows of o).
+ *   rows_all[i] = local row of idx[i], clamped into the shard (any owned row where the shard has no say)
+ *   rows_own[i] = local row, or -1 if another shard owns idx[i];  keep[i] = 1.0 / 0.0 likewise
+ *   pos_col[padded id] = i for batch members, -1 elsewhere ([world * maxr]);  pos_row[local row] = i or -1 ([nl]) */
+int gss_shard_batch_maps(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
+                         int32_t *rows_all, int32_t *rows_own, float *keep, int32_t *pos_col, int32_t *pos_row, void *stream);
 
 /* ---- K10  torch.optim.Adam.step, train.py:139-141,184 -----------------------------------------
  * One tensor of `count` floats; step is the 1-based step number.  lr, betas, eps as torch defaults.

@@ -100,7 +100,21 @@ class NumpyOps:
 
     def scatter_add_rows(self, src, rows, dst):
         if src.shape[0]:
-            dst.index_add_(0, rows.long(), src)
+            keep = rows >= 0
+            dst.index_add_(0, rows[keep].long(), src[keep])
+
+    def batch_maps(self, idx32, lo, nl, bounds_dev, world, maxr):
+        idx = idx32.numpy().astype(np.int64)
+        bounds = bounds_dev.numpy()
+        rel = idx - lo
+        mine = (rel >= 0) & (rel < nl)
+        o = np.searchsorted(bounds, idx, side="right") - 1
+        pos_col = np.full(world * maxr, -1, np.int32)
+        pos_col[o * maxr + (idx - bounds[o])] = np.arange(len(idx), dtype=np.int32)
+        pos_row = np.full(max(nl, 1), -1, np.int32)
+        pos_row[rel[mine]] = np.arange(len(idx), dtype=np.int32)[mine]
+        return (torch.from_numpy(np.clip(rel, 0, max(nl - 1, 0)).astype(np.int32)), torch.from_numpy(np.where(mine, rel, -1).astype(np.int32)),
+                torch.from_numpy(mine.astype(np.float32)[:, None]), torch.from_numpy(pos_col), torch.from_numpy(pos_row))
 
     def adam(self, params, grads, m, v, step, lr, betas, eps):
         b1, b2 = betas
