@@ -156,6 +156,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 // LDS-DMA in inline asm: hipcc must not see these loads, otherwise it drains them (vmcnt(0)) before every
 // ds_read / barrier and the multi-chunk pipeline collapses (cdna guide section 5 'Pipelining across barriers').
 // M0 (the LDS destination base) is written in the same statement that uses it and restored afterwards.
+// Measured dead end: letting a workgroup walk 2-4 node tiles in sequence (next tile's DMA in flight under the epilogue)
+// to spread the epilogue stores over the launch: 36.8 / 52.8 / 67.8 us vs 30.6 us at d = 128 -- a tile costs ~18 us of
+// wall time per workgroup whatever surrounds it (rocprofv3: per wave 16k cycles of MFMA, 19k of s_waitcnt, 2 waves per
+// SIMD), so the co-resident workgroups of the one-tile-per-workgroup grid are what hides the stalls.
 __device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_byte_addr) {
   unsigned keep;
   asm volatile(
