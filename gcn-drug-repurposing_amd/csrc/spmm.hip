@@ -224,7 +224,7 @@ __device__ __forceinline__ long compact_off(const SpmmEpi &ep, int row, int d4, 
   return pr >= 0 ? ((long)pr * d4 + f4) * 4 : -1;
 }
 
-template <int MODE, int LPR_LOG2, int VPL>
+template <int MODE, int LPR_LOG2, int VPL, bool NARROW>
 __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, const int4 *__restrict__ segs, int d4,
                                                                    const float *__restrict__ x, SpmmEpi ep, int rowstride_f, int pin_ns) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -255,14 +255,24 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   float4 acc[VPL];
 #pragma unroll
   for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // the (col, val) pairs of the next LPR entries are requested before the gathers of the current ones
+  int c_next = 0;
+  float w_next = 0.f;
+  if (e0 + li < e1) {
+    c_next = a.col[e0 + li];
+    w_next = a.val[e0 + li];
+  }
   for (int base = e0; __any(base < e1); base += LPR) {
-    const int ce = base + li;
-    int c = 0;
-    float w = 0.f;
-    if (ce < e1) {
-      c = a.col[ce];
-      w = a.val[ce];
+    const int c = c_next;
+    const float w = w_next;
+    const int ne = base + LPR + li;
+    c_next = 0;
+    w_next = 0.f;
+    if (ne < e1) {
+      c_next = a.col[ne];
+      w_next = a.val[ne];
     }
+    const int ce = base + li;
     const int cnt = min(LPR, e1 - base);  // <= 0 once this group is done
     if (MODE == SPMM_BWD1S) {
       // row-sparse operand: only neighbours that are batch rows contribute (about B/N of the entries).  Look
@@ -302,6 +312,17 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
         wv[u] = __shfl(w, src, 64);
         const bool ok = (t + u < cnt) && col_ok;
         if (!ok) wv[u] = 0.f;
+        if (NARROW) {
+          // operand < 4 GB, < 2^24 rows: 32-bit byte offsets from the (uniform) base, one full-rate 24-bit multiply-add per gather
+          const unsigned off = __umul24((unsigned)cc, (unsigned)(rowstride_f * 4)) + (unsigned)li * 16u;
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) {
+            const int f4 = li + v * 64;
+            xv[u][v] = (ok && (VPL == 1 || f4 < d4)) ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(x) + (off + v * 1024u))
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          continue;
+        }
         const float *xr = x + (size_t)cc * rowstride;
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
@@ -467,8 +488,13 @@ static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool p
   if (nblk == 0) return GSS_OK;
   CsrView v{a->rowptr, a->col, a->val, a->n_rows};
   const size_t lds = (size_t)kBalWaves * d4_slice * sizeof(float4);
-  hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL>), pin ? dim3(nblk * nslices) : dim3(nblk, nslices), dim3(kBalThreads), lds,
-                     st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0);
+  const bool narrow = (double)a->n_cols * d4_slice * nslices * 16.0 < 4.0e9 && a->n_cols < (1 << 24);
+  if (narrow)
+    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, true>), pin ? dim3(nblk * nslices) : dim3(nblk, nslices), dim3(kBalThreads),
+                       lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0);
+  else
+    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, false>), pin ? dim3(nblk * nslices) : dim3(nblk, nslices), dim3(kBalThreads),
+                       lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0);
   GSS_LAUNCH_CHECK("spmm_balanced_kernel");
   return GSS_OK;
 }

@@ -19,8 +19,7 @@ n, nnz = g.n, g.nnz
 print(f"graph {which}: N={n} nnz={nnz} long_rows={(np.diff(g.a.h_indptr) > 512).sum()}")
 for d in [int(v) for v in (sys.argv[4:] or ["16", "32", "64", "128", "256"])]:
   for variant in (1, 2):
-    lib.gss_debug_set_option(b"spmm_variant", 2)
-    lib.gss_debug_set_option(b"spmm_slices", max(1, variant // 10))
+    lib.gss_debug_set_option(b"spmm_variant", variant)   # 1 = row per wave, 2 = nnz-balanced segments (automatic slicing)
     x = torch.randn(n, d, device="cuda")
     y = torch.empty(n, d, device="cuda")
     st = _lib.current_stream()
