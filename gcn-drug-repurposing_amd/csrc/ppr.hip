@@ -50,6 +50,7 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 }
 
 // y[row][chunk] = sum_e val[e] * x[col[e]][chunk] for the segments of one workgroup; kpad doubles per row
+template <bool NARROW>
 __global__ __launch_bounds__(kPprThreads) void ppr_spmm_kernel(const int32_t *__restrict__ col, const double *__restrict__ val,
                                                                const int4 *__restrict__ segs, const double *__restrict__ x,
                                                                double *__restrict__ y, int kpad) {
@@ -66,13 +67,22 @@ __global__ __launch_bounds__(kPprThreads) void ppr_spmm_kernel(const int32_t *__
   const size_t coff = (size_t)blockIdx.y * 64 + half * 32 + li * 2;  // first of this lane's two columns
   const double *xs = x + coff;
   double2 acc = make_double2(0.0, 0.0);
+  // the (col, val) pairs of the next LPR entries are requested before the gathers of the current ones
+  int c_next = 0;
+  double w_next = 0.0;
+  if (e0 + li < e1) {
+    c_next = col[e0 + li];
+    w_next = val[e0 + li];
+  }
   for (int base = e0; __any(base < e1); base += LPR) {
-    const int ce = base + li;
-    int c = 0;
-    double w = 0.0;
-    if (ce < e1) {
-      c = col[ce];
-      w = val[ce];
+    const int c = c_next;
+    const double w = w_next;
+    const int ne = base + LPR + li;
+    c_next = 0;
+    w_next = 0.0;
+    if (ne < e1) {
+      c_next = col[ne];
+      w_next = val[ne];
     }
     const int cnt = min(LPR, e1 - base);
     constexpr int kFly = 4;
@@ -86,7 +96,12 @@ __global__ __launch_bounds__(kPprThreads) void ppr_spmm_kernel(const int32_t *__
         wv[u] = shfl_f64(w, src);
         const bool ok = t + u < cnt;
         if (!ok) wv[u] = 0.0;
-        xv[u] = ok ? *reinterpret_cast<const double2 *>(xs + (size_t)cc * kpad) : make_double2(0.0, 0.0);
+        if (NARROW) {  // matrix < 4 GB, < 2^24 rows: 32-bit byte offsets, one 24-bit multiply-add per gather
+          const unsigned off = __umul24((unsigned)cc, (unsigned)kpad * 8u);
+          xv[u] = ok ? *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(xs) + off) : make_double2(0.0, 0.0);
+        } else {
+          xv[u] = ok ? *reinterpret_cast<const double2 *>(xs + (size_t)cc * kpad) : make_double2(0.0, 0.0);
+        }
       }
 #pragma unroll
       for (int u = 0; u < kFly; ++u) {
@@ -248,7 +263,13 @@ static int ppr_spmm_launch(gss_ppr *p, const double *x, double *y, hipStream_t s
   int nblk = 0;
   if (int rc = csr_segments(p->csr, 2, &segs, &nblk)) return rc;
   if (nblk == 0) return GSS_OK;
-  hipLaunchKernelGGL(ppr_spmm_kernel, dim3(nblk * 2, p->d.kpad / 64), dim3(kPprThreads), 0, st, p->d.t_col, p->d.t_val, segs, x, y, p->d.kpad);
+  const bool narrow = (double)p->d.n * p->d.kpad * 8.0 < 4.0e9 && p->d.n < (1 << 24) && (int64_t)p->d.kpad * 8 < (1 << 24);
+  if (narrow)
+    hipLaunchKernelGGL(ppr_spmm_kernel<true>, dim3(nblk * 2, p->d.kpad / 64), dim3(kPprThreads), 0, st, p->d.t_col, p->d.t_val, segs, x, y,
+                       p->d.kpad);
+  else
+    hipLaunchKernelGGL(ppr_spmm_kernel<false>, dim3(nblk * 2, p->d.kpad / 64), dim3(kPprThreads), 0, st, p->d.t_col, p->d.t_val, segs, x, y,
+                       p->d.kpad);
   GSS_LAUNCH_CHECK("ppr_spmm_kernel");
   return GSS_OK;
 }
