@@ -110,6 +110,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise GssError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        f"or `make -C {CSRC}` -- there is no CPU fallback for the GSS-GCN kernels")
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so): it has to be in the process before this library is,
+    # otherwise the library binds to /opt/rocm's copy and the two runtimes do not see each other's device state
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here means header and library disagree

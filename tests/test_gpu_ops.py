@@ -359,3 +359,28 @@ def test_knn_topk_values_and_odd_sizes(G):
         got_idx = ti.cpu().numpy()
         assert np.array_equal(np.sort(got_idx, 1), np.sort(ref_idx, 1))
         np.testing.assert_allclose(np.sort(tv.cpu().numpy(), 1), np.sort(np.take_along_axis(sim, ref_idx, 1), 1), rtol=1e-12)
+
+
+def test_library_loaded_before_torch_still_sees_the_gpu():
+    """torch ships its own HIP runtime; a process that loads libgssgcn.so first (build() then smoke() in one interpreter)
+    must end up with ONE runtime.  Run in a child process so the import order is really this one."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as g\n"
+        "g.build()\n"                       # loads the library before anything imported torch
+        "import torch, numpy as np\n"
+        "import gcn_drug_repurposing_amd as pkg\n"
+        "from gcn_drug_repurposing_amd.graph import GssGraph\n"
+        "import scipy.sparse as sp\n"
+        "a = sp.random(300, 300, density=0.03, random_state=1, format='csr'); a = a + a.T\n"
+        "gg = GssGraph(a)\n"
+        "x = torch.ones(300, 16, device='cuda'); y = torch.empty_like(x)\n"
+        "pkg._lib.check(pkg.load().gss_spmm(gg.a.handle, 16, x.data_ptr(), y.data_ptr(), None, None, pkg._lib.current_stream()))\n"
+        "torch.cuda.synchronize(); print('rowsum', float(y[:, 0].sum()))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "rowsum" in out.stdout
