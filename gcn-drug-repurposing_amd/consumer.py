@@ -116,3 +116,13 @@ def diffusion_indication_aucs(profiles, names, drugs, indications, positives):
         aucs.append(roc_auc(ref, np.asarray(profiles[ind])[didx]))
         used.append(ind)
     return np.asarray(aucs), used
+
+
+def rank_by_diffusion(profile, names, candidates):
+    """predict_drug.py:107-121: candidates (the drug nodes, in node order) ranked by the query node's visit probability at
+    them, best first (np.argsort(...)[::-1], ties as numpy breaks them) -> (ranked candidates, their probabilities)"""
+    idx = {n: i for i, n in enumerate(names)}
+    cand = [c for c in candidates if c in idx]
+    prox = np.asarray([profile[idx[c]] for c in cand])
+    order = np.argsort(prox)[::-1]
+    return [cand[i] for i in order], prox[order]

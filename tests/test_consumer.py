@@ -75,3 +75,19 @@ def test_diffusion_indication_aucs_match_sklearn_on_reference_profiles():
     for a, i in zip(aucs, used):
         ref = np.array([1 if d in pos[i] else 0 for d in drugs])
         assert abs(a - roc_auc_score(ref, profiles[i][didx])) < 1e-12
+
+
+def test_rank_by_diffusion_follows_predict_drug():
+    import os
+    from conftest import GOLDEN
+    from gcn_drug_repurposing_amd import consumer
+    z = np.load(os.path.join(GOLDEN, "diffusion_msi_small.npz"))
+    names = [str(v) for v in z["nodelist"]]
+    starts = [str(s) for s in z["starts"]]
+    res = z["profiles"][starts.index("NodeCovid")]
+    drugs = [n for n in names if n.startswith("DB")]
+    ranked, prox = consumer.rank_by_diffusion(res, names, drugs)
+    # predict_drug.py:110-121 spelled out
+    p = np.array([res[i] for i, n in enumerate(names) if n.startswith("DB")])
+    o = np.argsort(p)[::-1]
+    assert ranked == [drugs[i] for i in o] and (prox == p[o]).all() and (np.diff(prox) <= 0).all()
