@@ -43,6 +43,13 @@ def build_workload(name, d_override=None):
         adj, _, _ = synth.whole_graph_standin(seed=1)
         d, L, B = 128, 2, 2048
         x = synth.gaussian_features(adj.shape[0], d_override or d, seed=2)
+    elif name == "whole_graph_knn":
+        # train.py's own adjacency: the "descriptor" kNN graph (k = 5) of the input features (helpers/helper.py:25-58),
+        # built on the device (gss_knn_topk); same N, d, L, B as whole_graph
+        from gcn_drug_repurposing_amd.graph import knn_descriptor_adj_device
+        d, L, B = 128, 2, 2048
+        x = synth.gaussian_features(29960, d_override or d, seed=2)
+        adj = knn_descriptor_adj_device(x.astype(np.float64), 5)
     elif name == "whole_graph_pathway":
         adj, _, _ = synth.whole_graph_standin(seed=1, pathway_edges=True)
         d, L, B = 256, 3, 2048

@@ -11,6 +11,9 @@ lib = pkg.load()
 which = sys.argv[1] if len(sys.argv) > 1 else "whole"
 if which == "whole":
     adj, _, _ = synth.whole_graph_standin(1)
+elif which == "knn":
+    from gcn_drug_repurposing_amd.graph import knn_descriptor_adj_device
+    adj = knn_descriptor_adj_device(synth.gaussian_features(29960, 128, 2).astype(np.float64), 5)
 else:
     n, m = int(sys.argv[2]), int(sys.argv[3])
     adj = synth.rmat_adj(n, m)
