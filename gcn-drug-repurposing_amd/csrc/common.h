@@ -71,7 +71,8 @@ __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(
 __device__ __forceinline__ float4 scale4(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
 
 // F.elu (alpha = 1) and its derivative expressed through the pre-activation
-__device__ __forceinline__ float elu1(float p) { return p > 0.f ? p : expm1f(p); }
+// torch's elu is exp(x) - 1 for x <= 0 (ATen/native/cpu/Activation.cpp), not expm1; expf - 1 is also a fraction of expm1f's cost
+__device__ __forceinline__ float elu1(float p) { return p > 0.f ? p : expf(p) - 1.f; }
 __device__ __forceinline__ float elu1_grad(float p) { return p > 0.f ? 1.f : expf(p); }
 __device__ __forceinline__ float4 elu_grad4(float4 p) {
   return make_float4(elu1_grad(p.x), elu1_grad(p.y), elu1_grad(p.z), elu1_grad(p.w));

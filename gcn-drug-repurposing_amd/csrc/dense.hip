@@ -145,6 +145,48 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
   }
 }
 
+// Epilogue of the forward projection for one 16-node x 16 NT tile row: lane (r, q) holds OUT[nd][j0 + 16 u + 4 q + 0..3]
+// in acc[u].  All loads (biases, previous layer's P) are issued before the first store: the stores may alias them as
+// far as the compiler knows, so a load placed after a store waits for that store (vmcnt counts both) -- written the
+// naive way this was 3 NT serialised memory round trips per tile and most of the kernel's time.
+template <int NT, int EPI>
+__device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&acc)[NT], int nd, int j0, int q) {
+  const bool live = nd < g.n;
+  const int ndc = min(nd, g.n - 1);
+  float4 bb[NT], pp[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const int j = j0 + 16 * u + 4 * q;
+    bb[u] = add4(ld4(g.b1 + j), ld4(g.b2 + j));
+    pp[u] = g.p_prev ? ld4(g.p_prev + (size_t)ndc * g.ld_out0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 pv[NT], o[NT];
+  float ss = 0.f;
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    pv[u] = add4(make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]), bb[u]);
+    o[u] = make_float4(elu1(pv[u].x), elu1(pv[u].y), elu1(pv[u].z), elu1(pv[u].w));
+    if (g.p_prev) o[u] = add4(pp[u], scale4(g.decay, o[u]));
+    ss += o[u].x * o[u].x + o[u].y * o[u].y + o[u].z * o[u].z + o[u].w * o[u].w;
+  }
+  float inv = 1.f;
+  if (EPI == EPI_FWD_NORM) {
+    // last layer: F.normalize (modules/model.py:205).  The tile row spans all d features, so the 4 lanes q = 0..3 of a
+    // node hold its whole row; the sum of squares is reduced with two xor-shuffles.
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+  }
+  if (!live) return;
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const size_t off = (size_t)nd * g.ld_out0 + j0 + 16 * u + 4 * q;
+    st4(g.out0 + off, pv[u]);
+    st4(g.x_next + off, EPI == EPI_FWD_NORM ? scale4(inv, o[u]) : o[u]);
+  }
+  if (EPI == EPI_FWD_NORM && q == 0) g.inv_den[nd] = inv;
+}
+
 // ---- LDS-staged variant (default) -----------------------------------------------------------------------
 // Workgroup tile = 128 nodes x BN features (BN = 16 NT), 4 waves of 32 nodes x BN.  Per 16-wide K chunk the
 // operands arrive by LDS-DMA (global_load_lds_dwordx4): one wave instruction moves one MFMA fragment block
@@ -269,60 +311,31 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int nd = node_base + 16 * (MT * w + t) + r;
-    if (nd >= g.n) continue;
+    if (EPI == EPI_SPLIT) {
+      if (nd >= g.n) continue;
+      const int orow = g.rows ? g.rows[nd] : nd;
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      const int j = j0 + 16 * u + 4 * q;
-      float4 v = make_float4(acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]);
-      if (EPI == EPI_FWD) {
-        const float4 bb = add4(ld4(g.b1 + j), ld4(g.b2 + j));
-        const float4 pv = add4(v, bb);
-        const size_t off = (size_t)nd * g.ld_out0 + j;
-        st4(g.out0 + off, pv);
-        float4 o = make_float4(elu1(pv.x), elu1(pv.y), elu1(pv.z), elu1(pv.w));
-        if (g.p_prev) o = add4(ld4(g.p_prev + off), scale4(g.decay, o));
-        st4(g.x_next + off, o);
-      } else if (EPI == EPI_SPLIT) {
-        const int orow = g.rows ? g.rows[nd] : nd;
+      for (int u = 0; u < NT; ++u) {
+        const int j = j0 + 16 * u + 4 * q;
+        const float4 v = make_float4(acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]);
         if (jh == 0)
           st4(g.out0 + (size_t)orow * g.ld_out0 + j, v);
         else
           st4(g.out1 + (size_t)orow * g.ld_out1 + (j - g.jsplit), v);
       }
-    }
-  }
-  if (EPI == EPI_FWD_NORM) {
-    // last layer: F.normalize (modules/model.py:205) fused here.  BN == d, so the 4 lanes (q = 0..3) that share a
-    // node hold its whole row across their NT tiles; the sum of squares is reduced with two xor-shuffles.
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int nd = node_base + 16 * (MT * w + t) + r;
-      const int ndc = min(nd, g.n - 1);
-      float4 xv[NT];
-      float ss = 0.f;
-#pragma unroll
-      for (int u = 0; u < NT; ++u) {
-        const int j = 16 * u + 4 * q;
-        const float4 bb = add4(ld4(g.b1 + j), ld4(g.b2 + j));
-        const float4 pv = add4(make_float4(acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]), bb);
-        const size_t off = (size_t)ndc * g.ld_out0 + j;
-        if (nd < g.n) st4(g.out0 + off, pv);
-        float4 o = make_float4(elu1(pv.x), elu1(pv.y), elu1(pv.z), elu1(pv.w));
-        if (g.p_prev) o = add4(ld4(g.p_prev + off), scale4(g.decay, o));
-        xv[u] = o;
-        ss += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
-      }
-      ss += __shfl_xor(ss, 16, 64);
-      ss += __shfl_xor(ss, 32, 64);
-      const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
-      if (nd < g.n) {
-#pragma unroll
-        for (int u = 0; u < NT; ++u) st4(g.x_next + (size_t)nd * g.ld_out0 + 16 * u + 4 * q, scale4(inv, xv[u]));
-        if (q == 0) g.inv_den[nd] = inv;
-      }
+    } else {
+      fwd_epilogue<NT, EPI>(g, acc[t], nd, j0, q);
     }
   }
 }
+
+// Measured dead end, for the record: a weights-resident variant for d <= 128 ([W1|W2] = 128 KB DMA'd into LDS once per
+// workgroup, 8 independent waves per CU, each holding its 16-node [AX|AM] block in registers, fragment reads one chunk
+// ahead, no barrier in the loop): 32.9 us vs 31.4 us at N = 29,960, 202 vs 210 us at N = 240k.  Per-wave timestamps
+// (wall_clock64) at N = 29,960: 6.5 us until the weights are in LDS (every CU pulls the same 128 KB through the same L2
+// channels at the same time, in 64-B pieces), 9-17 us of MFMA (two waves per SIMD), 5.5 us of epilogue, all waves in
+// lockstep -- the launch is one burst of input, one of MFMA, one of output, whatever the tiling.  A bare
+// ds_read_b128-fed MFMA loop reaches 126-131 TFLOP/s (tools/micro/mfma_lds.hip), so the loop is not the limit.
 
 int g_gemm_variant = 2;
 
