@@ -9,7 +9,13 @@ from gcn_drug_repurposing_amd.graph import GssGraph
 
 lib = pkg.load()
 which = sys.argv[1] if len(sys.argv) > 1 else "whole"
-adj = synth.whole_graph_standin(1)[0] if which == "whole" else synth.rmat_adj(int(sys.argv[2]), int(sys.argv[3]))
+if which == "whole":
+    adj = synth.whole_graph_standin(1)[0]
+elif which == "knn":
+    from gcn_drug_repurposing_amd.graph import knn_descriptor_adj_device
+    adj = knn_descriptor_adj_device(synth.gaussian_features(29960, 128, 2).astype(np.float64), 5)
+else:
+    adj = synth.rmat_adj(int(sys.argv[2]), int(sys.argv[3]))
 st = _lib.current_stream()
 PLAIN = os.environ.get('PLAIN', '1') == '1'
 if True:
