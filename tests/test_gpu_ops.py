@@ -384,3 +384,39 @@ def test_library_loaded_before_torch_still_sees_the_gpu():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "rowsum" in out.stdout
+
+
+@pytest.mark.parametrize("workload", ["whole_graph", "rmat_300k"])
+def test_full_size_spmm_properties(G, workload):
+    """size-independent properties of the SpMM pair (CSR of A_hat and of its transpose) at full size: the row sums
+    A_hat 1, adjointness <A x, y> = <x, A^T y>, linearity, and the fused Hadamard epilogue against two launches"""
+    from gcn_drug_repurposing_amd import synth
+    if workload == "whole_graph":
+        adj = synth.whole_graph_standin(seed=1)[0]
+    else:
+        adj = synth.rmat_adj(300_000, 6_000_000, seed=4)     # table 150 MB: the time-separated slicing path
+    gg = G.graph.GssGraph(adj)
+    n, d = gg.n, 128
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(n, d, device="cuda", generator=gen)
+    y = torch.randn(n, d, device="cuda", generator=gen)
+    ax, aty = torch.empty_like(x), torch.empty_like(x)
+    st = G.st()
+    G._lib.check(G.lib.gss_spmm(gg.a.handle, d, x.data_ptr(), ax.data_ptr(), None, None, st))
+    G._lib.check(G.lib.gss_spmm(gg.at.handle, d, y.data_ptr(), aty.data_ptr(), None, None, st))
+    lhs, rhs = (ax.double() * y.double()).sum().item(), (x.double() * aty.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), abs(rhs), 1.0)
+    ones = torch.ones(n, 16, device="cuda")
+    rs = torch.empty(n, 16, device="cuda")
+    G._lib.check(G.lib.gss_spmm(gg.a.handle, 16, ones.data_ptr(), rs.data_ptr(), None, None, st))
+    a_hat, _ = O.preprocess_graph(adj)
+    ref = np.asarray(a_hat.sum(1)).reshape(-1)
+    assert np.abs(rs[:, 0].cpu().numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max())   # BASELINE.md: row sums within 1e-5
+    axy = torch.empty_like(x)
+    G._lib.check(G.lib.gss_spmm(gg.a.handle, d, (x + 2 * y).data_ptr(), axy.data_ptr(), None, None, st))
+    ay = torch.empty_like(x)
+    G._lib.check(G.lib.gss_spmm(gg.a.handle, d, y.data_ptr(), ay.data_ptr(), None, None, st))
+    assert (axy - (ax + 2 * ay)).abs().max().item() < 2e-5 * max(1.0, axy.abs().max().item())
+    ax2, m = torch.empty_like(x), torch.empty_like(x)
+    G._lib.check(G.lib.gss_spmm(gg.a.handle, d, x.data_ptr(), ax2.data_ptr(), y.data_ptr(), m.data_ptr(), st))
+    assert torch.equal(ax2, ax) and torch.equal(m, ax * y)
