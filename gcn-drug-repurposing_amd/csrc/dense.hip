@@ -336,6 +336,11 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
 // channels at the same time, in 64-B pieces), 9-17 us of MFMA (two waves per SIMD), 5.5 us of epilogue, all waves in
 // lockstep -- the launch is one burst of input, one of MFMA, one of output, whatever the tiling.  A bare
 // ds_read_b128-fed MFMA loop reaches 126-131 TFLOP/s (tools/micro/mfma_lds.hip), so the loop is not the limit.
+// Also measured on gemm_nt_lds_kernel at N = 29,960, d = 128 (31-33 us by box): a separate, 7-deep ring for the streamed
+// node-row chunks (neutral), delaying the second workgroup of every CU by 3-14 us (neutral to worse), two column halves
+// per node tile so that half the stores leave early (35.8 us).  A plain elementwise kernel moves the projection's 76 MB in
+// 12.5 us (tools/micro/stream_small.py) and the MFMAs need 13.7 us; the launch takes their sum plus start-up because
+// all workgroups reach the store phase together.
 
 int g_gemm_variant = 2;
 
