@@ -73,6 +73,7 @@ SIGNATURES = {
     "gss_plan_activation": (_P, [_P, C.c_int, C.c_int]),
     "gss_plan_device_bytes": (_SZ, [_P]),
     "gss_plan_set_step": (None, [_P, _I32]),
+    "gss_plan_adam_buffer": (_P, [_P, _I32, _I32]),
     "gss_plan_get_step": (_I32, [_P]),
     "gss_plan_profile": (C.c_int, [_P, C.c_int]),
     "gss_plan_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), _P]),

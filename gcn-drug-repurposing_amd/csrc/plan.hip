@@ -493,7 +493,13 @@ const float *gss_plan_activation(const gss_plan *p, int layer, int which) {
 }
 size_t gss_plan_device_bytes(const gss_plan *p) { return p ? p->slab_bytes : 0; }
 void gss_plan_set_step(gss_plan *p, int32_t step) {
-  if (p) p->step = step;
+  if (!p) return;
+  p->step = step;
+  p->wt_valid = false;  // a restored state: the transposed weight copies no longer match the weights
+}
+float *gss_plan_adam_buffer(gss_plan *p, int32_t moment, int32_t tensor) {
+  if (!p || moment < 0 || moment > 1 || tensor < 0 || tensor > 3) return nullptr;
+  return moment == 0 ? p->adam_m[tensor] : p->adam_v[tensor];
 }
 int32_t gss_plan_get_step(const gss_plan *p) { return p ? p->step : 0; }
 int gss_plan_profile(gss_plan *p, int enable) {

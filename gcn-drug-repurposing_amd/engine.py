@@ -106,5 +106,34 @@ class GssEngine:
         _lib.check(self.lib.gss_plan_profile_read(self.handle, ms, cnt, _lib.current_stream()), "gss_plan_profile_read")
         return {name: (ms[i], cnt[i]) for i, name in enumerate(_lib.PROF_CLASSES)}
 
+    # -- checkpoint / resume (the reference has none: SURVEY section 5; a few hundred KB per replica) ---------------
+    def _adam_view(self, moment: int, k: int) -> torch.Tensor:
+        ptr = self.lib.gss_plan_adam_buffer(self.handle, moment, k)
+        assert ptr, (moment, k)
+        out = torch.empty_like(self.params[k])
+        _lib.check(self.lib.gss_memcpy_d2d(out.data_ptr(), ptr, out.numel() * 4, _lib.current_stream()), "gss_memcpy_d2d")
+        return out
+
+    def state_dict(self) -> dict:
+        """parameters, Adam moments and step count as host arrays"""
+        sd = {"step": np.int64(self.lib.gss_plan_get_step(self.handle))}
+        for k, name in enumerate(PARAM_NAMES):
+            sd[name] = self.params[k].detach().cpu().numpy()
+            sd["m_" + name] = self._adam_view(0, k).cpu().numpy()
+            sd["v_" + name] = self._adam_view(1, k).cpu().numpy()
+        return sd
+
+    def load_state_dict(self, sd) -> None:
+        dev = self.x.device
+        for k, name in enumerate(PARAM_NAMES):
+            self.params[k].copy_(torch.from_numpy(np.ascontiguousarray(sd[name], dtype=np.float32)).to(dev))
+            for moment, key in ((0, "m_" + name), (1, "v_" + name)):
+                src = torch.from_numpy(np.ascontiguousarray(sd[key], dtype=np.float32)).to(dev)
+                assert src.shape == self.params[k].shape, (key, src.shape)
+                _lib.check(self.lib.gss_memcpy_d2d(self.lib.gss_plan_adam_buffer(self.handle, moment, k), src.data_ptr(), src.numel() * 4,
+                                                   _lib.current_stream()), "gss_memcpy_d2d")
+                torch.cuda.current_stream().synchronize()   # src must outlive the copy
+        self.lib.gss_plan_set_step(self.handle, int(sd["step"]))
+
     def device_bytes(self) -> int:
         return int(self.lib.gss_plan_device_bytes(self.handle))

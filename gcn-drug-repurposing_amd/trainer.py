@@ -6,7 +6,7 @@
 reads F ('.embs.txt'), trains the GSS graph-convolution embedding and writes ./graph_embs.txt.
 Flags the reference parses but never uses (--dataset, --data-path, --report-hard, --regularizer-scale, --kq)
 are accepted and ignored.  New optional flags: --adj-file (weighted edgelist / .sif adjacency instead of the
-kNN graph), --out, --cache-layer1, --batch-file (replay recorded batches), --log-loss.
+kNN graph), --out, --cache-layer1, --batch-file (replay recorded batches), --log-loss, --checkpoint / --resume.
 """
 from __future__ import annotations
 
@@ -55,6 +55,9 @@ def build_parser():
     p.add_argument('--cache-layer1', action='store_true', help="keep layer 1's two SpMM results across steps (inputs are constant)")
     p.add_argument('--batch-file', type=str, default=None, help='.npz with batches/batch_sizes to replay instead of sampling')
     p.add_argument('--log-loss', action='store_true', help='print the last loss of every epoch')
+    p.add_argument('--checkpoint', default=None, help='write the training state (weights, Adam moments, step, beta, sampler RNG) '
+                   'to this .npz after every epoch (single GPU)')
+    p.add_argument('--resume', default=None, help='continue from a --checkpoint file: same flags, remaining epochs')
     p.add_argument('--ngpus', type=int, default=None,
                    help='node-range shards over N GPUs of this node; launch with `python -m torch.distributed.run '
                         '--nproc-per-node N train.py ...` (defaults to WORLD_SIZE)')
@@ -184,6 +187,17 @@ def main(argv=None):
     beta_score = args.beta
     itr = 0
     step_no = 0
+    if (args.checkpoint or args.resume) and sharded:
+        raise Exception("--checkpoint / --resume are single-GPU features")
+    if args.resume:
+        z = np.load(args.resume)
+        if int(z["n"]) != n or int(z["d"]) != d_pad or int(z["num_layers"]) != args.num_layers:
+            raise Exception(f"{args.resume} was written for N={int(z['n'])}, d={int(z['d'])}, L={int(z['num_layers'])}")
+        engine.load_state_dict(z)
+        itr, step_no, beta_score = int(z["epoch"]), int(z["step"]), float(z["beta"])
+        torch.set_rng_state(torch.from_numpy(z["torch_rng"].copy()))     # the sampler continues its permutation stream
+        engine.forward()                                     # the embeddings a finished run writes come from a forward
+        print(f"resumed from {args.resume}: {itr} epochs done, beta {beta_score}")
     while itr < args.epochs:                                  # train.py:151
         start_time = time.time()
         if replay is not None:
@@ -209,6 +223,12 @@ def main(argv=None):
             off += b
             step_no += 1
         itr += 1
+        if args.checkpoint:
+            sd = engine.state_dict()
+            tmp = args.checkpoint + ".tmp.npz"
+            np.savez(tmp, epoch=itr, beta=float(beta_score), n=n, d=d_pad, num_layers=args.num_layers,
+                     torch_rng=torch.get_rng_state().numpy(), **sd)
+            os.replace(tmp, args.checkpoint)
         if args.log_loss:
             print(f"iter {itr} loss {float(engine.loss.item()):.8f} time {time.time() - start_time:.4f}s")
         else:

@@ -235,9 +235,12 @@ int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *
 /* layer activations for parity tests: which 0 AX, 1 AM, 2 P of layer `layer` (0-based) */
 const float *gss_plan_activation(const gss_plan *p, int layer, int which);
 size_t gss_plan_device_bytes(const gss_plan *p);
-/* set the 1-based Adam step counter (resume) / read it */
+/* set the 1-based Adam step counter (resume; also marks every buffer derived from the weights stale) / read it */
 void gss_plan_set_step(gss_plan *p, int32_t step);
 int32_t gss_plan_get_step(const gss_plan *p);
+/* checkpoint / resume: device pointer of Adam's exp_avg (moment 0) or exp_avg_sq (moment 1) of tensor 0..3 =
+ * W1, b1, W2, b2 (same shapes as the parameters); NULL on a bad argument */
+float *gss_plan_adam_buffer(gss_plan *p, int32_t moment, int32_t tensor);
 /* Per-kernel-class timing with HIP events recorded on the caller's stream around every launch of a
  * plan call (bench.py's live roofline measurement).  gss_plan_profile_read synchronises the stream, returns
  * the accumulated milliseconds and launch counts per class (arrays of GSS_PROF_CLASSES) and resets them. */
