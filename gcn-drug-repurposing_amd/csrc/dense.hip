@@ -492,15 +492,19 @@ struct WgradArgs {
   int rows_per_slice;
 };
 
-__global__ __launch_bounds__(64 * kWgWaves) void wgrad_tn_kernel(WgradArgs g) {
+// Two problems may share one launch (grid.y = ns0 + slices of the second): the top layer's batch-row gradient is 64
+// latency-bound workgroups on its own (10 us) and rides along with a full-N launch for free.
+__global__ __launch_bounds__(64 * kWgWaves) void wgrad_tn_kernel(WgradArgs g0, WgradArgs g1, int ns0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bool second = (int)blockIdx.y >= ns0;
+  const WgradArgs &g = second ? g1 : g0;
   float4 *red = reinterpret_cast<float4 *>(smem);  // [4 slots][16 tiles][64 lanes] float4
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int fi = lane & 15, q = lane >> 4;
   const int tiles_k = (2 * g.d) / 64;
   const int G = blockIdx.x / tiles_k, H = blockIdx.x % tiles_k;
-  const int slice = blockIdx.y;
+  const int slice = second ? (int)blockIdx.y - ns0 : (int)blockIdx.y;
   const int r0 = slice * g.rows_per_slice;
   const int r1 = min(g.n, r0 + g.rows_per_slice);
   const int dh = g.d / 64;
@@ -744,12 +748,39 @@ int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const 
   }
   if (d % 64 == 0) {
     const int tiles = (d / 64) * (2 * d / 64);
-    hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns), dim3(64 * kWgWaves), 4 * 16 * 64 * sizeof(float4), st, g);
+    hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns), dim3(64 * kWgWaves), 4 * 16 * 64 * sizeof(float4), st, g, g, ns);
     GSS_LAUNCH_CHECK("wgrad_tn_kernel");
   } else {
     hipLaunchKernelGGL(wgrad_simple_kernel, dim3(ceil_div((int64_t)d * 2 * d + d, 256), ns), dim3(256), 0, st, g);
     GSS_LAUNCH_CHECK("wgrad_simple_kernel");
   }
+  return GSS_OK;
+}
+
+// the same for two problems in ONE launch: problem 0 into slices [slice0_0, ...), problem 1 into [slice0_1, ...).
+// Falls back to two launches when the MFMA kernel does not apply.
+int wgrad_partial_pair(int32_t d, int32_t n0, const float *dp0, const float *ax0, const float *am0, const int32_t *rows0, int slice0_0,
+                       int32_t n1, const float *dp1, const float *ax1, const float *am1, const int32_t *rows1, int slice0_1, void *ws,
+                       int total_slices, int *ns0_out, int *ns1_out, void *stream) {
+  if (d % 64 != 0 || n0 <= 0 || n1 <= 0) {
+    if (int rc = wgrad_partial(n0, d, dp0, ax0, am0, rows0, ws, total_slices, slice0_0, ns0_out, stream)) return rc;
+    return wgrad_partial(n1, d, dp1, ax1, am1, rows1, ws, total_slices, slice0_1, ns1_out, stream);
+  }
+  GSS_REQUIRE(dp0 && ax0 && am0 && dp1 && ax1 && am1 && ws && ns0_out && ns1_out, "wgrad_partial_pair: null operand");
+  int ns0, rps0, ns1, rps1;
+  wgrad_geometry(n0, d, ns0, rps0);
+  wgrad_geometry(n1, d, ns1, rps1);
+  GSS_REQUIRE(slice0_0 >= 0 && slice0_0 + ns0 <= total_slices && slice0_1 >= 0 && slice0_1 + ns1 <= total_slices,
+              "wgrad_partial_pair: slices exceed %d", total_slices);
+  *ns0_out = ns0;
+  *ns1_out = ns1;
+  float *base_w = (float *)ws, *base_b = (float *)ws + (size_t)total_slices * d * 2 * d;
+  WgradArgs g0{n0, d, dp0, ax0, am0, rows0, base_w + (size_t)slice0_0 * d * 2 * d, base_b + (size_t)slice0_0 * d, rps0};
+  WgradArgs g1{n1, d, dp1, ax1, am1, rows1, base_w + (size_t)slice0_1 * d * 2 * d, base_b + (size_t)slice0_1 * d, rps1};
+  const int tiles = (d / 64) * (2 * d / 64);
+  hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns0 + ns1), dim3(64 * kWgWaves), 4 * 16 * 64 * sizeof(float4), as_stream(stream), g0, g1,
+                     ns0);
+  GSS_LAUNCH_CHECK("wgrad_tn_kernel");
   return GSS_OK;
 }
 

@@ -37,6 +37,9 @@ int dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, con
                      float *gw1, float *gw2, float *gb, float *gb2, int accumulate, void *ws, void *stream);
 int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const float *am, const int32_t *rows, void *ws,
                   int total_slices, int slice0, int *nslices_out, void *stream);
+int wgrad_partial_pair(int32_t d, int32_t n0, const float *dp0, const float *ax0, const float *am0, const int32_t *rows0, int slice0_0,
+                       int32_t n1, const float *dp1, const float *ax1, const float *am1, const int32_t *rows1, int slice0_1, void *ws,
+                       int total_slices, int *ns0_out, int *ns1_out, void *stream);
 int wgrad_reduce(int32_t d, void *ws, int total_slices, int nslices, float *gw1, float *gw2, float *gb, float *gb2, int accumulate,
                  void *stream);
 int wgrad_slices(int32_t n, int32_t d);

@@ -350,7 +350,14 @@ static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const 
   }
   // every layer's partial slabs go to consecutive slices of one buffer; one fixed-order reduce at the end
   int wg_used = 0, wg_n = 0;
-  {
+  // gss_plan_step with L > 1: the top layer's batch-row weight gradient (64 latency-bound workgroups, its inputs stay
+  // untouched until the end of the step) is postponed and shares the launch of the next layer's full-N one.  Its
+  // partial slabs keep their place (slices [0, wg_top)), so the fixed-order reduce adds the same numbers in the same order.
+  const bool merge_top = deferred_slices && L > 1;
+  const int wg_top = wgrad_slices(b, D.d);
+  if (merge_top) {
+    wg_used = wg_top;
+  } else {
     PROF(GSS_PROF_WGRAD_BATCH);
     if (int rc = wgrad_partial(b, D.d, p->dp_b, p->ax[L - 1], p->am[L - 1], idx, p->wgrad_ws, p->wg_total, wg_used, &wg_n, stream))
       return rc;
@@ -405,8 +412,15 @@ static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const 
       }
       {
         PROF(GSS_PROF_WGRAD);
-        if (int rc = wgrad_partial(D.n, D.d, p->dp, p->ax[lp], p->am[lp], nullptr, p->wgrad_ws, p->wg_total, wg_used, &wg_n, stream))
-          return rc;
+        if (merge_top && lp == L - 2) {
+          int n_top = 0;
+          if (int rc = wgrad_partial_pair(D.d, D.n, p->dp, p->ax[lp], p->am[lp], nullptr, wg_used, b, p->dp_b, p->ax[L - 1], p->am[L - 1], idx, 0,
+                                          p->wgrad_ws, p->wg_total, &wg_n, &n_top, stream))
+            return rc;
+        } else {
+          if (int rc = wgrad_partial(D.n, D.d, p->dp, p->ax[lp], p->am[lp], nullptr, p->wgrad_ws, p->wg_total, wg_used, &wg_n, stream))
+            return rc;
+        }
         wg_used += wg_n;
       }
       if (lp >= 1) {
