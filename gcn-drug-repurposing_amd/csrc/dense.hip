@@ -6,9 +6,9 @@
 //       backward : [g_ax | g_am] = dP . [W1 ; W2]  using pre-transposed weights
 //   wgrad_tn_kernel  dW[f][k] = sum_n dP[n][f] * Z[n][k]        (reduction over the node dimension)
 //
-// MFMA: v_mfma_f32_16x16x4_f32 (exact fp32, 256 FLOP/clk/CU).  Operands are loaded as float4 per
-// lane straight from L1/L2 -- at the fp32 MFMA rate (32 cycles per instruction) one 16-B load per 4
-// MFMAs per lane is far below the L1 rate, so no LDS staging is needed.  The float4's four elements
+// MFMA: v_mfma_f32_16x16x4_f32 (exact fp32, 256 FLOP/clk/CU).  gemm_nt_kernel (gemm_variant 1, kept for A/B)
+// loads its operands as float4 per lane straight from L1/L2; the default is the LDS-DMA staged
+// gemm_nt_lds_kernel further down, which cuts the L2->L1 traffic sixfold.  The float4's four elements
 // feed four consecutive k-steps: a k-chunk of 16 is consumed in the order k = kc + 4*(lane>>4) + e,
 // a permutation of the reduction order that both operands share.
 // The operands are swapped (A = weights, B = node rows) so that each lane ends up with 4 consecutive
@@ -192,8 +192,8 @@ __device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&ac
 // operands arrive by LDS-DMA (global_load_lds_dwordx4): one wave instruction moves one MFMA fragment block
 // -- 16 rows x 64 B = 1 KB -- and writes it lane-linear (lane l's 16 B at base + 16 l).  The consuming lane
 // has the same (row = l & 15, k = 4 (l >> 4)) role as the staging lane, so a fragment is read back with one
-// conflict-free ds_read_b128 at base + 16 l.  Two LDS buffers; the DMA of chunk c+1 is in flight under the
-// 8 NT MFMAs of chunk c; one barrier per chunk.  Compared with fetching fragments from L1/L2 per wave (the
+// conflict-free ds_read_b128 at base + 16 l.  NBUF = 4 LDS buffers; the DMA runs 3 chunks ahead of the
+// MFMAs (counted vmcnt); one barrier per chunk.  Compared with fetching fragments from L1/L2 per wave (the
 // kernel above, kept for A/B) this cuts L2->L1 traffic from ~48 to ~8 B/clk/CU.
 // LDS-DMA in inline asm: hipcc must not see these loads, otherwise it drains them (vmcnt(0)) before every
 // ds_read / barrier and the multi-chunk pipeline collapses (cdna guide section 5 'Pipelining across barriers').
@@ -836,6 +836,17 @@ int wgrad_slices(int32_t n, int32_t d) {
   int ns, rps;
   wgrad_geometry(n, d, ns, rps);
   return ns;
+}
+
+// wgrad_geometry is not monotone in n (rows_per_slice is rounded up to 32, so a slightly smaller n can need more
+// slices: d = 128, n = 1034 -> 17, n = 1008 -> 32).  Upper bound over every n in [1, n_max]: nslices <= want <=
+// min(ceil(256 / tiles), ceil(n_max / 32)).  Plans size the batch-row region with this so that the short last
+// batch of an epoch always fits.
+int wgrad_slices_max(int32_t n_max, int32_t d) {
+  const int tiles = (d % 64 == 0) ? (d / 64) * (2 * d / 64) : ceil_div((int64_t)d * 2 * d + d, 256);
+  const int cap = n_max > 0 ? ceil_div(n_max, 32) : 1;
+  const int want = ceil_div(256, tiles);
+  return want < cap ? (want < 1 ? 1 : want) : cap;
 }
 
 int dense_bwd_weight(int32_t n, int32_t d, const float *dp, const float *ax, const float *am, const int32_t *rows,

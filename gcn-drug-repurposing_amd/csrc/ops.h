@@ -43,6 +43,7 @@ int wgrad_partial_pair(int32_t d, int32_t n0, const float *dp0, const float *ax0
 int wgrad_reduce(int32_t d, void *ws, int total_slices, int nslices, float *gw1, float *gw2, float *gb, float *gb2, int accumulate,
                  void *stream);
 int wgrad_slices(int32_t n, int32_t d);
+int wgrad_slices_max(int32_t n_max, int32_t d);  // bound over every n in [1, n_max]
 int wgrad_reduce_adam(int32_t d, void *ws, int total_slices, int nslices, float *const grad[4], float *const param[4],
                       float *const m[4], float *const v[4], int32_t step, float lr, float beta1, float beta2, float eps, float *w1t,
                       float *w2t, int32_t *pos_clear, const int32_t *idx, int32_t b, void *stream);

@@ -1,6 +1,6 @@
 // plan.hip -- one training replica: owns every activation / gradient buffer and enqueues a whole
 // iteration of train.py:155-184 (forward, gss_loss, backward, Adam) from a single host call, so
-// the ~25 kernels of a step are launched back to back from C++ with no Python in between.
+// the kernels of a step (11 launches at L = 2) are launched back to back from C++ with no Python in between.
 //
 // Layer l (0-based) keeps x_l (input), AX_l, AM_l, P_l for the backward pass (model.py:163-173).
 // The backward pass exploits that dLoss/dE is non-zero only on the B batch rows: normalise-bwd,
@@ -139,7 +139,7 @@ void carve(gss_plan *p, Carver &c) {
     p->adam_v[k] = c.take<float>(cnt[k]);
   }
   p->loss_ws = c.take<char>(loss_workspace_bytes(D.max_batch, D.d));
-  const int wg_total = wgrad_slices(D.max_batch, D.d) + (L - 1) * wgrad_slices(D.n, D.d);
+  const int wg_total = wgrad_slices_max(D.max_batch, D.d) + (L - 1) * wgrad_slices(D.n, D.d);
   p->wgrad_ws = c.take<char>(sizeof(float) * (size_t)wg_total * ((size_t)D.d * 2 * D.d + D.d));
 }
 }  // namespace
@@ -177,7 +177,7 @@ int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a,
   p->step = 0;
   p->layer1_valid = false;
   p->wt_valid = false;
-  p->wg_total = wgrad_slices(desc->max_batch, desc->d) + (desc->num_layers - 1) * wgrad_slices(desc->n, desc->d);
+  p->wg_total = wgrad_slices_max(desc->max_batch, desc->d) + (desc->num_layers - 1) * wgrad_slices(desc->n, desc->d);
   p->prof_on = false;
   p->ev_used = 0;
   for (int k = 0; k < GSS_PROF_CLASSES; ++k) {

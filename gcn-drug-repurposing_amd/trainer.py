@@ -111,7 +111,11 @@ def main(argv=None):
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29519")
+            if "MASTER_PORT" not in os.environ:          # single forced-sharded rank: any free port, so concurrent runs do not collide
+                import socket
+                with socket.socket() as s_:
+                    s_.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.seed:                       # seed 0 / None leaves the RNGs unseeded, like train.py:74-76
@@ -181,7 +185,16 @@ def main(argv=None):
     if args.batch_file:
         z = np.load(args.batch_file)
         offs = np.concatenate([[0], np.cumsum(z['batch_sizes'])])
-        replay = [z['batches'][offs[i]:offs[i + 1]] for i in range(len(z['batch_sizes']))]
+        replay = [np.asarray(z['batches'][offs[i]:offs[i + 1]], dtype=np.int64) for i in range(len(z['batch_sizes']))]
+        # replayed ids index device buffers directly: the kernels assume what the reference's sampler guarantees
+        # (a batch is a slice of a permutation of 0..N-1, method/dataset.py:25-28), so check it on the host
+        for i, b in enumerate(replay):
+            if b.size == 0 or b.size > min(bsz, n):
+                raise Exception(f"{args.batch_file}: batch {i} has {b.size} ids, expected 1..{min(bsz, n)} (--batch-size)")
+            if b.min() < 0 or b.max() >= n:
+                raise Exception(f"{args.batch_file}: batch {i} holds node ids outside [0, {n})")
+            if np.unique(b).size != b.size:
+                raise Exception(f"{args.batch_file}: batch {i} repeats a node id (batches must be duplicate-free)")
     steps_per_epoch = (n + bsz - 1) // bsz
 
     beta_score = args.beta
@@ -189,10 +202,21 @@ def main(argv=None):
     step_no = 0
     if (args.checkpoint or args.resume) and sharded:
         raise Exception("--checkpoint / --resume are single-GPU features")
+    # what a resumed run must share with the run that wrote the checkpoint to be its continuation
+    hyper = {"lr": args.lr, "alpha": args.alpha, "layer_decay": args.layer_decay, "batch_size": float(bsz),
+             "seed": float(args.seed or 0), "init_weights": args.init_weights}
     if args.resume:
         z = np.load(args.resume)
         if int(z["n"]) != n or int(z["d"]) != d_pad or int(z["num_layers"]) != args.num_layers:
             raise Exception(f"{args.resume} was written for N={int(z['n'])}, d={int(z['d'])}, L={int(z['num_layers'])}")
+        hyper_saved = {k: float(z["hp_" + k]) for k in hyper} if "hp_lr" in z.files else None
+        if hyper_saved is not None and any(abs(hyper_saved[k] - hyper[k]) > 1e-12 * max(1.0, abs(hyper[k])) for k in hyper):
+            diff = {k: (hyper_saved[k], hyper[k]) for k in hyper if hyper_saved[k] != hyper[k]}
+            raise Exception(f"{args.resume} was written with different hyper-parameters (saved, now): {diff}")
+        if int(z["epoch"]) >= args.epochs:
+            raise Exception(f"{args.resume} already holds {int(z['epoch'])} epochs, --epochs {args.epochs} leaves nothing to train "
+                            f"(a finished run writes the embeddings from BEFORE its last optimizer step; they cannot be rebuilt "
+                            f"from the post-step state)")
         engine.load_state_dict(z)
         itr, step_no, beta_score = int(z["epoch"]), int(z["step"]), float(z["beta"])
         torch.set_rng_state(torch.from_numpy(z["torch_rng"].copy()))     # the sampler continues its permutation stream
@@ -227,7 +251,7 @@ def main(argv=None):
             sd = engine.state_dict()
             tmp = args.checkpoint + ".tmp.npz"
             np.savez(tmp, epoch=itr, beta=float(beta_score), n=n, d=d_pad, num_layers=args.num_layers,
-                     torch_rng=torch.get_rng_state().numpy(), **sd)
+                     torch_rng=torch.get_rng_state().numpy(), **{"hp_" + k: v for k, v in hyper.items()}, **sd)
             os.replace(tmp, args.checkpoint)
         if args.log_loss:
             print(f"iter {itr} loss {float(engine.loss.item()):.8f} time {time.time() - start_time:.4f}s")

@@ -45,3 +45,55 @@ def test_csr_roundtrip_through_the_trainer_reader(tmp_path):
     assert abs(adj - adj2).max() < 1e-15
     # asymmetric weights: this is why the backward pass needs A_hat^T
     assert abs(adj - adj.T).max() > 0.1
+
+
+def test_whole_graph_standin_equals_the_msi_loader_on_its_own_tables(tmp_path):
+    """SURVEY 8(d): the stand-in = the four real MSI layers + a synthetic PPI layer.  synth builds it vectorised;
+    here the same five tables go through the MsiGraph loader (the networkx-order restatement checked above against
+    the reference's MSI class): node order, node types and every edge weight must agree, at full size."""
+    from gcn_drug_repurposing_amd import synth
+    from gcn_drug_repurposing_amd.msi import MsiGraph
+    tables = synth.standin_tables(seed=1)
+    files = {}
+    for name, rows in tables.items():
+        files[name] = str(tmp_path / (name + ".tsv"))
+        with open(files[name], "w") as f:
+            f.write("node_1\tnode_2\n")
+            f.writelines(f"{u}\t{v}\n" for u, v in rows)
+    g = MsiGraph().load(files).weight_graph()
+    adj_ref, names_ref, types_ref = g.to_csr()
+    adj, ntype, names = synth.whole_graph_standin(seed=1)
+    assert adj.shape == (29960, 29960) and adj.nnz == 958068          # SURVEY 8-a2: 479,034 undirected edges
+    assert names == names_ref
+    code = {"drug": 0, "indication": 1, "protein": 2, "functional_pathway": 3}
+    assert [code[t] for t in types_ref] == ntype.tolist()
+    assert np.bincount(ntype).tolist() == [1661, 841, 17660, 9798]    # 840 indications + NodeCovid
+    assert (adj != adj_ref).nnz == 0 or abs(adj - adj_ref).max() < 1e-15
+    # config 3: + 324 NodeCovid <-> pathway edge pairs of weight 3/353 (predict_drug.py:182-196)
+    R = synth.real_layers()
+    g.add_covid_pathway_edges([R["names_pathway"][i] for i in R["covid_pathway_idx"]] + [f"absent{i}" for i in range(353 - 324)])
+    adj3_ref, _, _ = g.to_csr()
+    adj3, _, _ = synth.whole_graph_standin(seed=1, pathway_edges=True)
+    assert adj3.nnz == 958068 + 2 * 324 and abs(adj3 - adj3_ref).max() < 1e-15
+    covid = names.index("NodeCovid")
+    assert abs(adj3[covid].sum() - (4.396695660380823 + 324 * 3.0 / 353.0)) < 1e-12
+
+
+def test_real_layer_fixture_is_the_reference_tables_verbatim():
+    """build container only: data/msi_real_layers.npz holds exactly the node_1/node_2 columns of the shipped tables"""
+    import csv
+    import pytest
+    ref = "/root/reference/data"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present (GPU box)")
+    from gcn_drug_repurposing_amd import synth
+    R = synth.real_layers()
+    kinds = {"drug_to_protein": ("drug", "protein"), "indication_to_protein": ("indication", "protein"),
+             "covid_to_protein": ("indication", "protein"), "protein_to_functional_pathway": ("protein", "pathway"),
+             "functional_pathway_to_functional_pathway": ("pathway", "pathway")}
+    for stem, (t1, t2) in kinds.items():
+        with open(os.path.join(ref, stem + ".tsv"), newline="") as f:
+            rows = list(csv.reader(f, delimiter="\t"))[1:]
+        got = [(R["names_" + t1][a], R["names_" + t2][b]) for a, b in zip(R[stem + "_u"], R[stem + "_v"])]
+        assert got == [(r[0], r[1]) for r in rows], stem
+    assert int(R["covid_pathway_total"]) == 353 and len(R["covid_pathway_idx"]) == 324
