@@ -9,7 +9,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgssgcn.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -31,6 +31,10 @@ class PprDesc(C.Structure):
                 + [(k, C.c_void_p) for k in ("ovr_col", "ovr_row", "ovr_ratio", "zero_ptr", "zero_ovr")]
                 + [("n_sel", C.c_int64)]
                 + [(k, C.c_void_p) for k in ("sel_col", "sel_row", "sel_val", "keep_ptr", "keep_row", "keep_val")])
+
+
+class ShardDesc(C.Structure):
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("max_rows", C.c_int32), ("h_bounds", C.c_void_p)]
 
 
 class PlanIO(C.Structure):
@@ -60,10 +64,21 @@ SIGNATURES = {
     "gss_rownorm_elu_bwd": (C.c_int, [_I32, _P, _P, _I32, _P, _P, _P, _F, _P, _P, _P]),
     "gss_scatter_add_rows": (C.c_int, [_I32, _P, _P, _I32, _P, _P]),
     "gss_shard_batch_maps": (C.c_int, [_P, _I32, _I32, _I32, _P, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "gss_comm_unique_id": (C.c_int, [_P]),
+    "gss_comm_create_rccl": (C.c_int, [C.POINTER(_P), _I32, _I32, _P]),
+    "gss_comm_create_local": (C.c_int, [C.POINTER(_P), _I32]),
+    "gss_comm_destroy": (None, [_P]),
+    "gss_comm_world": (_I32, [_P]),
+    "gss_comm_rank": (_I32, [_P]),
+    "gss_allgather_rows": (C.c_int, [_P, _I32, _I32, _P, _P, _P]),
+    "gss_allgather_bytes": (C.c_int, [_P, _P, _P, _SZ, _P]),
+    "gss_allreduce_sum": (C.c_int, [_P, _P, _I64, _P]),
     "gss_adam_step": (C.c_int, [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P, _I32, _P]),
     "gss_percentile": (C.c_int, [_I32, _I32, _P, _D, C.POINTER(_F), _P]),
     "gss_knn_topk": (C.c_int, [_I32, _I32, _P, _I32, _P, _P, _P]),
     "gss_plan_create": (C.c_int, [C.POINTER(_P), C.POINTER(PlanDesc), _P, _P, C.POINTER(PlanIO)]),
+    "gss_plan_create_sharded": (C.c_int, [C.POINTER(_P), C.POINTER(PlanDesc), C.POINTER(ShardDesc), _P, _P, _P, C.POINTER(PlanIO)]),
+    "gss_plan_gather_embeddings": (C.c_int, [_P, _P, _P]),
     "gss_plan_destroy": (None, [_P]),
     "gss_plan_forward": (C.c_int, [_P, _P]),
     "gss_plan_loss_backward": (C.c_int, [_P, _P, _I32, _F, _P]),
@@ -88,7 +103,7 @@ SIGNATURES = {
 
 
 PROF_CLASSES = ("spmm_fwd_hadamard", "spmm_fwd", "spmm_bwd1", "spmm_bwd2", "dense_fwd", "dgrad", "wgrad", "wgrad_batch",
-                "loss", "rownorm", "elementwise", "adam")
+                "loss", "rownorm", "elementwise", "adam", "comm")
 
 
 def build(verbose: bool = False) -> str:

@@ -1,0 +1,217 @@
+// comm.hip -- the collectives of the node-range sharded trainer.
+//
+// The reference is single-process, single-device (train.py:68,118-122); these are the exchange points a
+// 1-D node-range sharding of its training step needs:
+//   C1  all-gather of the [N][d] operand of every SpMM hop (model.py:163,169 and their autograd)
+//   C2  all-reduce (sum) of the 2 (d^2 + d) weight-gradient floats (train.py:183)
+//   C3  all-reduce of the B batch rows of the embeddings / of their input gradients (model.py:216-217)
+//
+// Two backends behind one interface:
+//   * RCCL over xGMI: one process per GPU, communicator created from a 128-byte unique id that the host
+//     distributes (torch.distributed store, MPI, a file ...).  Collectives are enqueued on the caller's stream.
+//   * local: `world` ranks that are THREADS of one process (each with its own stream, possibly all on one
+//     GPU).  Exchanges are device-to-device copies fenced by a timed host barrier.  It exists so that the
+//     sharded plan can be run and checked at world 2..8 on a box with a single GPU; it is not a fast path.
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "ops.h"
+
+namespace gss {
+
+#define GSS_NCCL(call)                                                                                    \
+  do {                                                                                                    \
+    ncclResult_t r_ = (call);                                                                             \
+    if (r_ != ncclSuccess) return ::gss::fail(GSS_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r_)); \
+  } while (0)
+
+// ---- RCCL ------------------------------------------------------------------------------------------------
+struct RcclComm final : gss_comm {
+  ncclComm_t comm = nullptr;
+  ~RcclComm() override {
+    if (comm) (void)ncclCommDestroy(comm);
+  }
+  int all_gather(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) override {
+    // in place when send == recv + rank * bytes_per_rank (RCCL detects it)
+    GSS_NCCL(ncclAllGather(send, recv, bytes_per_rank, ncclInt8, comm, st));
+    return GSS_OK;
+  }
+  int all_reduce_sum(float *const *bufs, const size_t *counts, int nbuf, hipStream_t st) override {
+    // several tensors = one fused RCCL operation (one launch)
+    if (nbuf > 1) GSS_NCCL(ncclGroupStart());
+    for (int k = 0; k < nbuf; ++k) {
+      const ncclResult_t r = ncclAllReduce(bufs[k], bufs[k], counts[k], ncclFloat, ncclSum, comm, st);
+      if (r != ncclSuccess) {
+        if (nbuf > 1) (void)ncclGroupEnd();
+        return fail(GSS_EHIP, "ncclAllReduce -> %s", ncclGetErrorString(r));
+      }
+    }
+    if (nbuf > 1) GSS_NCCL(ncclGroupEnd());
+    return GSS_OK;
+  }
+};
+
+// ---- local (threads of one process) --------------------------------------------------------------------------
+struct LocalShared {
+  int world;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t generation = 0;
+  bool broken = false;
+  std::vector<const void *> src;
+  explicit LocalShared(int w) : world(w), src((size_t)w, nullptr) {}
+  // timed barrier: a rank that failed elsewhere must not hang the others forever
+  int wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (broken) return fail(GSS_EHIP, "local comm: a peer rank failed or timed out");
+    const uint64_t gen = generation;
+    if (++arrived == world) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+      return GSS_OK;
+    }
+    if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return generation != gen || broken; })) {
+      broken = true;
+      cv.notify_all();
+      return fail(GSS_EHIP, "local comm: barrier timed out after 120 s (a peer rank never arrived)");
+    }
+    if (broken) return fail(GSS_EHIP, "local comm: a peer rank failed or timed out");
+    return GSS_OK;
+  }
+};
+
+__global__ __launch_bounds__(256) void local_sum_kernel(size_t count, int world, const float *__restrict__ tmp, float *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float s = tmp[i];
+  for (int r = 1; r < world; ++r) s += tmp[(size_t)r * count + i];  // rank order: the same bits on every rank
+  out[i] = s;
+}
+
+struct LocalComm final : gss_comm {
+  std::shared_ptr<LocalShared> sh;
+  float *tmp = nullptr;
+  size_t tmp_floats = 0;
+  ~LocalComm() override {
+    if (tmp) (void)hipFree(tmp);
+  }
+  int all_gather(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) override {
+    GSS_HIP(hipStreamSynchronize(st));  // my rows are complete before a peer copies them
+    sh->src[(size_t)rank] = send;
+    if (int rc = sh->wait()) return rc;
+    for (int r = 0; r < world; ++r) {
+      char *dst = (char *)recv + (size_t)r * bytes_per_rank;
+      if ((const void *)dst != sh->src[(size_t)r]) GSS_HIP(hipMemcpyAsync(dst, sh->src[(size_t)r], bytes_per_rank, hipMemcpyDeviceToDevice, st));
+    }
+    GSS_HIP(hipStreamSynchronize(st));
+    return sh->wait();  // nobody overwrites its send buffer while a peer still reads it
+  }
+  int all_reduce_sum(float *const *bufs, const size_t *counts, int nbuf, hipStream_t st) override {
+    for (int k = 0; k < nbuf; ++k) {
+      const size_t count = counts[k];
+      if (tmp_floats < count * (size_t)world) {
+        if (tmp) GSS_HIP(hipFree(tmp));
+        tmp = nullptr;
+        GSS_HIP(hipMalloc((void **)&tmp, sizeof(float) * count * (size_t)world));
+        tmp_floats = count * (size_t)world;
+      }
+      GSS_HIP(hipStreamSynchronize(st));
+      sh->src[(size_t)rank] = bufs[k];
+      if (int rc = sh->wait()) return rc;
+      for (int r = 0; r < world; ++r)
+        GSS_HIP(hipMemcpyAsync(tmp + (size_t)r * count, sh->src[(size_t)r], sizeof(float) * count, hipMemcpyDeviceToDevice, st));
+      GSS_HIP(hipStreamSynchronize(st));
+      if (int rc = sh->wait()) return rc;  // every rank holds its copy of all contributions: buffers may change now
+      if (count) {
+        hipLaunchKernelGGL(local_sum_kernel, dim3(ceil_div((int64_t)count, 256)), dim3(256), 0, st, count, world, tmp, bufs[k]);
+        GSS_LAUNCH_CHECK("local_sum_kernel");
+      }
+    }
+    return GSS_OK;
+  }
+};
+
+}  // namespace gss
+
+using namespace gss;
+
+extern "C" {
+
+int gss_comm_unique_id(void *id_out) {
+  GSS_REQUIRE(id_out, "comm_unique_id: null pointer");
+  static_assert(sizeof(ncclUniqueId) == GSS_COMM_ID_BYTES, "GSS_COMM_ID_BYTES must match ncclUniqueId");
+  ncclUniqueId id;
+  GSS_NCCL(ncclGetUniqueId(&id));
+  memcpy(id_out, &id, sizeof(id));
+  return GSS_OK;
+}
+
+int gss_comm_create_rccl(gss_comm **out, int32_t world, int32_t rank, const void *id) {
+  GSS_REQUIRE(out && id && world >= 1 && rank >= 0 && rank < world, "comm_create_rccl: bad argument (world=%d rank=%d)", world, rank);
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  RcclComm *c = new RcclComm();
+  c->world = world;
+  c->rank = rank;
+  const ncclResult_t r = ncclCommInitRank(&c->comm, world, uid, rank);  // binds to the calling thread's current device
+  if (r != ncclSuccess) {
+    c->comm = nullptr;
+    delete c;
+    return fail(GSS_EHIP, "ncclCommInitRank(world=%d, rank=%d) -> %s", world, rank, ncclGetErrorString(r));
+  }
+  *out = c;
+  return GSS_OK;
+}
+
+int gss_comm_create_local(gss_comm **out, int32_t world) {
+  GSS_REQUIRE(out && world >= 1 && world <= 64, "comm_create_local: bad argument (world=%d)", world);
+  auto sh = std::make_shared<LocalShared>(world);
+  for (int r = 0; r < world; ++r) {
+    LocalComm *c = new LocalComm();
+    c->world = world;
+    c->rank = r;
+    c->sh = sh;
+    out[r] = c;
+  }
+  return GSS_OK;
+}
+
+void gss_comm_destroy(gss_comm *c) { delete c; }
+int32_t gss_comm_world(const gss_comm *c) { return c ? c->world : 0; }
+int32_t gss_comm_rank(const gss_comm *c) { return c ? c->rank : -1; }
+
+int gss_allgather_rows(gss_comm *c, int32_t d, int32_t max_rows, const float *src, float *dst_padded, void *stream) {
+  GSS_REQUIRE(c && src && dst_padded && d > 0 && max_rows >= 0, "allgather_rows: bad argument");
+  if (max_rows == 0) return GSS_OK;
+  const size_t bytes = sizeof(float) * (size_t)max_rows * d;
+  if (c->world == 1) {
+    if (src != dst_padded) GSS_HIP(hipMemcpyAsync(dst_padded, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return GSS_OK;
+  }
+  return c->all_gather(src, dst_padded, bytes, as_stream(stream));
+}
+
+int gss_allgather_bytes(gss_comm *c, const void *src, void *dst, size_t bytes_per_rank, void *stream) {
+  GSS_REQUIRE(c && src && dst, "allgather_bytes: bad argument");
+  if (bytes_per_rank == 0) return GSS_OK;
+  if (c->world == 1) {
+    if (src != dst) GSS_HIP(hipMemcpyAsync(dst, src, bytes_per_rank, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return GSS_OK;
+  }
+  return c->all_gather(src, dst, bytes_per_rank, as_stream(stream));
+}
+
+int gss_allreduce_sum(gss_comm *c, float *buf, int64_t count, void *stream) {
+  GSS_REQUIRE(c && buf && count >= 0, "allreduce_sum: bad argument");
+  if (count == 0 || c->world == 1) return GSS_OK;
+  const size_t cnt = (size_t)count;
+  return c->all_reduce_sum(&buf, &cnt, 1, as_stream(stream));
+}
+}

@@ -80,13 +80,14 @@ __global__ __launch_bounds__(256) void rownorm_elu_bwd_kernel(int b, int d4, int
 }
 
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(int b, int d4, const float *__restrict__ src,
-                                                               const int32_t *__restrict__ rows, float *__restrict__ dst,
-                                                               int32_t *__restrict__ pos_clear) {
+                                                               const int32_t *__restrict__ rows, const float *__restrict__ keep,
+                                                               float *__restrict__ dst, int32_t *__restrict__ pos_clear,
+                                                               const int32_t *__restrict__ pos_ids) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)b * d4) return;
   const int r = (int)(i / d4), f4 = (int)(i % d4);
-  if (rows[r] < 0) return;  // not a row of this shard
-  if (pos_clear && f4 == 0) pos_clear[rows[r]] = -1;
+  if (pos_clear && f4 == 0) pos_clear[pos_ids[r]] = -1;
+  if (rows[r] < 0 || (keep && keep[r] == 0.f)) return;  // not a row of this shard
   float *p = dst + ((size_t)rows[r] * d4 + f4) * 4;
   st4(p, add4(ld4(p), ld4(src + i * 4)));
 }
@@ -107,6 +108,22 @@ __global__ void shard_batch_maps_kernel(const int32_t *__restrict__ idx, int b, 
   while (o + 1 < world && (int64_t)id >= bounds[o + 1]) ++o;
   pos_col[(size_t)o * maxr + (id - (int)bounds[o])] = i;
   if (mine) pos_row[rel] = i;
+}
+
+// per-batch maps of a sharded plan: pid = padded global id (owner * maxr + offset in the owner's range), rloc = the local
+// row clamped into this shard (any owned row where the shard has no say), keep = 1.0 / 0.0 for owned / foreign rows
+__global__ void shard_batch_ids_kernel(const int32_t *__restrict__ idx, int b, int lo, int nl, const int64_t *__restrict__ bounds, int world,
+                                       int maxr, int32_t *__restrict__ pid, int32_t *__restrict__ rloc, float *__restrict__ keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b) return;
+  const int id = idx[i];
+  const int rel = id - lo;
+  const bool mine = rel >= 0 && rel < nl;
+  rloc[i] = min(max(rel, 0), max(nl - 1, 0));
+  keep[i] = mine ? 1.f : 0.f;
+  int o = 0;
+  while (o + 1 < world && (int64_t)id >= bounds[o + 1]) ++o;
+  pid[i] = o * maxr + (id - (int)bounds[o]);
 }
 
 // ---- K10  torch.optim.Adam (single-tensor form of torch/optim/adam.py; train.py:139-141,184) -------
@@ -135,12 +152,16 @@ struct Adam4 {
   int64_t start[5];
   float *wt[4];  // optional transposed copies of the square tensors (the backward GEMM wants [in][out])
   int dim;
+  int32_t *pos_clear;  // optional: reset the batch-position map entries pos_clear[ids[0..b)] for the next step
+  const int32_t *ids;
+  int b;
 };
 
 // all four parameter tensors in one launch (the reference's optimizer.step() is one foreach call)
 __global__ __launch_bounds__(256) void adam4_kernel(Adam4 a, float lr_over_bc1, float inv_sqrt_bc2, float beta1, float beta2,
                                                     float eps) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (a.pos_clear && i < a.b) a.pos_clear[a.ids[i]] = -1;
   if (i >= a.start[4]) return;
   const int k = i < a.start[1] ? 0 : i < a.start[2] ? 1 : i < a.start[3] ? 2 : 3;
   const int64_t j = i - a.start[k];
@@ -226,12 +247,13 @@ int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b,
   return GSS_OK;
 }
 
-int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, int32_t *pos_clear, void *stream) {
+int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, const float *keep, int32_t b, float *dst, int32_t *pos_clear,
+                     const int32_t *pos_ids, void *stream) {
   if (int rc = check_d(d)) return rc;
-  GSS_REQUIRE(b >= 0 && src && rows && dst, "scatter_add_rows: null operand");
+  GSS_REQUIRE(b >= 0 && src && rows && dst && (!pos_clear || pos_ids), "scatter_add_rows: null operand");
   if (b == 0) return GSS_OK;
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(ceil_div((int64_t)b * d / 4, 256)), dim3(256), 0, as_stream(stream), b,
-                     d / 4, src, rows, dst, pos_clear);
+                     d / 4, src, rows, keep, dst, pos_clear, pos_ids);
   GSS_LAUNCH_CHECK("scatter_add_rows_kernel");
   return GSS_OK;
 }
@@ -263,10 +285,23 @@ int adam_step(int64_t count, float *param, const float *grad, float *m, float *v
   return GSS_OK;
 }
 
+int shard_batch_ids(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
+                    int32_t *pid, int32_t *rloc, float *keep, void *stream) {
+  GSS_REQUIRE(b >= 0 && nl >= 0 && world >= 1 && maxr >= 1 && idx && bounds && pid && rloc && keep, "shard_batch_ids: bad argument");
+  if (b == 0) return GSS_OK;
+  hipLaunchKernelGGL(shard_batch_ids_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, as_stream(stream), idx, b, lo, nl, bounds, world, maxr, pid,
+                     rloc, keep);
+  GSS_LAUNCH_CHECK("shard_batch_ids_kernel");
+  return GSS_OK;
+}
+
 int adam_step4(const AdamTensor (&t)[4], int32_t step, float lr, float beta1, float beta2, float eps, float *w1t, float *w2t,
-               int32_t dim, void *stream) {
+               int32_t dim, void *stream, int32_t *pos_clear, const int32_t *ids, int32_t b) {
   GSS_REQUIRE(step >= 1, "adam: step is 1-based");
   Adam4 a;
+  a.pos_clear = pos_clear;
+  a.ids = ids;
+  a.b = pos_clear ? b : 0;
   a.wt[0] = w1t;
   a.wt[1] = nullptr;
   a.wt[2] = w2t;
@@ -281,7 +316,7 @@ int adam_step4(const AdamTensor (&t)[4], int32_t step, float lr, float beta1, fl
   if (a.start[4] == 0) return GSS_OK;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adam4_kernel, dim3(ceil_div(a.start[4], 256)), dim3(256), 0, as_stream(stream), a, (float)((double)lr / bc1),
+  hipLaunchKernelGGL(adam4_kernel, dim3(ceil_div(a.start[4] > a.b ? a.start[4] : (int64_t)a.b, 256)), dim3(256), 0, as_stream(stream), a, (float)((double)lr / bc1),
                      (float)(1.0 / sqrt(bc2)), beta1, beta2, eps);
   GSS_LAUNCH_CHECK("adam4_kernel");
   return GSS_OK;
@@ -306,7 +341,7 @@ int gss_rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_
   return rownorm_elu_bwd(d, de_b, idx, b, e, inv_den, p, c, dx_b, dp_b, nullptr, stream);
 }
 int gss_scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, void *stream) {
-  return scatter_add_rows(d, src, rows, b, dst, nullptr, stream);
+  return scatter_add_rows(d, src, rows, nullptr, b, dst, nullptr, nullptr, stream);
 }
 int gss_shard_batch_maps(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
                          int32_t *rows_all, int32_t *rows_own, float *keep, int32_t *pos_col, int32_t *pos_row, void *stream) {

@@ -32,12 +32,15 @@ struct LossArgs {
 };
 
 // E_B = e[idx] (modules/model.py:216-217) into a contiguous buffer, so the MFMA loop has no index indirection
+// keep != NULL (a shard of a node-range sharded plan): rows this shard does not own are written as zeros, so that
+// the all-reduce over the shards assembles E_B
 __global__ __launch_bounds__(256) void gather_rows_kernel(int b, int d4, const float *__restrict__ e, const int32_t *__restrict__ idx,
-                                                          float *__restrict__ out) {
+                                                          const float *__restrict__ keep, float *__restrict__ out) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)b * d4) return;
   const int r = (int)(i / d4), f4 = (int)(i % d4);
-  st4(out + i * 4, ld4(e + ((size_t)idx[r] * d4 + f4) * 4));
+  const bool mine = !keep || keep[r] != 0.f;
+  st4(out + i * 4, mine ? ld4(e + ((size_t)idx[r] * d4 + f4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
 template <int NG, bool EXACT>  // EXACT: d == 64 NG, no feature masking anywhere
@@ -230,6 +233,7 @@ template <int VPL>
 __global__ __launch_bounds__(256) void loss_finish_bwd_kernel(int b, int d4, int lpr_log2, int js, int nloss,
                                                               const float *__restrict__ de_part, const double *__restrict__ loss_part,
                                                               float alpha, const float *__restrict__ e_b, const int32_t *__restrict__ idx,
+                                                              const int32_t *__restrict__ pos_ids, const float *__restrict__ keep,
                                                               const float *__restrict__ inv_den, const float *__restrict__ p, float c,
                                                               float *__restrict__ dx_b, float *__restrict__ dp_b,
                                                               int32_t *__restrict__ pos_set, float *__restrict__ loss_out) {
@@ -265,8 +269,10 @@ __global__ __launch_bounds__(256) void loss_finish_bwd_kernel(int b, int d4, int
     if (threadIdx.x == 0) loss_out[0] = (float)(-0.5 * (double)alpha * t / ((double)b * (double)b));
   }
   if (!ok) return;
-  if (pos_set && li == 0) pos_set[node] = r;
-  const float inv = inv_den[node];
+  // idx: row of inv_den / p (this shard's local row); pos_ids: the id the batch-position map is keyed by (the same array on
+  // one GPU, the padded global id on a shard); keep[r] == 0: another shard owns the row -> zero gradient here
+  if (pos_set && li == 0) pos_set[pos_ids[r]] = r;
+  const float inv = (!keep || keep[r] != 0.f) ? inv_den[node] : 0.f;
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
     const int f4 = li + k * 64;
@@ -310,8 +316,7 @@ struct LossLaunch {
   float *e_b;
 };
 
-static int loss_main(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha, void *ws,
-                     hipStream_t st, LossLaunch &L) {
+static void loss_layout(int32_t d, int32_t b, void *ws, LossLaunch &L) {
   loss_geometry(b, d, L.ni, L.js, L.nz, L.ng);
   size_t de_bytes = sizeof(float) * (size_t)L.js * b * d;
   de_bytes = (de_bytes + 15) / 16 * 16;
@@ -319,8 +324,18 @@ static int loss_main(int32_t n, int32_t d, const float *e, const int32_t *idx, i
   L.de_part = (float *)ws;
   L.loss_part = (double *)((char *)ws + de_bytes);
   L.e_b = (float *)((char *)ws + de_bytes + lp_bytes);
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div((int64_t)b * d / 4, 256)), dim3(256), 0, st, b, d / 4, e, idx, L.e_b);
+}
+
+// stage 1: E_B = e[idx] (zero where keep == 0) into the workspace; returns where it is
+static int loss_gather(int32_t d, const float *e, const int32_t *idx, const float *keep, int32_t b, void *ws, hipStream_t st, LossLaunch &L) {
+  loss_layout(d, b, ws, L);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div((int64_t)b * d / 4, 256)), dim3(256), 0, st, b, d / 4, e, idx, keep, L.e_b);
   GSS_LAUNCH_CHECK("gather_rows_kernel");
+  return GSS_OK;
+}
+
+// stage 2: the fused S / G / dE sweep over the gathered rows
+static int loss_sweep(int32_t d, int32_t b, float beta, float alpha, hipStream_t st, LossLaunch &L) {
   LossArgs g{d, b, L.js, L.e_b, beta, alpha, L.de_part, L.loss_part};
   dim3 grid(L.ni, L.js, L.nz), block(64 * kLossWaves);
   const size_t lds = (size_t)2 * L.ng * 4 * 64 * sizeof(float4);
@@ -350,7 +365,8 @@ int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32
   GSS_REQUIRE(n > 0 && b > 0 && e && idx && loss_out && de_b && ws, "loss_fwd_bwd: null operand or empty batch");
   hipStream_t st = as_stream(stream);
   LossLaunch L;
-  if (int rc = loss_main(n, d, e, idx, b, beta, alpha, ws, st, L)) return rc;
+  if (int rc = loss_gather(d, e, idx, nullptr, b, ws, st, L)) return rc;
+  if (int rc = loss_sweep(d, b, beta, alpha, st, L)) return rc;
   const int nb = ceil_div((int64_t)b * d / 4, 256);
   hipLaunchKernelGGL(loss_finish_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, b, d, L.js, L.ni * L.js, L.de_part, L.loss_part,
                      alpha, de_b, loss_out);
@@ -362,11 +378,30 @@ int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32
 int loss_fwd_bwd_fused(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha, float *loss_out,
                        const float *inv_den, const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set, void *ws,
                        void *stream) {
+  float *e_b = nullptr;
+  if (int rc = loss_gather_rows(d, e, idx, nullptr, b, ws, &e_b, stream)) return rc;
+  return loss_fused_gathered(d, b, beta, alpha, loss_out, idx, idx, nullptr, inv_den, p, c, dx_b, dp_b, pos_set, ws, stream);
+}
+
+// the two halves of loss_fwd_bwd_fused, for a sharded plan that all-reduces the gathered rows in between
+int loss_gather_rows(int32_t d, const float *e, const int32_t *rows, const float *keep, int32_t b, void *ws, float **e_b_out, void *stream) {
   if (int rc = check_d(d)) return rc;
-  GSS_REQUIRE(n > 0 && b > 0 && e && idx && loss_out && inv_den && p && dx_b && dp_b && ws, "loss_fwd_bwd_fused: null operand");
+  GSS_REQUIRE(b > 0 && (e || keep) && rows && ws && e_b_out, "loss_gather_rows: null operand or empty batch");  // e may be null on an empty shard
+  LossLaunch L;
+  if (int rc = loss_gather(d, e, rows, keep, b, ws, as_stream(stream), L)) return rc;
+  *e_b_out = L.e_b;
+  return GSS_OK;
+}
+
+int loss_fused_gathered(int32_t d, int32_t b, float beta, float alpha, float *loss_out, const int32_t *idx, const int32_t *pos_ids,
+                        const float *keep, const float *inv_den, const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set,
+                        void *ws, void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(b > 0 && idx && pos_ids && loss_out && inv_den && p && dx_b && dp_b && ws, "loss_fused_gathered: null operand");
   hipStream_t st = as_stream(stream);
   LossLaunch L;
-  if (int rc = loss_main(n, d, e, idx, b, beta, alpha, ws, st, L)) return rc;
+  loss_layout(d, b, ws, L);
+  if (int rc = loss_sweep(d, b, beta, alpha, st, L)) return rc;
   const int d4 = d / 4;
   int lg = 2;
   while ((1 << lg) < d4 && lg < 6) ++lg;
@@ -374,7 +409,7 @@ int loss_fwd_bwd_fused(int32_t n, int32_t d, const float *e, const int32_t *idx,
   dim3 grid(ceil_div(b, 4 * (64 >> lg))), block(256);
 #define GSS_FIN(V)                                                                                                              \
   hipLaunchKernelGGL((loss_finish_bwd_kernel<V>), grid, block, 0, st, b, d4, lg, L.js, L.ni * L.js, L.de_part, L.loss_part, alpha, \
-                     L.e_b, idx, inv_den, p, c, dx_b, dp_b, pos_set, loss_out)
+                     L.e_b, idx, pos_ids, keep, inv_den, p, c, dx_b, dp_b, pos_set, loss_out)
   if (vpl == 1)
     GSS_FIN(1);
   else if (vpl == 2)

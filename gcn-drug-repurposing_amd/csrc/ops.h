@@ -17,6 +17,16 @@ struct gss_csr {
   int32_t n_seg_blocks[5];
 };
 
+// communicator interface of the sharded plan (comm.hip): RCCL, or threads of one process
+struct gss_comm {
+  int world = 1, rank = 0;
+  virtual ~gss_comm() {}
+  // rank r's `bytes_per_rank` land at recv + r * bytes_per_rank; in place when send == recv + rank * bytes_per_rank
+  virtual int all_gather(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) = 0;
+  // in place, nbuf tensors as one fused operation; identical bits on every rank
+  virtual int all_reduce_sum(float *const *bufs, const size_t *counts, int nbuf, hipStream_t st) = 0;
+};
+
 namespace gss {
 // nnz-balanced segment descriptors of a CSR for 2^gpw_log2 lane groups per wave (spmm.hip; cached in the handle)
 int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks);
@@ -50,7 +60,11 @@ int wgrad_reduce_adam(int32_t d, void *ws, int total_slices, int nslices, float 
 int rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, void *stream);
 int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b, const float *e, const float *inv_den,
                     const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set, void *stream);
-int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, int32_t *pos_clear, void *stream);
+// dst[rows[r]] += src[r] unless rows[r] < 0 or keep[r] == 0 (keep nullable); pos_clear != NULL: also pos_clear[pos_ids[r]] = -1
+int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, const float *keep, int32_t b, float *dst, int32_t *pos_clear,
+                     const int32_t *pos_ids, void *stream);
+int shard_batch_ids(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
+                    int32_t *pid, int32_t *rloc, float *keep, void *stream);
 int shard_batch_maps(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
                      int32_t *rows_all, int32_t *rows_own, float *keep, int32_t *pos_col, int32_t *pos_row, void *stream);
 int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,
@@ -67,10 +81,14 @@ struct AdamTensor {
   int64_t count;
 };
 int adam_step4(const AdamTensor (&t)[4], int32_t step, float lr, float beta1, float beta2, float eps, float *w1t, float *w2t,
-               int32_t dim, void *stream);
+               int32_t dim, void *stream, int32_t *pos_clear = nullptr, const int32_t *ids = nullptr, int32_t b = 0);
 int loss_fwd_bwd_fused(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha, float *loss_out,
                        const float *inv_den, const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set, void *ws,
                        void *stream);
+int loss_gather_rows(int32_t d, const float *e, const int32_t *rows, const float *keep, int32_t b, void *ws, float **e_b_out, void *stream);
+int loss_fused_gathered(int32_t d, int32_t b, float beta, float alpha, float *loss_out, const int32_t *idx, const int32_t *pos_ids,
+                        const float *keep, const float *inv_den, const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set,
+                        void *ws, void *stream);
 int transpose2(int32_t dim, const float *a, const float *b, float *at, float *bt, void *stream);
 size_t loss_workspace_bytes(int32_t b, int32_t d);
 int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha,

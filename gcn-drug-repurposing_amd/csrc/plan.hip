@@ -45,6 +45,19 @@ struct gss_plan {
   size_t ev_used;
   double prof_ms[GSS_PROF_CLASSES];
   int64_t prof_cnt[GSS_PROF_CLASSES];
+  // node-range sharding.  A single-GPU plan is the case P = 1, rank = 0, maxr = n, comm = NULL: the
+  // gathers below return their argument and the all-reduces vanish.
+  gss_comm *comm;
+  int P, rank, maxr;           // shards, this shard, rows of the largest shard (local buffers hold maxr rows: equal send counts)
+  int lo;                      // first global node id of this shard
+  int64_t *d_bounds;           // device copy of the shard boundaries [P + 1]
+  std::vector<int64_t> h_bounds;
+  float *full[2];              // receive buffers of the operand all-gathers, [P * maxr][d]
+  float *x0full;               // the gathered input features (constant: gathered once)
+  bool x0_ready;
+  int32_t *pid, *rloc;         // per batch: padded global id / local row (clamped) of every batch member
+  float *keep;                 // per batch: 1.0 where this shard owns the member
+  float *gab;                  // [2 * max_batch][d]: the top layer's compact input gradients, all-reduced as one buffer
 };
 
 using namespace gss;
@@ -92,9 +105,17 @@ struct Carver {
 
 void carve(gss_plan *p, Carver &c) {
   const gss_plan_desc &D = p->desc;
-  const size_t nd = (size_t)D.n * D.d;
+  const size_t nd = (size_t)p->maxr * D.d;   // local buffers hold maxr >= n rows (all-gather send counts are equal)
   const size_t bd = (size_t)D.max_batch * D.d;
   const int L = D.num_layers;
+  const bool sharded = p->P > 1;
+  p->full[0] = sharded ? c.take<float>(nd * p->P) : nullptr;
+  p->full[1] = sharded ? c.take<float>(nd * p->P) : nullptr;
+  p->x0full = sharded ? c.take<float>(nd * p->P) : nullptr;
+  p->pid = sharded ? c.take<int32_t>(D.max_batch) : nullptr;
+  p->rloc = sharded ? c.take<int32_t>(D.max_batch) : nullptr;
+  p->keep = sharded ? c.take<float>(D.max_batch) : nullptr;
+  p->d_bounds = sharded ? c.take<int64_t>(p->P + 1) : nullptr;
   p->ax.assign(L, nullptr);
   p->am.assign(L, nullptr);
   p->p.assign(L, nullptr);
@@ -113,7 +134,7 @@ void carve(gss_plan *p, Carver &c) {
   p->am0[1] = pipe ? c.take<float>(nd) : nullptr;
   p->m_side = pipe ? c.take<float>(nd) : nullptr;
   p->x_last = c.take<float>(nd);
-  p->inv_den = c.take<float>(D.n);
+  p->inv_den = c.take<float>(p->maxr);
   if (L > 1) {
     p->g_ax = c.take<float>(nd);
     p->g_am = c.take<float>(nd);
@@ -128,9 +149,9 @@ void carve(gss_plan *p, Carver &c) {
   p->de_b = c.take<float>(bd);
   p->dx_b = c.take<float>(bd);
   p->dp_b = c.take<float>(bd);
-  p->gax_b = L > 1 ? c.take<float>(bd) : nullptr;
-  p->gam_b = L > 1 ? c.take<float>(bd) : nullptr;
-  p->pos = L > 1 ? c.take<int32_t>(D.n) : nullptr;
+  p->gab = L > 1 ? c.take<float>(2 * bd) : nullptr;   // gax_b = gab, gam_b = gab + b * d (contiguous for one all-reduce)
+  p->gax_b = p->gam_b = nullptr;
+  p->pos = L > 1 ? c.take<int32_t>((size_t)p->P * p->maxr) : nullptr;
   p->w1t = c.take<float>((size_t)D.d * D.d);
   p->w2t = c.take<float>((size_t)D.d * D.d);
   const size_t cnt[4] = {(size_t)D.d * D.d, (size_t)D.d, (size_t)D.d * D.d, (size_t)D.d};
@@ -146,21 +167,52 @@ void carve(gss_plan *p, Carver &c) {
 
 extern "C" {
 
-int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a, const gss_csr *at, const gss_plan_io *io) {
+static int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_desc *shard, gss_comm *comm, const gss_csr *a,
+                            const gss_csr *at, const gss_plan_io *io) {
   GSS_REQUIRE(out && desc && a && io, "plan_create: null argument");
-  GSS_REQUIRE(io->x && io->w1 && io->b1 && io->w2 && io->b2 && io->emb && io->loss && io->gw1 && io->gb1 && io->gw2 && io->gb2,
+  GSS_REQUIRE(io->w1 && io->b1 && io->w2 && io->b2 && io->loss && io->gw1 && io->gb1 && io->gw2 && io->gb2,
               "plan_create: null pointer in gss_plan_io");
+  GSS_REQUIRE((io->x && io->emb) || desc->n == 0, "plan_create: null x / emb in gss_plan_io");  // an empty shard has neither
   if (int rc = check_d(desc->d)) return rc;
-  GSS_REQUIRE(desc->n > 0 && desc->num_layers >= 1 && desc->num_layers <= 64, "plan_create: n=%d num_layers=%d", desc->n,
-              desc->num_layers);
-  GSS_REQUIRE(desc->max_batch >= 1 && desc->max_batch <= desc->n, "plan_create: max_batch=%d out of [1, n=%d]", desc->max_batch,
-              desc->n);
-  GSS_REQUIRE(a->n_rows == desc->n && a->n_cols == desc->n, "plan_create: A is %d x %d, expected %d x %d", a->n_rows, a->n_cols,
-              desc->n, desc->n);
-  GSS_REQUIRE(desc->num_layers == 1 || (at && at->n_rows == desc->n && at->n_cols == desc->n),
+  const int P = shard ? shard->world : 1;
+  const int rank = shard ? shard->rank : 0;
+  GSS_REQUIRE(desc->num_layers >= 1 && desc->num_layers <= 64, "plan_create: num_layers=%d", desc->num_layers);
+  GSS_REQUIRE(desc->n > 0 || P > 1, "plan_create: n=%d", desc->n);
+  int64_t n_global = desc->n;
+  int maxr = desc->n;
+  if (shard) {
+    GSS_REQUIRE(P >= 1 && rank >= 0 && rank < P && shard->h_bounds && shard->max_rows >= 1, "plan_create_sharded: bad shard descriptor");
+    GSS_REQUIRE(P == 1 || comm, "plan_create_sharded: world %d needs a communicator", P);
+    GSS_REQUIRE(!comm || (comm->world == P && comm->rank == rank), "plan_create_sharded: communicator is rank %d of %d, shard is %d of %d",
+                comm ? comm->rank : -1, comm ? comm->world : -1, rank, P);
+    GSS_REQUIRE(shard->h_bounds[0] == 0, "plan_create_sharded: bounds[0] must be 0");
+    for (int r = 0; r < P; ++r) {
+      const int64_t rows = shard->h_bounds[r + 1] - shard->h_bounds[r];
+      GSS_REQUIRE(rows >= 0 && rows <= shard->max_rows, "plan_create_sharded: shard %d has %lld rows, max_rows=%d", r, (long long)rows,
+                  shard->max_rows);
+    }
+    n_global = shard->h_bounds[P];
+    GSS_REQUIRE(shard->h_bounds[rank + 1] - shard->h_bounds[rank] == desc->n, "plan_create_sharded: desc->n=%d is not this shard's row count",
+                desc->n);
+    GSS_REQUIRE((int64_t)P * shard->max_rows < (int64_t)INT32_MAX, "plan_create_sharded: world * max_rows overflows int32");
+    GSS_REQUIRE(!desc->pipeline_layer1 || P == 1, "plan_create_sharded: pipeline_layer1 is a single-GPU option");
+    maxr = P > 1 ? shard->max_rows : desc->n;
+  }
+  GSS_REQUIRE(desc->max_batch >= 1 && (int64_t)desc->max_batch <= n_global, "plan_create: max_batch=%d out of [1, N=%lld]", desc->max_batch,
+              (long long)n_global);
+  const int ncols = P > 1 ? P * maxr : desc->n;
+  GSS_REQUIRE(a->n_rows == desc->n && a->n_cols == ncols, "plan_create: A is %d x %d, expected %d x %d", a->n_rows, a->n_cols, desc->n, ncols);
+  GSS_REQUIRE(desc->num_layers == 1 || (at && at->n_rows == desc->n && at->n_cols == ncols),
               "plan_create: A^T missing or mis-shaped (needed for num_layers >= 2)");
   gss_plan *p = new gss_plan();
   p->desc = *desc;
+  p->comm = P > 1 ? comm : nullptr;
+  p->P = P;
+  p->rank = rank;
+  p->maxr = maxr;
+  p->lo = shard ? (int)shard->h_bounds[rank] : 0;
+  if (shard) p->h_bounds.assign(shard->h_bounds, shard->h_bounds + P + 1);
+  p->x0_ready = false;
   p->a = a;
   p->at = at;
   p->x = io->x;
@@ -217,15 +269,33 @@ int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a,
     }
   }
   if (p->pos) {
-    e = hipMemset(p->pos, 0xff, sizeof(int32_t) * (size_t)desc->n);  // all -1
+    e = hipMemset(p->pos, 0xff, sizeof(int32_t) * (size_t)P * maxr);  // all -1
     if (e != hipSuccess) {
       (void)hipFree(p->slab);
       delete p;
       return fail(GSS_EHIP, "plan_create: hipMemset(pos) -> %s", hipGetErrorString(e));
     }
   }
+  if (p->d_bounds) {
+    e = hipMemcpy(p->d_bounds, shard->h_bounds, sizeof(int64_t) * (size_t)(P + 1), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(p->slab);
+      delete p;
+      return fail(GSS_EHIP, "plan_create: copy of the shard bounds -> %s", hipGetErrorString(e));
+    }
+  }
   *out = p;
   return GSS_OK;
+}
+
+int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a, const gss_csr *at, const gss_plan_io *io) {
+  return plan_create_impl(out, desc, nullptr, nullptr, a, at, io);
+}
+
+int gss_plan_create_sharded(gss_plan **out, const gss_plan_desc *desc, const gss_shard_desc *shard, gss_comm *comm, const gss_csr *a,
+                            const gss_csr *at, const gss_plan_io *io) {
+  GSS_REQUIRE(shard, "plan_create_sharded: null shard descriptor");
+  return plan_create_impl(out, desc, shard, comm, a, at, io);
 }
 
 void gss_plan_destroy(gss_plan *p) {
@@ -262,6 +332,43 @@ static int plan_prefetch_layer1(gss_plan *p, void *main_stream) {
   return GSS_OK;
 }
 
+// ---- exchange points of a sharded plan (no-ops on one GPU) ------------------------------------------------------
+// all-gather the maxr local rows of `local` into receive buffer `which`; returns the [P * maxr][d] operand
+static int plan_gather(gss_plan *p, const float *local, int which, const float **full, void *stream) {
+  if (p->P == 1) {
+    *full = local;
+    return GSS_OK;
+  }
+  PROF(GSS_PROF_COMM);
+  *full = p->full[which];
+  return p->comm->all_gather(local, p->full[which], sizeof(float) * (size_t)p->maxr * p->desc.d, as_stream(stream));
+}
+
+static int plan_allreduce(gss_plan *p, float *buf, size_t count, void *stream) {
+  if (p->P == 1 || count == 0) return GSS_OK;
+  PROF(GSS_PROF_COMM);
+  return p->comm->all_reduce_sum(&buf, &count, 1, as_stream(stream));
+}
+
+// the input features never change: every shard's rows are distributed once
+static int plan_x0(gss_plan *p, const float **full, void *stream) {
+  if (p->P == 1) {
+    *full = p->x;
+    return GSS_OK;
+  }
+  if (!p->x0_ready) {
+    PROF(GSS_PROF_COMM);
+    const size_t slot = (size_t)p->maxr * p->desc.d;
+    float *mine = p->x0full + (size_t)p->rank * slot;
+    if (p->desc.n > 0)
+      GSS_HIP(hipMemcpyAsync(mine, p->x, sizeof(float) * (size_t)p->desc.n * p->desc.d, hipMemcpyDeviceToDevice, as_stream(stream)));
+    if (int rc = p->comm->all_gather(mine, p->x0full, sizeof(float) * slot, as_stream(stream))) return rc;  // in place
+    p->x0_ready = true;
+  }
+  *full = p->x0full;
+  return GSS_OK;
+}
+
 static int plan_forward_impl(gss_plan *p, void *stream, bool pipelined = false) {
   GSS_REQUIRE(p, "plan_forward: null plan");
   const gss_plan_desc &D = p->desc;
@@ -279,18 +386,25 @@ static int plan_forward_impl(gss_plan *p, void *stream, bool pipelined = false) 
   for (int l = 0; l < L; ++l) {
     const float *xl = p->xin[l];
     const bool cached = (l == 0 && ((D.cache_layer1 && p->layer1_valid) || have_l0));
-    // the next step's layer-1 SpMMs go to the side stream when this stream reaches its last (MFMA-bound) GEMM
     (void)pipelined;
     if (!cached) {
-      // AX = A x ; M = AX (.) x      (model.py:163,168)
+      // AX = A x ; M = AX (.) x      (model.py:163,168); x gathered from every shard (C1)
+      const float *xf = nullptr;
+      if (l == 0) {
+        if (int rc = plan_x0(p, &xf, stream)) return rc;
+      } else {
+        if (int rc = plan_gather(p, xl, 0, &xf, stream)) return rc;
+      }
       {
         PROF(GSS_PROF_SPMM_FWD_HAD);
-        if (int rc = spmm_fwd(p->a, D.d, xl, p->ax[l], xl, p->m_tmp, stream)) return rc;
+        if (int rc = spmm_fwd(p->a, D.d, xf, p->ax[l], xl, p->m_tmp, stream)) return rc;
       }
       // AM = A M                      (model.py:169)
+      const float *mf = nullptr;
+      if (int rc = plan_gather(p, p->m_tmp, 1, &mf, stream)) return rc;
       {
         PROF(GSS_PROF_SPMM_FWD);
-        if (int rc = spmm_fwd(p->a, D.d, p->m_tmp, p->am[l], nullptr, nullptr, stream)) return rc;
+        if (int rc = spmm_fwd(p->a, D.d, mf, p->am[l], nullptr, nullptr, stream)) return rc;
       }
       if (l == 0) p->layer1_valid = true;
     }
@@ -309,42 +423,73 @@ static int plan_forward_impl(gss_plan *p, void *stream, bool pipelined = false) 
   return rownorm_fwd(D.n, D.d, p->x_last, p->emb, p->inv_den, stream);
 }
 
-static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const float *de_rows, bool top_done, bool wt_ok,
+static int plan_allreduce_grads(gss_plan *p, void *stream);
+
+// What the kernels index a batch with.  One GPU: the node ids themselves.  A shard: `rows` = the local row of every
+// batch member clamped into the shard (foreign rows get zero gradients through `keep`), `ids` = the padded global ids
+// the batch-position map is keyed by.
+struct BatchView {
+  const int32_t *rows, *ids;
+  const float *keep;
+};
+
+static int plan_batch_view(gss_plan *p, const int32_t *idx, int32_t b, BatchView &v, void *stream) {
+  if (p->P == 1) {
+    v = BatchView{idx, idx, nullptr};
+    return GSS_OK;
+  }
+  PROF(GSS_PROF_ELEMENTWISE);
+  v = BatchView{p->rloc, p->pid, p->keep};
+  return shard_batch_ids(idx, b, p->lo, p->desc.n, p->d_bounds, p->P, p->maxr, p->pid, p->rloc, p->keep, stream);
+}
+
+static int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float *de_rows, bool top_done, bool wt_ok,
                               void *stream, int *deferred_slices = nullptr);
 
-static int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta, bool wt_ok, void *stream,
+static int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta, bool wt_ok, void *stream, BatchView &bv,
                                    int *deferred_slices = nullptr) {
   GSS_REQUIRE(p && idx, "plan_loss_backward: null argument");
   const gss_plan_desc &D = p->desc;
   GSS_REQUIRE(b >= 1 && b <= D.max_batch, "plan_loss_backward: batch %d out of [1, %d]", b, D.max_batch);
   const int L = D.num_layers;
+  if (int rc = plan_batch_view(p, idx, b, bv, stream)) return rc;
+  const bool sparse_top = L > 1 && spmm_sparse_available();
+  GSS_REQUIRE(p->P == 1 || L == 1 || sparse_top, "a sharded plan needs the balanced SpMM (spmm_variant 2)");
+  float *e_b = nullptr;
   {
-    // loss, dLoss/dE_B and the backward of F.normalize / F.elu on the batch rows in three launches
+    // E_B = emb[idx] (model.py:216-217): every shard contributes the rows it owns, one all-reduce assembles them (C3)
     PROF(GSS_PROF_LOSS);
-    const bool sparse_top = L > 1 && spmm_sparse_available();
-    if (int rc = loss_fwd_bwd_fused(D.n, D.d, p->emb, idx, b, beta, D.alpha, p->loss, p->inv_den, p->p[L - 1],
-                                    L > 1 ? D.layer_decay : 1.f, p->dx_b, p->dp_b, sparse_top ? p->pos : nullptr, p->loss_ws, stream))
+    if (int rc = loss_gather_rows(D.d, p->emb, bv.rows, bv.keep, b, p->loss_ws, &e_b, stream)) return rc;
+  }
+  if (int rc = plan_allreduce(p, e_b, (size_t)b * D.d, stream)) return rc;
+  {
+    // loss, dLoss/dE_B and the backward of F.normalize / F.elu on the batch rows (every shard computes the full B x B
+    // sweep -- identical bits everywhere, no exchange of the loss -- and keeps the gradient rows it owns)
+    PROF(GSS_PROF_LOSS);
+    if (int rc = loss_fused_gathered(D.d, b, beta, D.alpha, p->loss, bv.rows, bv.ids, bv.keep, p->inv_den, p->p[L - 1],
+                                     L > 1 ? D.layer_decay : 1.f, p->dx_b, p->dp_b, sparse_top ? p->pos : nullptr, p->loss_ws, stream))
       return rc;
   }
-  return plan_backward_impl(p, idx, b, nullptr, true, wt_ok, stream, deferred_slices);
+  return plan_backward_impl(p, bv, b, nullptr, true, wt_ok, stream, deferred_slices);
 }
 
 // deferred_slices != NULL (gss_plan_step): the caller finishes with the fused reduce + Adam kernel, which also resets
 // the batch-position map; the residual of the top layer then rides in the backward SpMM's epilogue
-static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const float *de_rows, bool top_done, bool wt_ok,
+static int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float *de_rows, bool top_done, bool wt_ok,
                               void *stream, int *deferred_slices) {
-  GSS_REQUIRE(p && idx, "plan_backward: null argument");
+  GSS_REQUIRE(p && bv.rows, "plan_backward: null argument");
   const gss_plan_desc &D = p->desc;
   GSS_REQUIRE(b >= 1 && b <= D.max_batch, "plan_backward: %d rows out of [1, %d]", b, D.max_batch);
   const int L = D.num_layers;
   hipStream_t st = as_stream(stream);
   const float *de_b = de_rows ? de_rows : p->de_b;
+  const int32_t *pos_row = p->pos ? p->pos + (size_t)p->rank * p->maxr : nullptr;  // local row r has padded id rank * maxr + r
   // top layer, batch rows only
   const float c_top = L > 1 ? D.layer_decay : 1.f;
   const bool sparse_top = L > 1 && spmm_sparse_available();
   if (!top_done) {
     PROF(GSS_PROF_ELEMENTWISE);
-    if (int rc = rownorm_elu_bwd(D.d, de_b, idx, b, p->emb, p->inv_den, p->p[L - 1], c_top, p->dx_b, p->dp_b,
+    if (int rc = rownorm_elu_bwd(D.d, de_b, bv.rows, b, p->emb, p->inv_den, p->p[L - 1], c_top, p->dx_b, p->dp_b,
                                  sparse_top ? p->pos : nullptr, stream))
       return rc;
   }
@@ -353,13 +498,13 @@ static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const 
   // gss_plan_step with L > 1: the top layer's batch-row weight gradient (64 latency-bound workgroups, its inputs stay
   // untouched until the end of the step) is postponed and shares the launch of the next layer's full-N one.  Its
   // partial slabs keep their place (slices [0, wg_top)), so the fixed-order reduce adds the same numbers in the same order.
-  const bool merge_top = deferred_slices && L > 1;
+  const bool merge_top = deferred_slices && L > 1 && D.n > 0;
   const int wg_top = wgrad_slices(b, D.d);
   if (merge_top) {
     wg_used = wg_top;
   } else {
     PROF(GSS_PROF_WGRAD_BATCH);
-    if (int rc = wgrad_partial(b, D.d, p->dp_b, p->ax[L - 1], p->am[L - 1], idx, p->wgrad_ws, p->wg_total, wg_used, &wg_n, stream))
+    if (int rc = wgrad_partial(b, D.d, p->dp_b, p->ax[L - 1], p->am[L - 1], bv.rows, p->wgrad_ws, p->wg_total, wg_used, &wg_n, stream))
       return rc;
     wg_used += wg_n;
   }
@@ -370,13 +515,17 @@ static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const 
     }
     if (sparse_top) {
       // the top layer's input gradients live on the b batch rows only: keep them compact and let the SpMM
-      // skip every neighbour that is not a batch row
+      // skip every neighbour that is not a batch row.  Sharded: rows a shard does not own are zero in dp_b, so the
+      // sum over the shards (C3) is the batch's gradient
+      p->gax_b = p->gab;
+      p->gam_b = p->gab + (size_t)b * D.d;
       {
         PROF(GSS_PROF_DGRAD);
         if (int rc = dense_bwd_input(b, D.d, p->dp_b, p->w1t, p->w2t, nullptr, p->gax_b, p->gam_b, stream)) return rc;
       }
+      if (int rc = plan_allreduce(p, p->gab, (size_t)2 * b * D.d, stream)) return rc;
       PROF(GSS_PROF_SPMM_BWD1);
-      if (int rc = spmm_bwd1_sparse(p->at, D.d, p->gam_b, p->gax_b, p->pos, p->pos, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream))
+      if (int rc = spmm_bwd1_sparse(p->at, D.d, p->gam_b, p->gax_b, p->pos, pos_row, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream))
         return rc;
     } else {
       const size_t nd_bytes = sizeof(float) * (size_t)D.n * D.d;
@@ -387,7 +536,7 @@ static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const 
       }
       {
         PROF(GSS_PROF_DGRAD);
-        if (int rc = dense_bwd_input(b, D.d, p->dp_b, p->w1t, p->w2t, idx, p->g_ax, p->g_am, stream)) return rc;
+        if (int rc = dense_bwd_input(b, D.d, p->dp_b, p->w1t, p->w2t, bv.rows, p->g_ax, p->g_am, stream)) return rc;
       }
       PROF(GSS_PROF_SPMM_BWD1);
       if (int rc = spmm_bwd1(p->at, D.d, p->g_am, p->g_ax, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream)) return rc;
@@ -397,25 +546,27 @@ static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const 
       const float *res = (lp + 2 <= L - 1) ? p->gx[(lp + 2) & 1] : nullptr;
       float *gx_out = (lp >= 1 && L > 2) ? p->gx[(lp + 1) & 1] : nullptr;
       const bool fold_res = deferred_slices && sparse_top && lp + 2 == L;
+      const float *uf = nullptr;
+      if (int rc = plan_gather(p, p->u, 0, &uf, stream)) return rc;   // C1
       {
         PROF(GSS_PROF_SPMM_BWD2);
         if (fold_res) {
           // dP += dx_b on the batch rows inside the SpMM epilogue (no separate scatter-add launch)
-          if (int rc = spmm_bwd2_sparse_res(p->at, D.d, p->u, p->t, p->p[lp], c, p->dx_b, p->pos, p->dp, gx_out, stream)) return rc;
+          if (int rc = spmm_bwd2_sparse_res(p->at, D.d, uf, p->t, p->p[lp], c, p->dx_b, pos_row, p->dp, gx_out, stream)) return rc;
         } else {
-          if (int rc = spmm_bwd2(p->at, D.d, p->u, p->t, p->p[lp], c, res, p->dp, gx_out, stream)) return rc;
+          if (int rc = spmm_bwd2(p->at, D.d, uf, p->t, p->p[lp], c, res, p->dp, gx_out, stream)) return rc;
         }
       }
       if (lp + 2 == L && !fold_res) {
         PROF(GSS_PROF_ELEMENTWISE);
-        if (int rc = scatter_add_rows(D.d, p->dx_b, idx, b, p->dp, sparse_top ? p->pos : nullptr, stream)) return rc;
+        if (int rc = scatter_add_rows(D.d, p->dx_b, bv.rows, bv.keep, b, p->dp, sparse_top ? p->pos : nullptr, bv.ids, stream)) return rc;
       }
       {
         PROF(GSS_PROF_WGRAD);
         if (merge_top && lp == L - 2) {
           int n_top = 0;
-          if (int rc = wgrad_partial_pair(D.d, D.n, p->dp, p->ax[lp], p->am[lp], nullptr, wg_used, b, p->dp_b, p->ax[L - 1], p->am[L - 1], idx, 0,
-                                          p->wgrad_ws, p->wg_total, &wg_n, &n_top, stream))
+          if (int rc = wgrad_partial_pair(D.d, D.n, p->dp, p->ax[lp], p->am[lp], nullptr, wg_used, b, p->dp_b, p->ax[L - 1], p->am[L - 1], bv.rows,
+                                          0, p->wgrad_ws, p->wg_total, &wg_n, &n_top, stream))
             return rc;
         } else {
           if (int rc = wgrad_partial(D.n, D.d, p->dp, p->ax[lp], p->am[lp], nullptr, p->wgrad_ws, p->wg_total, wg_used, &wg_n, stream))
@@ -428,8 +579,10 @@ static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const 
           PROF(GSS_PROF_DGRAD);
           if (int rc = dense_bwd_input(D.n, D.d, p->dp, p->w1t, p->w2t, nullptr, p->g_ax, p->g_am, stream)) return rc;
         }
+        const float *gf = nullptr;
+        if (int rc = plan_gather(p, p->g_am, 1, &gf, stream)) return rc;   // C1
         PROF(GSS_PROF_SPMM_BWD1);
-        if (int rc = spmm_bwd1(p->at, D.d, p->g_am, p->g_ax, p->xin[lp], p->ax[lp], p->u, p->t, stream)) return rc;
+        if (int rc = spmm_bwd1(p->at, D.d, gf, p->g_ax, p->xin[lp], p->ax[lp], p->u, p->t, stream)) return rc;
       }
     }
   }
@@ -439,11 +592,23 @@ static int plan_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, const 
     *deferred_slices = wg_used;
     return GSS_OK;
   }
-  PROF(GSS_PROF_WGRAD);
-  return wgrad_reduce(D.d, p->wgrad_ws, p->wg_total, wg_used, p->grad[0], p->grad[2], p->grad[1], p->grad[3], 0, stream);
+  {
+    PROF(GSS_PROF_WGRAD);
+    if (int rc = wgrad_reduce(D.d, p->wgrad_ws, p->wg_total, wg_used, p->grad[0], p->grad[2], p->grad[1], p->grad[3], 0, stream)) return rc;
+  }
+  return plan_allreduce_grads(p, stream);
 }
 
-static int plan_adam_impl(gss_plan *p, void *stream) {
+// C2: the four weight-gradient tensors summed over the shards, one fused collective
+static int plan_allreduce_grads(gss_plan *p, void *stream) {
+  if (p->P == 1) return GSS_OK;
+  PROF(GSS_PROF_COMM);
+  const gss_plan_desc &D = p->desc;
+  const size_t cnt[4] = {(size_t)D.d * D.d, (size_t)D.d, (size_t)D.d * D.d, (size_t)D.d};
+  return p->comm->all_reduce_sum(p->grad, cnt, 4, as_stream(stream));
+}
+
+static int plan_adam_impl(gss_plan *p, void *stream, int32_t *pos_clear = nullptr, const int32_t *ids = nullptr, int32_t b = 0) {
   GSS_REQUIRE(p, "plan_adam: null plan");
   const gss_plan_desc &D = p->desc;
   p->step += 1;
@@ -453,7 +618,7 @@ static int plan_adam_impl(gss_plan *p, void *stream) {
   AdamTensor t[4];
   for (int k = 0; k < 4; ++k) t[k] = AdamTensor{params[k], p->grad[k], p->adam_m[k], p->adam_v[k], cnt[k]};
   const bool wt = D.num_layers > 1;
-  return adam_step4(t, p->step, D.lr, D.beta1, D.beta2, D.eps, wt ? p->w1t : nullptr, wt ? p->w2t : nullptr, D.d, stream);
+  return adam_step4(t, p->step, D.lr, D.beta1, D.beta2, D.eps, wt ? p->w1t : nullptr, wt ? p->w2t : nullptr, D.d, stream, pos_clear, ids, b);
 }
 
 // ---- public entry points.  The separate phases make no assumption about who changed the weights in between, so
@@ -464,11 +629,15 @@ int gss_plan_forward(gss_plan *p, void *stream) {
 }
 int gss_plan_loss_backward(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
   if (p) p->wt_valid = false;
-  return plan_loss_backward_impl(p, idx, b, beta, false, stream);
+  BatchView bv{};
+  return plan_loss_backward_impl(p, idx, b, beta, false, stream, bv);
 }
 int gss_plan_backward(gss_plan *p, const int32_t *rows, int32_t b, const float *de_rows, void *stream) {
-  if (p) p->wt_valid = false;
-  return plan_backward_impl(p, rows, b, de_rows, false, false, stream);
+  GSS_REQUIRE(p && rows, "plan_backward: null argument");
+  GSS_REQUIRE(p->P == 1, "plan_backward: an external upstream gradient is not supported on a sharded plan");
+  p->wt_valid = false;
+  const BatchView bv{rows, rows, nullptr};
+  return plan_backward_impl(p, bv, b, de_rows, false, false, stream);
 }
 int gss_plan_adam(gss_plan *p, void *stream) {
   const int rc = plan_adam_impl(p, stream);
@@ -482,22 +651,51 @@ int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *
   if (pipe)  // the side stream starts when this stream reaches the loss kernel (MFMA-bound, 1 MB working set)
     if (int rc = plan_prefetch_layer1(p, stream)) return rc;
   int slices = 0;
-  if (int rc = plan_loss_backward_impl(p, idx, b, beta, p->wt_valid, stream, &slices)) return rc;
-  {
+  BatchView bv{};
+  if (int rc = plan_loss_backward_impl(p, idx, b, beta, p->wt_valid, stream, bv, &slices)) return rc;
+  const gss_plan_desc &D = p->desc;
+  const bool wt = D.num_layers > 1;
+  const bool sparse_top = wt && spmm_sparse_available();
+  if (p->P == 1) {
     // weight-gradient reduce + Adam on the four tensors (+ transposed weights for the next backward, + reset of the
     // batch-position map) in one launch
-    const gss_plan_desc &D = p->desc;
     p->step += 1;
     PROF(GSS_PROF_ADAM);
     float *params[4] = {p->w1, p->b1, p->w2, p->b2};
-    const bool wt = D.num_layers > 1;
-    const bool sparse_top = wt && spmm_sparse_available();
     if (int rc = wgrad_reduce_adam(D.d, p->wgrad_ws, p->wg_total, slices, p->grad, params, p->adam_m, p->adam_v, p->step, D.lr, D.beta1,
                                    D.beta2, D.eps, wt ? p->w1t : nullptr, wt ? p->w2t : nullptr, sparse_top ? p->pos : nullptr, idx, b,
                                    stream))
       return rc;
+  } else {
+    // sharded: the gradients of the shards are summed between the reduce and the optimizer (C2)
+    {
+      PROF(GSS_PROF_WGRAD);
+      if (int rc = wgrad_reduce(D.d, p->wgrad_ws, p->wg_total, slices, p->grad[0], p->grad[2], p->grad[1], p->grad[3], 0, stream)) return rc;
+    }
+    if (int rc = plan_allreduce_grads(p, stream)) return rc;
+    if (int rc = plan_adam_impl(p, stream, sparse_top ? p->pos : nullptr, bv.ids, b)) return rc;
   }
-  p->wt_valid = p->desc.num_layers > 1;
+  p->wt_valid = wt;
+  return GSS_OK;
+}
+
+int gss_plan_gather_embeddings(gss_plan *p, float *out, void *stream) {
+  GSS_REQUIRE(p && out, "plan_gather_embeddings: null argument");
+  const gss_plan_desc &D = p->desc;
+  hipStream_t st = as_stream(stream);
+  if (p->P == 1) {
+    GSS_HIP(hipMemcpyAsync(out, p->emb, sizeof(float) * (size_t)D.n * D.d, hipMemcpyDeviceToDevice, st));
+    return GSS_OK;
+  }
+  const size_t slot = (size_t)p->maxr * D.d;
+  float *mine = p->full[0] + (size_t)p->rank * slot;
+  if (D.n > 0) GSS_HIP(hipMemcpyAsync(mine, p->emb, sizeof(float) * (size_t)D.n * D.d, hipMemcpyDeviceToDevice, st));
+  if (int rc = p->comm->all_gather(mine, p->full[0], sizeof(float) * slot, st)) return rc;
+  for (int r = 0; r < p->P; ++r) {
+    const int64_t lo = p->h_bounds[(size_t)r], rows = p->h_bounds[(size_t)r + 1] - lo;
+    if (rows > 0)
+      GSS_HIP(hipMemcpyAsync(out + (size_t)lo * D.d, p->full[0] + (size_t)r * slot, sizeof(float) * (size_t)rows * D.d, hipMemcpyDeviceToDevice, st));
+  }
   return GSS_OK;
 }
 

@@ -136,6 +136,116 @@ class ThreadComm:
 
 
 # ---------------------------------------------------------------------------------------------------------
+# native communicators (include/gssgcn.h gss_comm_*) and the sharded plan
+# ---------------------------------------------------------------------------------------------------------
+class Comm:
+    """owner of one gss_comm handle"""
+
+    def __init__(self, handle, world, rank):
+        self.handle, self.world, self.rank = handle, int(world), int(rank)
+        self._destroy = _lib.load().gss_comm_destroy
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            self._destroy(h)
+            self.handle = None
+
+    def all_gather_rows(self, src, dst_padded):
+        """C1: src [max_rows, d] -> dst_padded [world * max_rows, d] on torch's current stream"""
+        _lib.check(_lib.load().gss_allgather_rows(self.handle, src.shape[1], src.shape[0], src.data_ptr(), dst_padded.data_ptr(),
+                                                  _lib.current_stream()), "gss_allgather_rows")
+
+    def all_reduce_sum_(self, t):
+        _lib.check(_lib.load().gss_allreduce_sum(self.handle, t.data_ptr(), t.numel(), _lib.current_stream()), "gss_allreduce_sum")
+
+
+def rccl_comm(world=None, rank=None):
+    """RCCL communicator of this process inside a torch.distributed job: rank 0 draws the unique id, the (gloo or
+    nccl) process group only carries its 128 bytes; afterwards the data path never touches torch.distributed."""
+    import torch.distributed as dist
+    lib = _lib.load()
+    world = dist.get_world_size() if world is None else world
+    rank = dist.get_rank() if rank is None else rank
+    buf = (C.c_char * 128)()
+    if rank == 0:
+        _lib.check(lib.gss_comm_unique_id(buf), "gss_comm_unique_id")
+    box = [bytes(buf)]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    h = C.c_void_p()
+    _lib.check(lib.gss_comm_create_rccl(C.byref(h), int(world), int(rank), box[0]), "gss_comm_create_rccl")
+    return Comm(h, world, rank)
+
+
+def local_comms(world):
+    """`world` communicators for ranks that are threads of this process (gss_comm_create_local)"""
+    arr = (C.c_void_p * world)()
+    _lib.check(_lib.load().gss_comm_create_local(arr, int(world)), "gss_comm_create_local")
+    return [Comm(C.c_void_p(arr[r]), world, r) for r in range(world)]
+
+
+class _ShardGraph:
+    """the (a, at) pair GssEngine expects, for one shard"""
+
+    def __init__(self, a, at, n):
+        self.a, self.at, self.n = a, at, n
+
+    @property
+    def nnz(self):
+        return self.a.nnz
+
+
+def partition_for(a_hat, world):
+    """nnz-balanced node ranges over forward + backward entries (the same rule as ShardedEngine)"""
+    work = a_hat.indptr + sp.csr_matrix(a_hat.T).indptr
+    return Partition(nnz_balanced_ranges(work, world))
+
+
+def sharded_plan_engine(adj, x_host, params_host, comm, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4, max_batch=None,
+                        betas=(0.9, 0.999), eps=1e-8, device=None, a_hat=None, cache_layer1=False):
+    """One rank of the node-range sharded trainer on the NATIVE path: a gss_plan created with gss_plan_create_sharded
+    that holds the communicator and enqueues kernels and collectives from C++ (no Python between kernels).  Returns a
+    GssEngine (same methods as the single-GPU one; .global_nnz, .part added)."""
+    from .engine import GssEngine
+    from .graph import DeviceCSR
+    world, rank = comm.world, comm.rank
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if a_hat is None:
+        a_hat = ShardedEngine._normalize_host(adj)
+    a_hat = sp.csr_matrix(a_hat)
+    a_hat.sort_indices()
+    part = partition_for(a_hat, world)
+    lo, hi = part.rows(rank)
+    nl = hi - lo
+    if world == 1:
+        ncols = nl
+
+        def cols(sub):
+            return sub.indptr.astype(np.int32), sub.indices.astype(np.int32), sub.data.astype(np.float32)
+    else:
+        ncols = world * part.max_rows
+
+        def cols(sub):
+            return sub.indptr.astype(np.int32), part.padded_id(sub.indices).astype(np.int32), sub.data.astype(np.float32)
+    sub = sp.csr_matrix(a_hat[lo:hi])
+    sub.sort_indices()
+    a = DeviceCSR(*cols(sub), nl, ncols, dev)
+    at = None
+    if num_layers > 1:
+        sub_t = sp.csr_matrix(sp.csr_matrix(a_hat.T)[lo:hi])
+        sub_t.sort_indices()
+        at = DeviceCSR(*cols(sub_t), nl, ncols, dev)
+    x = torch.from_numpy(np.ascontiguousarray(x_host[lo:hi], dtype=np.float32)).to(dev)
+    params = [torch.from_numpy(np.ascontiguousarray(params_host[k], dtype=np.float32)).to(dev) for k in ("W1", "b1", "W2", "b2")]
+    eng = GssEngine(_ShardGraph(a, at, nl), x, params, num_layers=num_layers, layer_decay=layer_decay, alpha=alpha, lr=lr,
+                    max_batch=max_batch or a_hat.shape[0], cache_layer1=cache_layer1, betas=betas, eps=eps,
+                    shard=(world, rank, part.max_rows, part.bounds), comm=comm)
+    eng.global_nnz, eng.part = int(a_hat.nnz), part
+    return eng
+
+
+# ---------------------------------------------------------------------------------------------------------
 # op backend over the C ABI
 # ---------------------------------------------------------------------------------------------------------
 class HipOps:

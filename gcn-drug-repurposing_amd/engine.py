@@ -17,8 +17,11 @@ PARAM_NAMES = ("W1", "b1", "W2", "b2")
 
 
 class GssEngine:
-    def __init__(self, graph: GssGraph, x: torch.Tensor, params, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4,
-                 max_batch=None, cache_layer1=False, betas=(0.9, 0.999), eps=1e-8, pipeline_layer1=False):
+    def __init__(self, graph, x: torch.Tensor, params, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4,
+                 max_batch=None, cache_layer1=False, betas=(0.9, 0.999), eps=1e-8, pipeline_layer1=False, shard=None, comm=None):
+        """shard = (world, rank, max_rows, bounds[world + 1]) + comm (dist.Comm): one shard of a node-range sharded
+        replica (gss_plan_create_sharded); graph.a / graph.at then hold this shard's rows with padded column ids and
+        x / emb this shard's rows.  Every method is then a collective over the shards."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
         n, d = x.shape
         assert n == graph.n, f"features have {n} rows, graph has {graph.n} nodes"
@@ -26,7 +29,9 @@ class GssEngine:
             raise ValueError("num_layers >= 2 needs the transposed CSR (GssGraph(need_transpose=True))")
         self.graph, self.x = graph, x
         self.n, self.d, self.num_layers = n, d, int(num_layers)
-        self.max_batch = int(max_batch or n)
+        self.shard, self.comm = shard, comm
+        self.n_global = int(shard[3][-1]) if shard is not None else n
+        self.max_batch = int(max_batch or self.n_global)
         self.params = list(params)
         shapes = [(d, d), (d,), (d, d), (d,)]
         for p, s in zip(self.params, shapes):
@@ -43,8 +48,15 @@ class GssEngine:
                          *[g.data_ptr() for g in self.grads])
         self._param_ptrs = [p.data_ptr() for p in self.params]
         h = C.c_void_p()
-        _lib.check(self.lib.gss_plan_create(C.byref(h), C.byref(self.desc), graph.a.handle,
-                                            graph.at.handle if graph.at is not None else None, C.byref(io)), "gss_plan_create")
+        at_h = graph.at.handle if graph.at is not None else None
+        if shard is None:
+            _lib.check(self.lib.gss_plan_create(C.byref(h), C.byref(self.desc), graph.a.handle, at_h, C.byref(io)), "gss_plan_create")
+        else:
+            world, rank, max_rows, bounds = shard
+            self._bounds = np.ascontiguousarray(bounds, dtype=np.int64)
+            sd = _lib.ShardDesc(int(world), int(rank), int(max_rows), self._bounds.ctypes.data)
+            _lib.check(self.lib.gss_plan_create_sharded(C.byref(h), C.byref(self.desc), C.byref(sd), comm.handle if comm is not None else None,
+                                                        graph.a.handle, at_h, C.byref(io)), "gss_plan_create_sharded")
         self.handle = h
         self._destroy = self.lib.gss_plan_destroy
 
@@ -80,10 +92,19 @@ class GssEngine:
         _lib.check(self.lib.gss_plan_step(self.handle, idx32.data_ptr() + 4 * offset, b, float(beta), _lib.current_stream()),
                    "gss_plan_step")
 
+    def gather_embeddings(self) -> torch.Tensor:
+        """the full [N][d] embeddings in node order (a collective on a sharded plan; the plan's own tensor otherwise)"""
+        if self.shard is None:
+            return self.emb
+        out = torch.empty(self.n_global, self.d, dtype=torch.float32, device=self.x.device)
+        _lib.check(self.lib.gss_plan_gather_embeddings(self.handle, out.data_ptr(), _lib.current_stream()), "gss_plan_gather_embeddings")
+        return out
+
     def percentile(self, q: float) -> float:
         """beta = np.percentile(E E^T, q) of the current embeddings (train.py:165-167), exact, on device."""
+        e = self.gather_embeddings()
         out = C.c_float()
-        _lib.check(self.lib.gss_percentile(self.n, self.d, self.emb.data_ptr(), float(q), C.byref(out), _lib.current_stream()),
+        _lib.check(self.lib.gss_percentile(self.n_global, self.d, e.data_ptr(), float(q), C.byref(out), _lib.current_stream()),
                    "gss_percentile")
         return float(out.value)
 

@@ -56,7 +56,7 @@ def build_parser():
     p.add_argument('--batch-file', type=str, default=None, help='.npz with batches/batch_sizes to replay instead of sampling')
     p.add_argument('--log-loss', action='store_true', help='print the last loss of every epoch')
     p.add_argument('--checkpoint', default=None, help='write the training state (weights, Adam moments, step, beta, sampler RNG) '
-                   'to this .npz after every epoch (single GPU)')
+                   'to this .npz after every epoch')
     p.add_argument('--resume', default=None, help='continue from a --checkpoint file: same flags, remaining epochs')
     p.add_argument('--ngpus', type=int, default=None,
                    help='node-range shards over N GPUs of this node; launch with `python -m torch.distributed.run '
@@ -157,21 +157,19 @@ def main(argv=None):
         for k in ("b1", "b2"):
             host_params[k] = np.concatenate([host_params[k], np.zeros(d_pad - d, np.float32)])
     if sharded:
-        # one process per GPU, node-range shards, RCCL all-gather per SpMM hop (dist.py); same step semantics
-        from .dist import ShardedEngine
-        from . import _lib
-        engine = ShardedEngine(adj, X32, host_params, num_layers=args.num_layers, layer_decay=args.layer_decay,
-                               alpha=args.alpha, lr=args.lr, max_batch=min(bsz, n), device=dev)
+        # one process per GPU, node-range shards: a native gss_plan per rank that owns the RCCL communicator and enqueues
+        # kernels and collectives from C++ (dist.sharded_plan_engine); same step semantics
+        from .dist import rccl_comm, sharded_plan_engine
+        engine = sharded_plan_engine(adj, X32, host_params, rccl_comm(world, rank), num_layers=args.num_layers, layer_decay=args.layer_decay,
+                                     alpha=args.alpha, lr=args.lr, max_batch=min(bsz, n), device=dev, cache_layer1=args.cache_layer1)
+        if rank == 0:
+            print('Created G with [k={}] [shape=[{}, {}]] [nnz(A_hat)={}] in {:.2f}s; {} node-range shards'.format(
+                args.k, n, n, engine.global_nnz, time.time() - t0, world))
 
         def full_embeddings():
-            return engine.gather_embeddings().contiguous()
+            return engine.gather_embeddings()
 
-        def percentile(q):
-            import ctypes as C
-            e = full_embeddings()
-            out = C.c_float()
-            _lib.check(_lib.load().gss_percentile(n, d_pad, e.data_ptr(), float(q), C.byref(out), _lib.current_stream()), "gss_percentile")
-            return float(out.value)
+        percentile = engine.percentile
     else:
         feats = torch.from_numpy(X32).to(dev)                    # method/dataset.py:13
         params = [torch.from_numpy(host_params[k]).to(dev) for k in ("W1", "b1", "W2", "b2")]
@@ -200,8 +198,6 @@ def main(argv=None):
     beta_score = args.beta
     itr = 0
     step_no = 0
-    if (args.checkpoint or args.resume) and sharded:
-        raise Exception("--checkpoint / --resume are single-GPU features")
     # what a resumed run must share with the run that wrote the checkpoint to be its continuation
     hyper = {"lr": args.lr, "alpha": args.alpha, "layer_decay": args.layer_decay, "batch_size": float(bsz),
              "seed": float(args.seed or 0), "init_weights": args.init_weights}
@@ -247,7 +243,7 @@ def main(argv=None):
             off += b
             step_no += 1
         itr += 1
-        if args.checkpoint:
+        if args.checkpoint and rank == 0:          # weights and optimizer state are replicated: rank 0's copy is the job's
             sd = engine.state_dict()
             tmp = args.checkpoint + ".tmp.npz"
             np.savez(tmp, epoch=itr, beta=float(beta_score), n=n, d=d_pad, num_layers=args.num_layers,

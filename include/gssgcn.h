@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GSS_ABI_VERSION 1
+#define GSS_ABI_VERSION 2
 
 #define GSS_OK 0
 #define GSS_EINVAL (-22)   /* bad argument (shape, null pointer, unsupported d) */
@@ -34,6 +34,7 @@ extern "C" {
 
 typedef struct gss_csr gss_csr;   /* a CSR operand plus its launch schedule (row bins) */
 typedef struct gss_plan gss_plan; /* activations + workspace of one training replica/shard */
+typedef struct gss_comm gss_comm; /* the communicator of a node-range sharded job (RCCL over xGMI, or in-process ranks) */
 
 int gss_abi_version(void);
 const char *gss_last_error(void);
@@ -122,6 +123,27 @@ int gss_scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32
  *   pos_col[padded id] = i for batch members, -1 elsewhere ([world * maxr]);  pos_row[local row] = i or -1 ([nl]) */
 int gss_shard_batch_maps(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
                          int32_t *rows_all, int32_t *rows_own, float *keep, int32_t *pos_col, int32_t *pos_row, void *stream);
+
+/* ---- C1-C3  collectives of the node-range sharded trainer (the reference is single-device,
+ * train.py:68,118-122, so there is nothing to match -- these are the exchange points 1-D sharding of its step needs).
+ * One process per GPU: rank 0 calls gss_comm_unique_id, the host distributes the GSS_COMM_ID_BYTES bytes (torch.distributed
+ * store, a file ...), every rank calls gss_comm_create_rccl with its current HIP device set.  gss_comm_create_local makes
+ * `world` communicators for ranks that are THREADS of one process (each with its own stream, possibly all on one GPU):
+ * device-to-device copies behind a timed host barrier, so that a sharded plan can be run at world 2..8 on a one-GPU box.
+ * Collectives are enqueued on `stream` (the local backend also synchronises it); every rank must call them in the same order. */
+#define GSS_COMM_ID_BYTES 128
+int gss_comm_unique_id(void *id_out);
+int gss_comm_create_rccl(gss_comm **out, int32_t world, int32_t rank, const void *id);
+int gss_comm_create_local(gss_comm **out /* [world] */, int32_t world);
+void gss_comm_destroy(gss_comm *c);
+int32_t gss_comm_world(const gss_comm *c);
+int32_t gss_comm_rank(const gss_comm *c);
+/* C1: src [max_rows][d] (this rank's rows first, the rest don't-care) -> dst_padded [world * max_rows][d], rank r's rows at
+ * row r * max_rows.  In place when src == dst_padded + rank * max_rows * d. */
+int gss_allgather_rows(gss_comm *c, int32_t d, int32_t max_rows, const float *src, float *dst_padded, void *stream);
+int gss_allgather_bytes(gss_comm *c, const void *src, void *dst, size_t bytes_per_rank, void *stream);
+/* C2/C3: buf <- sum over ranks, in place, the same bits on every rank */
+int gss_allreduce_sum(gss_comm *c, float *buf, int64_t count, void *stream);
 
 /* ---- K10  torch.optim.Adam.step, train.py:139-141,184 -----------------------------------------
  * One tensor of `count` floats; step is the 1-based step number.  lr, betas, eps as torch defaults.
@@ -220,6 +242,26 @@ typedef struct gss_plan_io {
 
 int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a, const gss_csr *at,
                     const gss_plan_io *io);
+
+/* One shard of a node-range sharded replica.  Rank r owns the node range [bounds[r], bounds[r+1]) -- the rows
+ * of A_hat and A_hat^T (every column) and the matching rows of every activation and gradient; weights are replicated.
+ *   desc->n = rows of THIS shard; a / at: CSR handles of the shard's rows with n_cols = world * max_rows and PADDED column
+ *   ids  col' = owner(col) * max_rows + (col - bounds[owner(col)])  (operands are gathered into [world][max_rows][d]);
+ *   io->x / io->emb: this shard's rows; the weights / gradients / loss in io are full-size and end up identical on every rank.
+ * Every gss_plan_* call then is a collective: all ranks call it with the same batch.  Per step the plan enqueues, on the
+ * caller's stream, 2L - 1 + max(0, 2L - 3) all-gathers of a [N][d] operand (C1), one all-reduce of the B gathered batch rows
+ * and one of their 2 B d input gradients (C3), and one grouped all-reduce of the four weight gradients (C2); no host
+ * round trip in between.  world == 1 is exactly gss_plan_create.  gss_plan_backward (external upstream gradient) is not
+ * available on a sharded plan. */
+typedef struct gss_shard_desc {
+  int32_t world, rank;
+  int32_t max_rows;          /* largest shard's row count */
+  const int64_t *h_bounds;   /* host, [world + 1], bounds[0] = 0, bounds[world] = N */
+} gss_shard_desc;
+int gss_plan_create_sharded(gss_plan **out, const gss_plan_desc *desc, const gss_shard_desc *shard, gss_comm *comm,
+                            const gss_csr *a, const gss_csr *at, const gss_plan_io *io);
+/* this shard's rows of the last embeddings gathered from every shard: out [N][d] in node order (collective) */
+int gss_plan_gather_embeddings(gss_plan *p, float *out, void *stream);
 void gss_plan_destroy(gss_plan *p);
 /* forward only (model.py:197-207): writes io.emb */
 int gss_plan_forward(gss_plan *p, void *stream);
@@ -257,7 +299,8 @@ enum {
   GSS_PROF_ROWNORM = 9,
   GSS_PROF_ELEMENTWISE = 10, /* norm/ELU backward on batch rows, transposes, memsets, scatter */
   GSS_PROF_ADAM = 11,
-  GSS_PROF_CLASSES = 12
+  GSS_PROF_COMM = 12,        /* sharded plans: all-gathers / all-reduces */
+  GSS_PROF_CLASSES = 13
 };
 int gss_plan_profile(gss_plan *p, int enable);
 int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void *stream);

@@ -56,6 +56,126 @@ def test_sharded_hip_matches_reference(world, case):
         assert np.abs(p - g["final_" + k]).max() < 2.5 * float(g["lr"]), k
 
 
+def _run_native(adj, X, params, L, batches, beta, world, decay=0.3, alpha=1.0, lr=3e-4, max_batch=None, fused_step=True, a_hat=None):
+    """the NATIVE sharded plan (gss_plan_create_sharded + gss_comm_create_local): `world` ranks as threads of this process,
+    each with its own stream on the one GPU -> per rank (losses, full embeddings, params, grads)"""
+    from gcn_drug_repurposing_amd.dist import local_comms, sharded_plan_engine
+    comms = local_comms(world)
+    results, errors = [None] * world, []
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                eng = sharded_plan_engine(adj, X, params, comms[rank], num_layers=L, layer_decay=decay, alpha=alpha, lr=lr,
+                                          max_batch=max_batch, device=torch.device("cuda:0"), a_hat=a_hat)
+                losses = []
+                for idx in batches:
+                    t = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).cuda()
+                    if fused_step:
+                        eng.step(t, beta)
+                    else:
+                        eng.forward()
+                        eng.loss_backward(t, beta)
+                        eng.adam()
+                    losses.append(float(eng.loss.item()))
+                emb = eng.gather_embeddings().cpu().numpy()
+                torch.cuda.current_stream().synchronize()
+                results[rank] = (losses, emb, [p.cpu().numpy() for p in eng.params], [g.cpu().numpy() for g in eng.grads], eng.part.bounds.copy())
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    assert not errors, errors
+    assert all(r is not None for r in results), "a rank thread did not finish"
+    return results
+
+
+@pytest.mark.parametrize("fused_step", [True, False])
+@pytest.mark.parametrize("world,case", [(1, "edge_n600_d128_L2"), (2, "edge_n600_d128_L2"), (3, "knn_n2000_d64_L3"), (4, "knn_n200_d16_L2"),
+                                        (8, "toy_sif_d64_L2")])
+def test_native_sharded_plan_matches_reference(world, case, fused_step):
+    """C1-C3 inside the C++ plan.  toy_sif at world 8 has more shards than some ranks have rows (empty shards)."""
+    g = load_golden(case)
+    n, d, L = (int(v) for v in g["meta"])
+    res = _run_native(golden_csr(g, "A"), g["X"], golden_params(g, "init"), L, golden_batches(g), float(g["beta"]), world,
+                      decay=float(g["decay"]), alpha=float(g["alpha"]), lr=float(g["lr"]), fused_step=fused_step)
+    for r in range(1, world):
+        assert res[r][0] == res[0][0]                       # replicated state is bit-identical on every rank
+        np.testing.assert_array_equal(res[r][1], res[0][1])
+        for a, b in zip(res[r][2], res[0][2]):
+            np.testing.assert_array_equal(a, b)
+    losses, emb, params, _, _ = res[0]
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-4, atol=1e-8)
+    assert np.abs(emb - g["emb_last"]).max() / np.abs(g["emb_last"]).max() < 2e-3
+    for k, p in zip(("W1", "b1", "W2", "b2"), params):
+        assert np.abs(p - g["final_" + k]).max() < 2.5 * float(g["lr"]), k
+
+
+def test_native_sharded_plan_first_step_equals_single_gpu_plan():
+    """one forward + loss + backward, world 3 vs the single-GPU plan on the same inputs: embeddings and loss bit-identical
+    (row results do not depend on the shard), gradients to fp32 summation order"""
+    from gcn_drug_repurposing_amd.engine import GssEngine
+    from gcn_drug_repurposing_amd.graph import GssGraph
+    g = load_golden("knn_n2000_d64_L3")
+    n, d, L = (int(v) for v in g["meta"])
+    idx = golden_batches(g)[0]
+    res = _run_native(golden_csr(g, "A"), g["X"], golden_params(g, "init"), L, [idx], float(g["beta"]), 3, decay=float(g["decay"]),
+                      alpha=float(g["alpha"]), lr=float(g["lr"]), fused_step=False, a_hat=golden_csr(g, "Ahat"))
+    graph = GssGraph.from_normalized(golden_csr(g, "Ahat"))
+    params = [torch.from_numpy(g["init_" + k].copy()).cuda() for k in ("W1", "b1", "W2", "b2")]
+    eng = GssEngine(graph, torch.from_numpy(g["X"]).cuda(), params, num_layers=L, layer_decay=float(g["decay"]), alpha=float(g["alpha"]),
+                    lr=float(g["lr"]))
+    eng.forward()
+    emb1 = eng.emb.cpu().numpy().copy()
+    eng.loss_backward(torch.from_numpy(idx.astype(np.int32)).cuda(), float(g["beta"]))
+    np.testing.assert_array_equal(res[0][1], emb1)          # the embeddings of the forward (Adam does not touch them)
+    assert res[0][0][0] == float(eng.loss.item())
+    for got, ref in zip(res[0][3], eng.grads):
+        ref = ref.cpu().numpy()
+        assert np.abs(got - ref).max() < 1e-5 * np.abs(ref).max() + 1e-12
+
+
+def test_native_collectives_local_backend():
+    """gss_allgather_rows / gss_allreduce_sum through the in-process backend, uneven shards"""
+    from gcn_drug_repurposing_amd.dist import local_comms
+    world, d, maxr = 3, 16, 5
+    rows = [5, 3, 0]
+    comms = local_comms(world)
+    out, errors = [None] * world, []
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                src = torch.zeros(maxr, d, device="cuda")
+                src[:rows[rank]] = rank + 1 + torch.arange(rows[rank], device="cuda").float()[:, None]
+                dst = torch.full((world * maxr, d), -1.0, device="cuda")
+                comms[rank].all_gather_rows(src, dst)
+                t = torch.full((7,), float(rank + 1), device="cuda")
+                comms[rank].all_reduce_sum_(t)
+                torch.cuda.current_stream().synchronize()
+                out[rank] = (dst.cpu(), t.cpu())
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not errors, errors
+    for r in range(world):
+        dst, t = out[r]
+        assert torch.equal(t, torch.full((7,), 6.0))
+        for o in range(world):
+            blk = dst[o * maxr:(o + 1) * maxr]
+            for k in range(rows[o]):
+                assert torch.equal(blk[k], torch.full((d,), float(o + 1 + k)))
+            assert torch.equal(blk[rows[o]:], torch.zeros(maxr - rows[o], d))
+
+
 def test_bench_sharded_path_over_rccl_single_rank(tmp_path):
     """bench.py's multi-GPU branch (torch.distributed 'nccl' == RCCL, TorchComm, ShardedEngine) with one rank, launched
     the way the driver launches it; must agree with the single-GPU plan's loss after the same steps."""
