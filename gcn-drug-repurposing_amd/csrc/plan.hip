@@ -254,6 +254,11 @@ static int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss
   Carver real;
   real.base = p->slab;
   carve(p, real);
+  if (desc->n == 0) {  // an empty shard: launchers still want non-null operands (they move zero rows)
+    if (!p->x) p->x = p->m_tmp;
+    if (!p->emb) p->emb = p->x_last;
+    p->xin[0] = const_cast<float *>(p->x);
+  }
   p->side = nullptr;
   p->ev_main_ready = p->ev_side_done = nullptr;
   p->cur0 = 0;
