@@ -33,8 +33,13 @@ class PprDesc(C.Structure):
                 + [(k, C.c_void_p) for k in ("sel_col", "sel_row", "sel_val", "keep_ptr", "keep_row", "keep_val")])
 
 
+class HaloDesc(C.Structure):
+    _fields_ = [("h_recv_off", C.c_void_p), ("h_send_off", C.c_void_p), ("d_send_rows", C.c_void_p)]
+
+
 class ShardDesc(C.Structure):
-    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("max_rows", C.c_int32), ("h_bounds", C.c_void_p)]
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("h_bounds", C.c_void_p), ("halo_a", HaloDesc), ("halo_at", HaloDesc),
+                ("d_gid2op_t", C.c_void_p)]
 
 
 class PlanIO(C.Structure):
@@ -73,6 +78,7 @@ SIGNATURES = {
     "gss_allgather_rows": (C.c_int, [_P, _I32, _I32, _P, _P, _P]),
     "gss_allgather_bytes": (C.c_int, [_P, _P, _P, _SZ, _P]),
     "gss_allreduce_sum": (C.c_int, [_P, _P, _I64, _P]),
+    "gss_exchange_rows": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P]),
     "gss_adam_step": (C.c_int, [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P, _I32, _P]),
     "gss_percentile": (C.c_int, [_I32, _I32, _P, _D, C.POINTER(_F), _P]),
     "gss_knn_topk": (C.c_int, [_I32, _I32, _P, _I32, _P, _P, _P]),

@@ -54,6 +54,21 @@ struct RcclComm final : gss_comm {
     if (nbuf > 1) GSS_NCCL(ncclGroupEnd());
     return GSS_OK;
   }
+  int exchange_rows(const float *send, const int64_t *send_off, float *recv, const int64_t *recv_off, int d, hipStream_t st) override {
+    // halo exchange: one fused group of point-to-point transfers, each over the xGMI link of its pair; pairs with an empty
+    // list are skipped
+    GSS_NCCL(ncclGroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (int q = 0; q < world && r == ncclSuccess; ++q) {
+      if (q == rank) continue;
+      const int64_t ns = send_off[q + 1] - send_off[q], nr = recv_off[q + 1] - recv_off[q];
+      if (ns > 0) r = ncclSend(send + (size_t)send_off[q] * d, (size_t)ns * d, ncclFloat, q, comm, st);
+      if (nr > 0 && r == ncclSuccess) r = ncclRecv(recv + (size_t)recv_off[q] * d, (size_t)nr * d, ncclFloat, q, comm, st);
+    }
+    const ncclResult_t e = ncclGroupEnd();
+    if (r != ncclSuccess || e != ncclSuccess) return fail(GSS_EHIP, "halo exchange (ncclSend/ncclRecv group) -> %s", ncclGetErrorString(r != ncclSuccess ? r : e));
+    return GSS_OK;
+  }
 };
 
 // ---- local (threads of one process) --------------------------------------------------------------------------
@@ -65,7 +80,8 @@ struct LocalShared {
   uint64_t generation = 0;
   bool broken = false;
   std::vector<const void *> src;
-  explicit LocalShared(int w) : world(w), src((size_t)w, nullptr) {}
+  std::vector<const int64_t *> off;  // exchange_rows: every rank's send offsets (host arrays, valid between the two barriers)
+  explicit LocalShared(int w) : world(w), src((size_t)w, nullptr), off((size_t)w, nullptr) {}
   // timed barrier: a rank that failed elsewhere must not hang the others forever
   int wait() {
     std::unique_lock<std::mutex> lk(mu);
@@ -112,6 +128,23 @@ struct LocalComm final : gss_comm {
     }
     GSS_HIP(hipStreamSynchronize(st));
     return sh->wait();  // nobody overwrites its send buffer while a peer still reads it
+  }
+  int exchange_rows(const float *send, const int64_t *send_off, float *recv, const int64_t *recv_off, int d, hipStream_t st) override {
+    GSS_HIP(hipStreamSynchronize(st));  // my packed rows are complete
+    sh->src[(size_t)rank] = send;
+    sh->off[(size_t)rank] = send_off;
+    if (int rc = sh->wait()) return rc;
+    for (int q = 0; q < world; ++q) {
+      if (q == rank) continue;
+      const int64_t nr = recv_off[q + 1] - recv_off[q];
+      if (nr <= 0) continue;
+      const int64_t theirs = sh->off[(size_t)q][rank + 1] - sh->off[(size_t)q][rank];
+      if (theirs != nr) return fail(GSS_EINVAL, "local comm: rank %d expects %lld rows from rank %d, which sends %lld", rank, (long long)nr, q, (long long)theirs);
+      const float *src = (const float *)sh->src[(size_t)q] + (size_t)sh->off[(size_t)q][rank] * d;
+      GSS_HIP(hipMemcpyAsync(recv + (size_t)recv_off[q] * d, src, sizeof(float) * (size_t)nr * d, hipMemcpyDeviceToDevice, st));
+    }
+    GSS_HIP(hipStreamSynchronize(st));
+    return sh->wait();
   }
   int all_reduce_sum(float *const *bufs, const size_t *counts, int nbuf, hipStream_t st) override {
     for (int k = 0; k < nbuf; ++k) {
@@ -190,28 +223,26 @@ int32_t gss_comm_rank(const gss_comm *c) { return c ? c->rank : -1; }
 int gss_allgather_rows(gss_comm *c, int32_t d, int32_t max_rows, const float *src, float *dst_padded, void *stream) {
   GSS_REQUIRE(c && src && dst_padded && d > 0 && max_rows >= 0, "allgather_rows: bad argument");
   if (max_rows == 0) return GSS_OK;
-  const size_t bytes = sizeof(float) * (size_t)max_rows * d;
-  if (c->world == 1) {
-    if (src != dst_padded) GSS_HIP(hipMemcpyAsync(dst_padded, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
-    return GSS_OK;
-  }
-  return c->all_gather(src, dst_padded, bytes, as_stream(stream));
+  return c->all_gather(src, dst_padded, sizeof(float) * (size_t)max_rows * d, as_stream(stream));
 }
 
 int gss_allgather_bytes(gss_comm *c, const void *src, void *dst, size_t bytes_per_rank, void *stream) {
   GSS_REQUIRE(c && src && dst, "allgather_bytes: bad argument");
   if (bytes_per_rank == 0) return GSS_OK;
-  if (c->world == 1) {
-    if (src != dst) GSS_HIP(hipMemcpyAsync(dst, src, bytes_per_rank, hipMemcpyDeviceToDevice, as_stream(stream)));
-    return GSS_OK;
-  }
   return c->all_gather(src, dst, bytes_per_rank, as_stream(stream));
 }
 
 int gss_allreduce_sum(gss_comm *c, float *buf, int64_t count, void *stream) {
   GSS_REQUIRE(c && buf && count >= 0, "allreduce_sum: bad argument");
-  if (count == 0 || c->world == 1) return GSS_OK;
+  if (count == 0) return GSS_OK;
   const size_t cnt = (size_t)count;
   return c->all_reduce_sum(&buf, &cnt, 1, as_stream(stream));
+}
+
+int gss_exchange_rows(gss_comm *c, int32_t d, const float *send, const int64_t *h_send_off, float *recv, const int64_t *h_recv_off, void *stream) {
+  GSS_REQUIRE(c && d > 0 && h_send_off && h_recv_off, "exchange_rows: bad argument");
+  GSS_REQUIRE((send || h_send_off[c->world] == h_send_off[0]) && (recv || h_recv_off[c->world] == h_recv_off[0]), "exchange_rows: null buffer");
+  if (c->world == 1) return GSS_OK;
+  return c->exchange_rows(send, h_send_off, recv, h_recv_off, d, as_stream(stream));
 }
 }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(int b, int d4, co
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)b * d4) return;
   const int r = (int)(i / d4), f4 = (int)(i % d4);
-  if (pos_clear && f4 == 0) pos_clear[pos_ids[r]] = -1;
+  if (pos_clear && f4 == 0 && pos_ids[r] >= 0) pos_clear[pos_ids[r]] = -1;
   if (rows[r] < 0 || (keep && keep[r] == 0.f)) return;  // not a row of this shard
   float *p = dst + ((size_t)rows[r] * d4 + f4) * 4;
   st4(p, add4(ld4(p), ld4(src + i * 4)));
@@ -110,10 +110,11 @@ __global__ void shard_batch_maps_kernel(const int32_t *__restrict__ idx, int b, 
   if (mine) pos_row[rel] = i;
 }
 
-// per-batch maps of a sharded plan: pid = padded global id (owner * maxr + offset in the owner's range), rloc = the local
-// row clamped into this shard (any owned row where the shard has no say), keep = 1.0 / 0.0 for owned / foreign rows
-__global__ void shard_batch_ids_kernel(const int32_t *__restrict__ idx, int b, int lo, int nl, const int64_t *__restrict__ bounds, int world,
-                                       int maxr, int32_t *__restrict__ pid, int32_t *__restrict__ rloc, float *__restrict__ keep) {
+// per-batch maps of a sharded plan: pid = the member's operand row in A_hat^T's column space (own rows first, then the
+// halo; -1 where this shard never reads the node), rloc = the local row clamped into this shard (any owned row where the
+// shard has no say), keep = 1.0 / 0.0 for owned / foreign rows
+__global__ void shard_batch_ids_kernel(const int32_t *__restrict__ idx, int b, int lo, int nl, const int32_t *__restrict__ gid2op,
+                                       int32_t *__restrict__ pid, int32_t *__restrict__ rloc, float *__restrict__ keep) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b) return;
   const int id = idx[i];
@@ -121,9 +122,16 @@ __global__ void shard_batch_ids_kernel(const int32_t *__restrict__ idx, int b, i
   const bool mine = rel >= 0 && rel < nl;
   rloc[i] = min(max(rel, 0), max(nl - 1, 0));
   keep[i] = mine ? 1.f : 0.f;
-  int o = 0;
-  while (o + 1 < world && (int64_t)id >= bounds[o + 1]) ++o;
-  pid[i] = o * maxr + (id - (int)bounds[o]);
+  pid[i] = gid2op ? gid2op[id] : (mine ? rel : -1);
+}
+
+// halo exchange, sender side: out[k] = src[rows[k]] -- the rows the peers reference, packed in peer order
+__global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n, int d4, const float *__restrict__ src, const int32_t *__restrict__ rows,
+                                                        float *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)n * d4) return;
+  const size_t r = i / d4, f4 = i % d4;
+  st4(out + i * 4, ld4(src + ((size_t)rows[r] * d4 + f4) * 4));
 }
 
 // ---- K10  torch.optim.Adam (single-tensor form of torch/optim/adam.py; train.py:139-141,184) -------
@@ -161,7 +169,7 @@ struct Adam4 {
 __global__ __launch_bounds__(256) void adam4_kernel(Adam4 a, float lr_over_bc1, float inv_sqrt_bc2, float beta1, float beta2,
                                                     float eps) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (a.pos_clear && i < a.b) a.pos_clear[a.ids[i]] = -1;
+  if (a.pos_clear && i < a.b && a.ids[i] >= 0) a.pos_clear[a.ids[i]] = -1;
   if (i >= a.start[4]) return;
   const int k = i < a.start[1] ? 0 : i < a.start[2] ? 1 : i < a.start[3] ? 2 : 3;
   const int64_t j = i - a.start[k];
@@ -285,13 +293,21 @@ int adam_step(int64_t count, float *param, const float *grad, float *m, float *v
   return GSS_OK;
 }
 
-int shard_batch_ids(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
-                    int32_t *pid, int32_t *rloc, float *keep, void *stream) {
-  GSS_REQUIRE(b >= 0 && nl >= 0 && world >= 1 && maxr >= 1 && idx && bounds && pid && rloc && keep, "shard_batch_ids: bad argument");
+int shard_batch_ids(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int32_t *gid2op, int32_t *pid, int32_t *rloc, float *keep,
+                    void *stream) {
+  GSS_REQUIRE(b >= 0 && nl >= 0 && idx && pid && rloc && keep, "shard_batch_ids: bad argument");
   if (b == 0) return GSS_OK;
-  hipLaunchKernelGGL(shard_batch_ids_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, as_stream(stream), idx, b, lo, nl, bounds, world, maxr, pid,
-                     rloc, keep);
+  hipLaunchKernelGGL(shard_batch_ids_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, as_stream(stream), idx, b, lo, nl, gid2op, pid, rloc, keep);
   GSS_LAUNCH_CHECK("shard_batch_ids_kernel");
+  return GSS_OK;
+}
+
+int pack_rows(int32_t d, const float *src, const int32_t *rows, int64_t n, float *out, void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(n >= 0 && (n == 0 || (src && rows && out)), "pack_rows: null operand");
+  if (n == 0) return GSS_OK;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(n * (d / 4), 256)), dim3(256), 0, as_stream(stream), n, d / 4, src, rows, out);
+  GSS_LAUNCH_CHECK("pack_rows_kernel");
   return GSS_OK;
 }
 

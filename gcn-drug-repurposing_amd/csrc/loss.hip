@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void loss_finish_bwd_kernel(int b, int d4, int
   if (!ok) return;
   // idx: row of inv_den / p (this shard's local row); pos_ids: the id the batch-position map is keyed by (the same array on
   // one GPU, the padded global id on a shard); keep[r] == 0: another shard owns the row -> zero gradient here
-  if (pos_set && li == 0) pos_set[pos_ids[r]] = r;
+  if (pos_set && li == 0 && pos_ids[r] >= 0) pos_set[pos_ids[r]] = r;
   const float inv = (!keep || keep[r] != 0.f) ? inv_den[node] : 0.f;
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {

@@ -25,6 +25,9 @@ struct gss_comm {
   virtual int all_gather(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) = 0;
   // in place, nbuf tensors as one fused operation; identical bits on every rank
   virtual int all_reduce_sum(float *const *bufs, const size_t *counts, int nbuf, hipStream_t st) = 0;
+  // halo exchange: rows [send_off[q], send_off[q+1]) of `send` go to rank q, rows from rank q land at [recv_off[q], recv_off[q+1])
+  // of `recv` (row = d floats; offsets are host arrays of world + 1 entries; own entries are empty)
+  virtual int exchange_rows(const float *send, const int64_t *send_off, float *recv, const int64_t *recv_off, int d, hipStream_t st) = 0;
 };
 
 namespace gss {
@@ -63,8 +66,9 @@ int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b,
 // dst[rows[r]] += src[r] unless rows[r] < 0 or keep[r] == 0 (keep nullable); pos_clear != NULL: also pos_clear[pos_ids[r]] = -1
 int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, const float *keep, int32_t b, float *dst, int32_t *pos_clear,
                      const int32_t *pos_ids, void *stream);
-int shard_batch_ids(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
-                    int32_t *pid, int32_t *rloc, float *keep, void *stream);
+int shard_batch_ids(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int32_t *gid2op, int32_t *pid, int32_t *rloc, float *keep,
+                    void *stream);
+int pack_rows(int32_t d, const float *src, const int32_t *rows, int64_t n, float *out, void *stream);
 int shard_batch_maps(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
                      int32_t *rows_all, int32_t *rows_own, float *keep, int32_t *pos_col, int32_t *pos_row, void *stream);
 int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,

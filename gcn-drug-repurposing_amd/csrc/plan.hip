@@ -1,10 +1,17 @@
-// plan.hip -- one training replica: owns every activation / gradient buffer and enqueues a whole
-// iteration of train.py:155-184 (forward, gss_loss, backward, Adam) from a single host call, so
-// the kernels of a step (11 launches at L = 2) are launched back to back from C++ with no Python in between.
+// plan.hip -- one training replica, or one node-range shard of one: owns every activation / gradient buffer and
+// enqueues a whole iteration of train.py:155-184 (forward, gss_loss, backward, Adam) from a single host call, so the
+// kernels of a step (11 launches at L = 2) and, on a shard, the collectives between them (comm.hip: halo exchanges and
+// all-reduces over RCCL) are issued back to back from C++ with no Python in between.
 //
 // Layer l (0-based) keeps x_l (input), AX_l, AM_l, P_l for the backward pass (model.py:163-173).
 // The backward pass exploits that dLoss/dE is non-zero only on the B batch rows: normalise-bwd,
 // ELU-bwd, the top layer's weight gradient and its input gradient run on B rows instead of N.
+//
+// Sharding: rank r owns rows [bounds[r], bounds[r+1]) of A_hat, A_hat^T and of every activation.  An SpMM
+// operand is a [n + n_halo][d] buffer: the shard's own rows, written in place by the producing kernel, followed by the
+// rows of other shards its CSR references (the boundary features), which one fused group of point-to-point transfers
+// fetches before the hop.  The CSR column ids are operand rows.  A single-GPU plan is the case P = 1 with empty halos.
+#include <algorithm>
 #include <vector>
 
 #include "ops.h"
@@ -17,11 +24,11 @@ struct gss_plan {
   // one slab, carved
   char *slab;
   size_t slab_bytes;
-  std::vector<float *> ax, am, p, xin;  // xin[l] = input of layer l (xin[0] = x)
+  std::vector<float *> ax, am, p, xin;  // xin[l] = input of layer l as an operand of A_hat (own rows, then halo)
   float *m_tmp, *x_last, *emb, *inv_den;
   float *g_ax, *g_am, *u, *t, *dp, *gx[2];
   float *de_b, *dx_b, *dp_b, *gax_b, *gam_b;
-  int32_t *pos;  // node -> batch position (-1 outside the batch) for the sparsity-aware backward SpMM
+  int32_t *pos;  // operand row of A_hat^T's column space -> batch position (-1 outside the batch), for the sparsity-aware backward SpMM
   float *w1t, *w2t;
   float *grad[4];
   float *adam_m[4], *adam_v[4];
@@ -45,19 +52,24 @@ struct gss_plan {
   size_t ev_used;
   double prof_ms[GSS_PROF_CLASSES];
   int64_t prof_cnt[GSS_PROF_CLASSES];
-  // node-range sharding.  A single-GPU plan is the case P = 1, rank = 0, maxr = n, comm = NULL: the
-  // gathers below return their argument and the all-reduces vanish.
-  gss_comm *comm;
-  int P, rank, maxr;           // shards, this shard, rows of the largest shard (local buffers hold maxr rows: equal send counts)
-  int lo;                      // first global node id of this shard
-  int64_t *d_bounds;           // device copy of the shard boundaries [P + 1]
+  // node-range sharding
+  gss_comm *comm;     // NULL on one GPU
+  int P, rank;
+  int lo;             // first global node id of this shard
   std::vector<int64_t> h_bounds;
-  float *full[2];              // receive buffers of the operand all-gathers, [P * maxr][d]
-  float *x0full;               // the gathered input features (constant: gathered once)
+  struct Halo {       // operand halo of one matrix (gss_halo_desc with the offsets copied)
+    int64_t n_halo = 0, n_send = 0;
+    std::vector<int64_t> recv_off, send_off;
+    const int32_t *d_send_rows = nullptr;
+  } halo_a, halo_t;
+  size_t rows_a, rows_t;   // operand rows of A_hat / A_hat^T: n + n_halo
+  const int32_t *gid2op_t; // node id -> operand row of A_hat^T's column space (borrowed), NULL on one GPU
+  float *sendbuf;          // packed rows for the peers, [max n_send][d]
+  float *x0op;             // the input features with their halo (constant: exchanged once); io.x itself on one GPU
   bool x0_ready;
-  int32_t *pid, *rloc;         // per batch: padded global id / local row (clamped) of every batch member
-  float *keep;                 // per batch: 1.0 where this shard owns the member
-  float *gab;                  // [2 * max_batch][d]: the top layer's compact input gradients, all-reduced as one buffer
+  int32_t *pid, *rloc;     // per batch: operand row in A_hat^T's column space (or -1) / local row (clamped) of every member
+  float *keep;             // per batch: 1.0 where this shard owns the member
+  float *gab;              // [2 * max_batch][d]: the top layer's compact input gradients, all-reduced as one buffer
 };
 
 using namespace gss;
@@ -105,17 +117,19 @@ struct Carver {
 
 void carve(gss_plan *p, Carver &c) {
   const gss_plan_desc &D = p->desc;
-  const size_t nd = (size_t)p->maxr * D.d;   // local buffers hold maxr >= n rows (all-gather send counts are equal)
+  const size_t n1 = (size_t)(D.n > 0 ? D.n : 1);
+  const size_t nd = n1 * D.d;                                  // a local [n][d] buffer
+  const size_t nd_a = (p->rows_a ? p->rows_a : 1) * D.d;       // an operand of A_hat: own rows + halo
+  const size_t nd_t = (p->rows_t ? p->rows_t : 1) * D.d;       // an operand of A_hat^T
   const size_t bd = (size_t)D.max_batch * D.d;
   const int L = D.num_layers;
   const bool sharded = p->P > 1;
-  p->full[0] = sharded ? c.take<float>(nd * p->P) : nullptr;
-  p->full[1] = sharded ? c.take<float>(nd * p->P) : nullptr;
-  p->x0full = sharded ? c.take<float>(nd * p->P) : nullptr;
+  const size_t n_send = (size_t)std::max(p->halo_a.n_send, p->halo_t.n_send);
+  p->sendbuf = sharded ? c.take<float>((n_send ? n_send : 1) * D.d) : nullptr;
+  p->x0op = sharded ? c.take<float>(nd_a) : const_cast<float *>(p->x);
   p->pid = sharded ? c.take<int32_t>(D.max_batch) : nullptr;
   p->rloc = sharded ? c.take<int32_t>(D.max_batch) : nullptr;
   p->keep = sharded ? c.take<float>(D.max_batch) : nullptr;
-  p->d_bounds = sharded ? c.take<int64_t>(p->P + 1) : nullptr;
   p->ax.assign(L, nullptr);
   p->am.assign(L, nullptr);
   p->p.assign(L, nullptr);
@@ -124,21 +138,21 @@ void carve(gss_plan *p, Carver &c) {
     p->ax[l] = c.take<float>(nd);
     p->am[l] = c.take<float>(nd);
     p->p[l] = c.take<float>(nd);
-    p->xin[l] = l == 0 ? const_cast<float *>(p->x) : c.take<float>(nd);
+    p->xin[l] = l == 0 ? p->x0op : c.take<float>(nd_a);       // layer inputs are operands of A_hat
   }
-  p->m_tmp = c.take<float>(nd);
+  p->m_tmp = c.take<float>(nd_a);
   p->ax0[0] = p->ax[0];
   p->am0[0] = p->am[0];
   const bool pipe = D.pipeline_layer1 != 0;
   p->ax0[1] = pipe ? c.take<float>(nd) : nullptr;
   p->am0[1] = pipe ? c.take<float>(nd) : nullptr;
-  p->m_side = pipe ? c.take<float>(nd) : nullptr;
+  p->m_side = pipe ? c.take<float>(nd_a) : nullptr;
   p->x_last = c.take<float>(nd);
-  p->inv_den = c.take<float>(p->maxr);
+  p->inv_den = c.take<float>(n1);
   if (L > 1) {
     p->g_ax = c.take<float>(nd);
-    p->g_am = c.take<float>(nd);
-    p->u = c.take<float>(nd);
+    p->g_am = c.take<float>(nd_t);                             // operands of A_hat^T
+    p->u = c.take<float>(nd_t);
     p->t = c.take<float>(nd);
     p->dp = c.take<float>(nd);
     p->gx[0] = L > 2 ? c.take<float>(nd) : nullptr;
@@ -149,9 +163,9 @@ void carve(gss_plan *p, Carver &c) {
   p->de_b = c.take<float>(bd);
   p->dx_b = c.take<float>(bd);
   p->dp_b = c.take<float>(bd);
-  p->gab = L > 1 ? c.take<float>(2 * bd) : nullptr;   // gax_b = gab, gam_b = gab + b * d (contiguous for one all-reduce)
+  p->gab = L > 1 ? c.take<float>(2 * bd) : nullptr;            // gax_b = gab, gam_b = gab + b * d: one all-reduce
   p->gax_b = p->gam_b = nullptr;
-  p->pos = L > 1 ? c.take<int32_t>((size_t)p->P * p->maxr) : nullptr;
+  p->pos = L > 1 ? c.take<int32_t>(p->rows_t ? p->rows_t : 1) : nullptr;
   p->w1t = c.take<float>((size_t)D.d * D.d);
   p->w2t = c.take<float>((size_t)D.d * D.d);
   const size_t cnt[4] = {(size_t)D.d * D.d, (size_t)D.d, (size_t)D.d * D.d, (size_t)D.d};
@@ -163,12 +177,26 @@ void carve(gss_plan *p, Carver &c) {
   const int wg_total = wgrad_slices_max(D.max_batch, D.d) + (L - 1) * wgrad_slices(D.n, D.d);
   p->wgrad_ws = c.take<char>(sizeof(float) * (size_t)wg_total * ((size_t)D.d * 2 * D.d + D.d));
 }
-}  // namespace
 
-extern "C" {
+bool halo_ok(const gss_halo_desc &h, int P, int rank) {
+  if (!h.h_recv_off || !h.h_send_off) return false;
+  if (h.h_recv_off[0] != 0 || h.h_send_off[0] != 0) return false;
+  for (int q = 0; q < P; ++q)
+    if (h.h_recv_off[q + 1] < h.h_recv_off[q] || h.h_send_off[q + 1] < h.h_send_off[q]) return false;
+  if (h.h_recv_off[rank + 1] != h.h_recv_off[rank] || h.h_send_off[rank + 1] != h.h_send_off[rank]) return false;  // nothing from / to itself
+  return h.h_send_off[P] == 0 || h.d_send_rows != nullptr;
+}
 
-static int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_desc *shard, gss_comm *comm, const gss_csr *a,
-                            const gss_csr *at, const gss_plan_io *io) {
+void take_halo(gss_plan::Halo &dst, const gss_halo_desc &h, int P) {
+  dst.recv_off.assign(h.h_recv_off, h.h_recv_off + P + 1);
+  dst.send_off.assign(h.h_send_off, h.h_send_off + P + 1);
+  dst.n_halo = dst.recv_off[(size_t)P];
+  dst.n_send = dst.send_off[(size_t)P];
+  dst.d_send_rows = h.d_send_rows;
+}
+
+int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_desc *shard, gss_comm *comm, const gss_csr *a,
+                     const gss_csr *at, const gss_plan_io *io) {
   GSS_REQUIRE(out && desc && a && io, "plan_create: null argument");
   GSS_REQUIRE(io->w1 && io->b1 && io->w2 && io->b2 && io->loss && io->gw1 && io->gb1 && io->gw2 && io->gb2,
               "plan_create: null pointer in gss_plan_io");
@@ -177,41 +205,51 @@ static int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss
   const int P = shard ? shard->world : 1;
   const int rank = shard ? shard->rank : 0;
   GSS_REQUIRE(desc->num_layers >= 1 && desc->num_layers <= 64, "plan_create: num_layers=%d", desc->num_layers);
-  GSS_REQUIRE(desc->n > 0 || P > 1, "plan_create: n=%d", desc->n);
+  GSS_REQUIRE(desc->n > 0 || (P > 1 && desc->n == 0), "plan_create: n=%d", desc->n);
   int64_t n_global = desc->n;
-  int maxr = desc->n;
+  int64_t ha = 0, hat = 0;
   if (shard) {
-    GSS_REQUIRE(P >= 1 && rank >= 0 && rank < P && shard->h_bounds && shard->max_rows >= 1, "plan_create_sharded: bad shard descriptor");
+    GSS_REQUIRE(P >= 1 && rank >= 0 && rank < P && shard->h_bounds, "plan_create_sharded: bad shard descriptor");
     GSS_REQUIRE(P == 1 || comm, "plan_create_sharded: world %d needs a communicator", P);
     GSS_REQUIRE(!comm || (comm->world == P && comm->rank == rank), "plan_create_sharded: communicator is rank %d of %d, shard is %d of %d",
                 comm ? comm->rank : -1, comm ? comm->world : -1, rank, P);
     GSS_REQUIRE(shard->h_bounds[0] == 0, "plan_create_sharded: bounds[0] must be 0");
-    for (int r = 0; r < P; ++r) {
-      const int64_t rows = shard->h_bounds[r + 1] - shard->h_bounds[r];
-      GSS_REQUIRE(rows >= 0 && rows <= shard->max_rows, "plan_create_sharded: shard %d has %lld rows, max_rows=%d", r, (long long)rows,
-                  shard->max_rows);
-    }
+    for (int r = 0; r < P; ++r) GSS_REQUIRE(shard->h_bounds[r + 1] >= shard->h_bounds[r], "plan_create_sharded: bounds not monotone at %d", r);
     n_global = shard->h_bounds[P];
+    GSS_REQUIRE(n_global > 0 && n_global < (int64_t)INT32_MAX, "plan_create_sharded: N=%lld", (long long)n_global);
     GSS_REQUIRE(shard->h_bounds[rank + 1] - shard->h_bounds[rank] == desc->n, "plan_create_sharded: desc->n=%d is not this shard's row count",
                 desc->n);
-    GSS_REQUIRE((int64_t)P * shard->max_rows < (int64_t)INT32_MAX, "plan_create_sharded: world * max_rows overflows int32");
     GSS_REQUIRE(!desc->pipeline_layer1 || P == 1, "plan_create_sharded: pipeline_layer1 is a single-GPU option");
-    maxr = P > 1 ? shard->max_rows : desc->n;
+    if (P > 1) {
+      GSS_REQUIRE(halo_ok(shard->halo_a, P, rank), "plan_create_sharded: malformed halo descriptor of A_hat");
+      ha = shard->halo_a.h_recv_off[P];
+      if (desc->num_layers > 1) {
+        GSS_REQUIRE(halo_ok(shard->halo_at, P, rank) && shard->d_gid2op_t, "plan_create_sharded: malformed halo descriptor of A_hat^T");
+        hat = shard->halo_at.h_recv_off[P];
+      }
+      GSS_REQUIRE(desc->n + ha < (int64_t)INT32_MAX && desc->n + hat < (int64_t)INT32_MAX, "plan_create_sharded: operand rows overflow int32");
+    }
   }
   GSS_REQUIRE(desc->max_batch >= 1 && (int64_t)desc->max_batch <= n_global, "plan_create: max_batch=%d out of [1, N=%lld]", desc->max_batch,
               (long long)n_global);
-  const int ncols = P > 1 ? P * maxr : desc->n;
-  GSS_REQUIRE(a->n_rows == desc->n && a->n_cols == ncols, "plan_create: A is %d x %d, expected %d x %d", a->n_rows, a->n_cols, desc->n, ncols);
-  GSS_REQUIRE(desc->num_layers == 1 || (at && at->n_rows == desc->n && at->n_cols == ncols),
+  GSS_REQUIRE(a->n_rows == desc->n && a->n_cols == desc->n + ha, "plan_create: A is %d x %d, expected %d x %lld", a->n_rows, a->n_cols, desc->n,
+              (long long)(desc->n + ha));
+  GSS_REQUIRE(desc->num_layers == 1 || (at && at->n_rows == desc->n && at->n_cols == desc->n + hat),
               "plan_create: A^T missing or mis-shaped (needed for num_layers >= 2)");
   gss_plan *p = new gss_plan();
   p->desc = *desc;
   p->comm = P > 1 ? comm : nullptr;
   p->P = P;
   p->rank = rank;
-  p->maxr = maxr;
   p->lo = shard ? (int)shard->h_bounds[rank] : 0;
   if (shard) p->h_bounds.assign(shard->h_bounds, shard->h_bounds + P + 1);
+  if (P > 1) {
+    take_halo(p->halo_a, shard->halo_a, P);
+    if (desc->num_layers > 1) take_halo(p->halo_t, shard->halo_at, P);
+  }
+  p->rows_a = (size_t)desc->n + (size_t)ha;
+  p->rows_t = (size_t)desc->n + (size_t)hat;
+  p->gid2op_t = (P > 1 && desc->num_layers > 1) ? shard->d_gid2op_t : nullptr;
   p->x0_ready = false;
   p->a = a;
   p->at = at;
@@ -255,9 +293,8 @@ static int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss
   real.base = p->slab;
   carve(p, real);
   if (desc->n == 0) {  // an empty shard: launchers still want non-null operands (they move zero rows)
-    if (!p->x) p->x = p->m_tmp;
+    if (!p->x) p->x = p->x_last;
     if (!p->emb) p->emb = p->x_last;
-    p->xin[0] = const_cast<float *>(p->x);
   }
   p->side = nullptr;
   p->ev_main_ready = p->ev_side_done = nullptr;
@@ -274,50 +311,56 @@ static int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss
     }
   }
   if (p->pos) {
-    e = hipMemset(p->pos, 0xff, sizeof(int32_t) * (size_t)P * maxr);  // all -1
+    e = hipMemset(p->pos, 0xff, sizeof(int32_t) * (p->rows_t ? p->rows_t : 1));  // all -1
     if (e != hipSuccess) {
       (void)hipFree(p->slab);
       delete p;
       return fail(GSS_EHIP, "plan_create: hipMemset(pos) -> %s", hipGetErrorString(e));
     }
   }
-  if (p->d_bounds) {
-    e = hipMemcpy(p->d_bounds, shard->h_bounds, sizeof(int64_t) * (size_t)(P + 1), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-      (void)hipFree(p->slab);
-      delete p;
-      return fail(GSS_EHIP, "plan_create: copy of the shard bounds -> %s", hipGetErrorString(e));
-    }
-  }
   *out = p;
   return GSS_OK;
 }
 
-int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a, const gss_csr *at, const gss_plan_io *io) {
-  return plan_create_impl(out, desc, nullptr, nullptr, a, at, io);
+// ---- exchange points of a sharded plan (no-ops on one GPU) ------------------------------------------------------
+// C1, boundary form: `op` is an operand whose own rows [0, n) are complete; fetch its halo rows [n, n + n_halo) from their
+// owners and serve the peers the rows they reference
+int plan_halo(gss_plan *p, const gss_plan::Halo &h, float *op, void *stream) {
+  if (p->P == 1) return GSS_OK;
+  PROF(GSS_PROF_COMM);
+  const int d = p->desc.d;
+  if (h.n_send > 0)
+    if (int rc = pack_rows(d, op, h.d_send_rows, h.n_send, p->sendbuf, stream)) return rc;
+  return p->comm->exchange_rows(p->sendbuf, h.send_off.data(), op + (size_t)p->desc.n * d, h.recv_off.data(), d, as_stream(stream));
 }
 
-int gss_plan_create_sharded(gss_plan **out, const gss_plan_desc *desc, const gss_shard_desc *shard, gss_comm *comm, const gss_csr *a,
-                            const gss_csr *at, const gss_plan_io *io) {
-  GSS_REQUIRE(shard, "plan_create_sharded: null shard descriptor");
-  return plan_create_impl(out, desc, shard, comm, a, at, io);
+int plan_allreduce(gss_plan *p, float *buf, size_t count, void *stream) {
+  if (p->P == 1 || count == 0) return GSS_OK;
+  PROF(GSS_PROF_COMM);
+  return p->comm->all_reduce_sum(&buf, &count, 1, as_stream(stream));
 }
 
-void gss_plan_destroy(gss_plan *p) {
-  if (!p) return;
-  for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
-  if (p->side) {
-    (void)hipStreamSynchronize(p->side);
-    (void)hipStreamDestroy(p->side);
-  }
-  if (p->ev_main_ready) (void)hipEventDestroy(p->ev_main_ready);
-  if (p->ev_side_done) (void)hipEventDestroy(p->ev_side_done);
-  if (p->slab) (void)hipFree(p->slab);
-  delete p;
+// C2: the four weight-gradient tensors summed over the shards, one fused collective
+int plan_allreduce_grads(gss_plan *p, void *stream) {
+  if (p->P == 1) return GSS_OK;
+  PROF(GSS_PROF_COMM);
+  const gss_plan_desc &D = p->desc;
+  const size_t cnt[4] = {(size_t)D.d * D.d, (size_t)D.d, (size_t)D.d * D.d, (size_t)D.d};
+  return p->comm->all_reduce_sum(p->grad, cnt, 4, as_stream(stream));
+}
+
+// the input features never change: their halo is fetched once
+int plan_x0(gss_plan *p, void *stream) {
+  if (p->P == 1 || p->x0_ready) return GSS_OK;
+  if (p->desc.n > 0)
+    GSS_HIP(hipMemcpyAsync(p->x0op, p->x, sizeof(float) * (size_t)p->desc.n * p->desc.d, hipMemcpyDeviceToDevice, as_stream(stream)));
+  if (int rc = plan_halo(p, p->halo_a, p->x0op, stream)) return rc;
+  p->x0_ready = true;
+  return GSS_OK;
 }
 
 // enqueue layer 1's SpMMs for the NEXT step on the side stream, to start once the main stream reaches this point
-static int plan_prefetch_layer1(gss_plan *p, void *main_stream) {
+int plan_prefetch_layer1(gss_plan *p, void *main_stream) {
   const gss_plan_desc &D = p->desc;
   const int nxt = p->cur0 ^ 1;
   // everything step t-1 read from buffer set `nxt` precedes this point of the main stream
@@ -337,44 +380,7 @@ static int plan_prefetch_layer1(gss_plan *p, void *main_stream) {
   return GSS_OK;
 }
 
-// ---- exchange points of a sharded plan (no-ops on one GPU) ------------------------------------------------------
-// all-gather the maxr local rows of `local` into receive buffer `which`; returns the [P * maxr][d] operand
-static int plan_gather(gss_plan *p, const float *local, int which, const float **full, void *stream) {
-  if (p->P == 1) {
-    *full = local;
-    return GSS_OK;
-  }
-  PROF(GSS_PROF_COMM);
-  *full = p->full[which];
-  return p->comm->all_gather(local, p->full[which], sizeof(float) * (size_t)p->maxr * p->desc.d, as_stream(stream));
-}
-
-static int plan_allreduce(gss_plan *p, float *buf, size_t count, void *stream) {
-  if (p->P == 1 || count == 0) return GSS_OK;
-  PROF(GSS_PROF_COMM);
-  return p->comm->all_reduce_sum(&buf, &count, 1, as_stream(stream));
-}
-
-// the input features never change: every shard's rows are distributed once
-static int plan_x0(gss_plan *p, const float **full, void *stream) {
-  if (p->P == 1) {
-    *full = p->x;
-    return GSS_OK;
-  }
-  if (!p->x0_ready) {
-    PROF(GSS_PROF_COMM);
-    const size_t slot = (size_t)p->maxr * p->desc.d;
-    float *mine = p->x0full + (size_t)p->rank * slot;
-    if (p->desc.n > 0)
-      GSS_HIP(hipMemcpyAsync(mine, p->x, sizeof(float) * (size_t)p->desc.n * p->desc.d, hipMemcpyDeviceToDevice, as_stream(stream)));
-    if (int rc = p->comm->all_gather(mine, p->x0full, sizeof(float) * slot, as_stream(stream))) return rc;  // in place
-    p->x0_ready = true;
-  }
-  *full = p->x0full;
-  return GSS_OK;
-}
-
-static int plan_forward_impl(gss_plan *p, void *stream, bool pipelined = false) {
+int plan_forward_impl(gss_plan *p, void *stream) {
   GSS_REQUIRE(p, "plan_forward: null plan");
   const gss_plan_desc &D = p->desc;
   const int L = D.num_layers;
@@ -389,27 +395,24 @@ static int plan_forward_impl(gss_plan *p, void *stream, bool pipelined = false) 
     have_l0 = true;
   }
   for (int l = 0; l < L; ++l) {
-    const float *xl = p->xin[l];
+    float *xl = p->xin[l];
     const bool cached = (l == 0 && ((D.cache_layer1 && p->layer1_valid) || have_l0));
-    (void)pipelined;
     if (!cached) {
-      // AX = A x ; M = AX (.) x      (model.py:163,168); x gathered from every shard (C1)
-      const float *xf = nullptr;
+      // AX = A x ; M = AX (.) x      (model.py:163,168); x's boundary rows come from their owners (C1)
       if (l == 0) {
-        if (int rc = plan_x0(p, &xf, stream)) return rc;
+        if (int rc = plan_x0(p, stream)) return rc;
       } else {
-        if (int rc = plan_gather(p, xl, 0, &xf, stream)) return rc;
+        if (int rc = plan_halo(p, p->halo_a, xl, stream)) return rc;
       }
       {
         PROF(GSS_PROF_SPMM_FWD_HAD);
-        if (int rc = spmm_fwd(p->a, D.d, xf, p->ax[l], xl, p->m_tmp, stream)) return rc;
+        if (int rc = spmm_fwd(p->a, D.d, xl, p->ax[l], xl, p->m_tmp, stream)) return rc;
       }
       // AM = A M                      (model.py:169)
-      const float *mf = nullptr;
-      if (int rc = plan_gather(p, p->m_tmp, 1, &mf, stream)) return rc;
+      if (int rc = plan_halo(p, p->halo_a, p->m_tmp, stream)) return rc;
       {
         PROF(GSS_PROF_SPMM_FWD);
-        if (int rc = spmm_fwd(p->a, D.d, mf, p->am[l], nullptr, nullptr, stream)) return rc;
+        if (int rc = spmm_fwd(p->a, D.d, p->m_tmp, p->am[l], nullptr, nullptr, stream)) return rc;
       }
       if (l == 0) p->layer1_valid = true;
     }
@@ -428,31 +431,29 @@ static int plan_forward_impl(gss_plan *p, void *stream, bool pipelined = false) 
   return rownorm_fwd(D.n, D.d, p->x_last, p->emb, p->inv_den, stream);
 }
 
-static int plan_allreduce_grads(gss_plan *p, void *stream);
-
 // What the kernels index a batch with.  One GPU: the node ids themselves.  A shard: `rows` = the local row of every
-// batch member clamped into the shard (foreign rows get zero gradients through `keep`), `ids` = the padded global ids
-// the batch-position map is keyed by.
+// batch member clamped into the shard (foreign rows get zero gradients through `keep`), `ids` = the member's operand row
+// in A_hat^T's column space (the key of the batch-position map; -1 where this shard never reads the node).
 struct BatchView {
   const int32_t *rows, *ids;
   const float *keep;
 };
 
-static int plan_batch_view(gss_plan *p, const int32_t *idx, int32_t b, BatchView &v, void *stream) {
+int plan_batch_view(gss_plan *p, const int32_t *idx, int32_t b, BatchView &v, void *stream) {
   if (p->P == 1) {
     v = BatchView{idx, idx, nullptr};
     return GSS_OK;
   }
   PROF(GSS_PROF_ELEMENTWISE);
   v = BatchView{p->rloc, p->pid, p->keep};
-  return shard_batch_ids(idx, b, p->lo, p->desc.n, p->d_bounds, p->P, p->maxr, p->pid, p->rloc, p->keep, stream);
+  return shard_batch_ids(idx, b, p->lo, p->desc.n, p->gid2op_t, p->pid, p->rloc, p->keep, stream);
 }
 
-static int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float *de_rows, bool top_done, bool wt_ok,
-                              void *stream, int *deferred_slices = nullptr);
+int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float *de_rows, bool top_done, bool wt_ok, void *stream,
+                       int *deferred_slices = nullptr);
 
-static int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta, bool wt_ok, void *stream, BatchView &bv,
-                                   int *deferred_slices = nullptr) {
+int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta, bool wt_ok, void *stream, BatchView &bv,
+                            int *deferred_slices = nullptr) {
   GSS_REQUIRE(p && idx, "plan_loss_backward: null argument");
   const gss_plan_desc &D = p->desc;
   GSS_REQUIRE(b >= 1 && b <= D.max_batch, "plan_loss_backward: batch %d out of [1, %d]", b, D.max_batch);
@@ -480,15 +481,15 @@ static int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, f
 
 // deferred_slices != NULL (gss_plan_step): the caller finishes with the fused reduce + Adam kernel, which also resets
 // the batch-position map; the residual of the top layer then rides in the backward SpMM's epilogue
-static int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float *de_rows, bool top_done, bool wt_ok,
-                              void *stream, int *deferred_slices) {
+int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float *de_rows, bool top_done, bool wt_ok, void *stream,
+                       int *deferred_slices) {
   GSS_REQUIRE(p && bv.rows, "plan_backward: null argument");
   const gss_plan_desc &D = p->desc;
   GSS_REQUIRE(b >= 1 && b <= D.max_batch, "plan_backward: %d rows out of [1, %d]", b, D.max_batch);
   const int L = D.num_layers;
   hipStream_t st = as_stream(stream);
   const float *de_b = de_rows ? de_rows : p->de_b;
-  const int32_t *pos_row = p->pos ? p->pos + (size_t)p->rank * p->maxr : nullptr;  // local row r has padded id rank * maxr + r
+  const int32_t *pos_row = p->pos;  // a shard's own rows are the first n operand rows of A_hat^T's column space
   // top layer, batch rows only
   const float c_top = L > 1 ? D.layer_decay : 1.f;
   const bool sparse_top = L > 1 && spmm_sparse_available();
@@ -551,15 +552,14 @@ static int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const
       const float *res = (lp + 2 <= L - 1) ? p->gx[(lp + 2) & 1] : nullptr;
       float *gx_out = (lp >= 1 && L > 2) ? p->gx[(lp + 1) & 1] : nullptr;
       const bool fold_res = deferred_slices && sparse_top && lp + 2 == L;
-      const float *uf = nullptr;
-      if (int rc = plan_gather(p, p->u, 0, &uf, stream)) return rc;   // C1
+      if (int rc = plan_halo(p, p->halo_t, p->u, stream)) return rc;   // C1
       {
         PROF(GSS_PROF_SPMM_BWD2);
         if (fold_res) {
           // dP += dx_b on the batch rows inside the SpMM epilogue (no separate scatter-add launch)
-          if (int rc = spmm_bwd2_sparse_res(p->at, D.d, uf, p->t, p->p[lp], c, p->dx_b, pos_row, p->dp, gx_out, stream)) return rc;
+          if (int rc = spmm_bwd2_sparse_res(p->at, D.d, p->u, p->t, p->p[lp], c, p->dx_b, pos_row, p->dp, gx_out, stream)) return rc;
         } else {
-          if (int rc = spmm_bwd2(p->at, D.d, uf, p->t, p->p[lp], c, res, p->dp, gx_out, stream)) return rc;
+          if (int rc = spmm_bwd2(p->at, D.d, p->u, p->t, p->p[lp], c, res, p->dp, gx_out, stream)) return rc;
         }
       }
       if (lp + 2 == L && !fold_res) {
@@ -584,10 +584,9 @@ static int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const
           PROF(GSS_PROF_DGRAD);
           if (int rc = dense_bwd_input(D.n, D.d, p->dp, p->w1t, p->w2t, nullptr, p->g_ax, p->g_am, stream)) return rc;
         }
-        const float *gf = nullptr;
-        if (int rc = plan_gather(p, p->g_am, 1, &gf, stream)) return rc;   // C1
+        if (int rc = plan_halo(p, p->halo_t, p->g_am, stream)) return rc;   // C1
         PROF(GSS_PROF_SPMM_BWD1);
-        if (int rc = spmm_bwd1(p->at, D.d, gf, p->g_ax, p->xin[lp], p->ax[lp], p->u, p->t, stream)) return rc;
+        if (int rc = spmm_bwd1(p->at, D.d, p->g_am, p->g_ax, p->xin[lp], p->ax[lp], p->u, p->t, stream)) return rc;
       }
     }
   }
@@ -604,16 +603,7 @@ static int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const
   return plan_allreduce_grads(p, stream);
 }
 
-// C2: the four weight-gradient tensors summed over the shards, one fused collective
-static int plan_allreduce_grads(gss_plan *p, void *stream) {
-  if (p->P == 1) return GSS_OK;
-  PROF(GSS_PROF_COMM);
-  const gss_plan_desc &D = p->desc;
-  const size_t cnt[4] = {(size_t)D.d * D.d, (size_t)D.d, (size_t)D.d * D.d, (size_t)D.d};
-  return p->comm->all_reduce_sum(p->grad, cnt, 4, as_stream(stream));
-}
-
-static int plan_adam_impl(gss_plan *p, void *stream, int32_t *pos_clear = nullptr, const int32_t *ids = nullptr, int32_t b = 0) {
+int plan_adam_impl(gss_plan *p, void *stream, int32_t *pos_clear = nullptr, const int32_t *ids = nullptr, int32_t b = 0) {
   GSS_REQUIRE(p, "plan_adam: null plan");
   const gss_plan_desc &D = p->desc;
   p->step += 1;
@@ -624,6 +614,32 @@ static int plan_adam_impl(gss_plan *p, void *stream, int32_t *pos_clear = nullpt
   for (int k = 0; k < 4; ++k) t[k] = AdamTensor{params[k], p->grad[k], p->adam_m[k], p->adam_v[k], cnt[k]};
   const bool wt = D.num_layers > 1;
   return adam_step4(t, p->step, D.lr, D.beta1, D.beta2, D.eps, wt ? p->w1t : nullptr, wt ? p->w2t : nullptr, D.d, stream, pos_clear, ids, b);
+}
+}  // namespace
+
+extern "C" {
+
+int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a, const gss_csr *at, const gss_plan_io *io) {
+  return plan_create_impl(out, desc, nullptr, nullptr, a, at, io);
+}
+
+int gss_plan_create_sharded(gss_plan **out, const gss_plan_desc *desc, const gss_shard_desc *shard, gss_comm *comm, const gss_csr *a,
+                            const gss_csr *at, const gss_plan_io *io) {
+  GSS_REQUIRE(shard, "plan_create_sharded: null shard descriptor");
+  return plan_create_impl(out, desc, shard, comm, a, at, io);
+}
+
+void gss_plan_destroy(gss_plan *p) {
+  if (!p) return;
+  for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+  if (p->side) {
+    (void)hipStreamSynchronize(p->side);
+    (void)hipStreamDestroy(p->side);
+  }
+  if (p->ev_main_ready) (void)hipEventDestroy(p->ev_main_ready);
+  if (p->ev_side_done) (void)hipEventDestroy(p->ev_side_done);
+  if (p->slab) (void)hipFree(p->slab);
+  delete p;
 }
 
 // ---- public entry points.  The separate phases make no assumption about who changed the weights in between, so
@@ -652,7 +668,7 @@ int gss_plan_adam(gss_plan *p, void *stream) {
 int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
   GSS_REQUIRE(p, "plan_step: null plan");
   const bool pipe = p->desc.pipeline_layer1 && p->side && !p->prof_on && !p->desc.cache_layer1;
-  if (int rc = plan_forward_impl(p, stream, pipe)) return rc;
+  if (int rc = plan_forward_impl(p, stream)) return rc;
   if (pipe)  // the side stream starts when this stream reaches the loss kernel (MFMA-bound, 1 MB working set)
     if (int rc = plan_prefetch_layer1(p, stream)) return rc;
   int slices = 0;
@@ -692,16 +708,22 @@ int gss_plan_gather_embeddings(gss_plan *p, float *out, void *stream) {
     GSS_HIP(hipMemcpyAsync(out, p->emb, sizeof(float) * (size_t)D.n * D.d, hipMemcpyDeviceToDevice, st));
     return GSS_OK;
   }
-  const size_t slot = (size_t)p->maxr * D.d;
-  float *mine = p->full[0] + (size_t)p->rank * slot;
+  // equal-count all-gather through a padded staging buffer (a one-off, not part of a step)
+  int64_t maxr = 1;
+  for (int r = 0; r < p->P; ++r) maxr = std::max(maxr, p->h_bounds[(size_t)r + 1] - p->h_bounds[(size_t)r]);
+  const size_t slot = (size_t)maxr * D.d;
+  float *stage = nullptr;
+  GSS_HIP(hipMallocAsync((void **)&stage, sizeof(float) * slot * (size_t)p->P, st));
+  float *mine = stage + (size_t)p->rank * slot;
   if (D.n > 0) GSS_HIP(hipMemcpyAsync(mine, p->emb, sizeof(float) * (size_t)D.n * D.d, hipMemcpyDeviceToDevice, st));
-  if (int rc = p->comm->all_gather(mine, p->full[0], sizeof(float) * slot, st)) return rc;
-  for (int r = 0; r < p->P; ++r) {
+  int rc = p->comm->all_gather(mine, stage, sizeof(float) * slot, st);
+  for (int r = 0; r < p->P && rc == GSS_OK; ++r) {
     const int64_t lo = p->h_bounds[(size_t)r], rows = p->h_bounds[(size_t)r + 1] - lo;
-    if (rows > 0)
-      GSS_HIP(hipMemcpyAsync(out + (size_t)lo * D.d, p->full[0] + (size_t)r * slot, sizeof(float) * (size_t)rows * D.d, hipMemcpyDeviceToDevice, st));
+    if (rows > 0 && hipMemcpyAsync(out + (size_t)lo * D.d, stage + (size_t)r * slot, sizeof(float) * (size_t)rows * D.d, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      rc = fail(GSS_EHIP, "plan_gather_embeddings: copy of shard %d failed", r);
   }
-  return GSS_OK;
+  (void)hipFreeAsync(stage, st);
+  return rc;
 }
 
 const float *gss_plan_activation(const gss_plan *p, int layer, int which) {

@@ -202,11 +202,89 @@ def partition_for(a_hat, world):
     return Partition(nnz_balanced_ranges(work, world))
 
 
+class Halo:
+    """Operand halo of one shard matrix (include/gssgcn.h gss_halo_desc): which rows of other shards its columns reference
+    (`remote`, ascending = grouped by owner), where they land behind the shard's own rows, and -- after exchange() -- which
+    of its own rows every peer wants."""
+
+    def __init__(self, cols_global, part: Partition, rank):
+        self.part, self.rank = part, rank
+        lo, hi = part.rows(rank)
+        self.lo, self.nl = lo, hi - lo
+        uniq = np.unique(np.asarray(cols_global, dtype=np.int64))
+        self.remote = uniq[(uniq < lo) | (uniq >= hi)]
+        owner = part.owner(self.remote) if len(self.remote) else np.zeros(0, np.int64)
+        self.recv_off = np.zeros(part.parts + 1, dtype=np.int64)
+        self.recv_off[1:] = np.cumsum(np.bincount(owner, minlength=part.parts))
+        self.gid2op = np.full(part.n, -1, dtype=np.int32)          # node id -> operand row (own rows first, then the halo)
+        self.gid2op[lo:hi] = np.arange(self.nl, dtype=np.int32)
+        self.gid2op[self.remote] = self.nl + np.arange(len(self.remote), dtype=np.int32)
+        self.n_halo = int(len(self.remote))
+        self.send_off = np.zeros(part.parts + 1, dtype=np.int64)
+        self.send_rows = None                                       # device int32, set by exchange()
+
+    def local_cols(self, cols_global):
+        return self.gid2op[np.asarray(cols_global, dtype=np.int64)]
+
+    def exchange(self, comm: "Comm", device):
+        """tell every owner which of its rows this shard reads (a collective over `comm`: counts by all-gather, the id lists
+        by gss_exchange_rows with one int32 per row)"""
+        P, rank = self.part.parts, self.rank
+        lib = _lib.load()
+        st = _lib.current_stream
+        if P == 1:
+            self.send_rows = torch.zeros(1, dtype=torch.int32, device=device)
+            return self
+        mine = torch.from_numpy(np.diff(self.recv_off).astype(np.int64)).to(device)            # [P]: rows I want from q
+        allc = torch.empty(P, P, dtype=torch.int64, device=device)
+        _lib.check(lib.gss_allgather_bytes(comm.handle, mine.data_ptr(), allc.data_ptr(), 8 * P, st()), "gss_allgather_bytes")
+        torch.cuda.current_stream().synchronize()
+        counts = allc.cpu().numpy()                                                            # counts[r][q]: r wants from q
+        self.send_off[1:] = np.cumsum(counts[:, rank])
+        want = torch.from_numpy(self.remote.astype(np.int32)).to(device) if self.n_halo else torch.zeros(1, dtype=torch.int32, device=device)
+        n_send = int(self.send_off[-1])
+        got = torch.empty(max(n_send, 1), dtype=torch.int32, device=device)
+        # my request list is grouped by owner = my recv layout; what I receive is grouped by requester = my send layout
+        _lib.check(lib.gss_exchange_rows(comm.handle, 1, want.data_ptr(), self.recv_off.ctypes.data, got.data_ptr(),
+                                         self.send_off.ctypes.data, st()), "gss_exchange_rows")
+        torch.cuda.current_stream().synchronize()
+        self.send_rows = (got - self.lo).contiguous()
+        if n_send:
+            r = self.send_rows[:n_send]
+            assert int(r.min()) >= 0 and int(r.max()) < self.nl, "a peer asked for a row this shard does not own"
+        return self
+
+    def c_desc(self):
+        return _lib.HaloDesc(self.recv_off.ctypes.data, self.send_off.ctypes.data, self.send_rows.data_ptr())
+
+
+class ShardLayout:
+    """everything gss_plan_create_sharded borrows for one shard; keeps the host arrays and device tensors alive"""
+
+    def __init__(self, part: Partition, rank, halo_a: Halo, halo_at, device):
+        self.part, self.rank, self.world = part, rank, part.parts
+        self.bounds = np.ascontiguousarray(part.bounds, dtype=np.int64)
+        self.halo_a, self.halo_at = halo_a, halo_at
+        self.gid2op_t = torch.from_numpy(halo_at.gid2op).to(device) if halo_at is not None else None
+        self._empty = np.zeros(part.parts + 1, dtype=np.int64)
+
+    def c_desc(self):
+        none = _lib.HaloDesc(self._empty.ctypes.data, self._empty.ctypes.data, None)
+        return _lib.ShardDesc(self.world, self.rank, self.bounds.ctypes.data, self.halo_a.c_desc(),
+                              self.halo_at.c_desc() if self.halo_at is not None else none, _lib.ptr(self.gid2op_t))
+
+    def halo_fraction(self):
+        """rows received per hop / rows owned by the other shards: (A_hat, A_hat^T)"""
+        others = max(1, self.part.n - self.halo_a.nl)
+        return self.halo_a.n_halo / others, (self.halo_at.n_halo / others if self.halo_at is not None else 0.0)
+
+
 def sharded_plan_engine(adj, x_host, params_host, comm, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4, max_batch=None,
                         betas=(0.9, 0.999), eps=1e-8, device=None, a_hat=None, cache_layer1=False):
     """One rank of the node-range sharded trainer on the NATIVE path: a gss_plan created with gss_plan_create_sharded
-    that holds the communicator and enqueues kernels and collectives from C++ (no Python between kernels).  Returns a
-    GssEngine (same methods as the single-GPU one; .global_nnz, .part added)."""
+    that holds the communicator and enqueues kernels and collectives from C++ (no Python between kernels).  The shard's
+    CSRs carry operand-row column ids: own rows first, then the boundary rows its entries reference (Halo).  Returns a
+    GssEngine (same methods as the single-GPU one; .global_nnz, .part, .layout added)."""
     from .engine import GssEngine
     from .graph import DeviceCSR
     world, rank = comm.world, comm.rank
@@ -218,30 +296,26 @@ def sharded_plan_engine(adj, x_host, params_host, comm, num_layers=2, layer_deca
     part = partition_for(a_hat, world)
     lo, hi = part.rows(rank)
     nl = hi - lo
-    if world == 1:
-        ncols = nl
 
-        def cols(sub):
-            return sub.indptr.astype(np.int32), sub.indices.astype(np.int32), sub.data.astype(np.float32)
-    else:
-        ncols = world * part.max_rows
+    def shard_of(m):
+        sub = sp.csr_matrix(m[lo:hi])
+        halo = Halo(sub.indices, part, rank).exchange(comm, dev)
+        sub.sort_indices()
+        # entries stay in ascending GLOBAL column order (only the ids are replaced), so a row is summed in the same order as
+        # on one GPU and its result is bit-identical whatever the sharding
+        return DeviceCSR(sub.indptr.astype(np.int32), halo.local_cols(sub.indices).astype(np.int32), sub.data.astype(np.float32), nl,
+                         nl + halo.n_halo, dev), halo
 
-        def cols(sub):
-            return sub.indptr.astype(np.int32), part.padded_id(sub.indices).astype(np.int32), sub.data.astype(np.float32)
-    sub = sp.csr_matrix(a_hat[lo:hi])
-    sub.sort_indices()
-    a = DeviceCSR(*cols(sub), nl, ncols, dev)
-    at = None
+    a, halo_a = shard_of(a_hat)
+    at, halo_at = (None, None)
     if num_layers > 1:
-        sub_t = sp.csr_matrix(sp.csr_matrix(a_hat.T)[lo:hi])
-        sub_t.sort_indices()
-        at = DeviceCSR(*cols(sub_t), nl, ncols, dev)
+        at, halo_at = shard_of(sp.csr_matrix(a_hat.T))
+    layout = ShardLayout(part, rank, halo_a, halo_at, dev)
     x = torch.from_numpy(np.ascontiguousarray(x_host[lo:hi], dtype=np.float32)).to(dev)
     params = [torch.from_numpy(np.ascontiguousarray(params_host[k], dtype=np.float32)).to(dev) for k in ("W1", "b1", "W2", "b2")]
     eng = GssEngine(_ShardGraph(a, at, nl), x, params, num_layers=num_layers, layer_decay=layer_decay, alpha=alpha, lr=lr,
-                    max_batch=max_batch or a_hat.shape[0], cache_layer1=cache_layer1, betas=betas, eps=eps,
-                    shard=(world, rank, part.max_rows, part.bounds), comm=comm)
-    eng.global_nnz, eng.part = int(a_hat.nnz), part
+                    max_batch=max_batch or a_hat.shape[0], cache_layer1=cache_layer1, betas=betas, eps=eps, shard=layout, comm=comm)
+    eng.global_nnz, eng.part, eng.layout = int(a_hat.nnz), part, layout
     return eng
 
 

@@ -19,8 +19,8 @@ PARAM_NAMES = ("W1", "b1", "W2", "b2")
 class GssEngine:
     def __init__(self, graph, x: torch.Tensor, params, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4,
                  max_batch=None, cache_layer1=False, betas=(0.9, 0.999), eps=1e-8, pipeline_layer1=False, shard=None, comm=None):
-        """shard = (world, rank, max_rows, bounds[world + 1]) + comm (dist.Comm): one shard of a node-range sharded
-        replica (gss_plan_create_sharded); graph.a / graph.at then hold this shard's rows with padded column ids and
+        """shard = dist.ShardLayout + comm (dist.Comm): one shard of a node-range sharded replica
+        (gss_plan_create_sharded); graph.a / graph.at then hold this shard's rows with operand-row column ids and
         x / emb this shard's rows.  Every method is then a collective over the shards."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
         n, d = x.shape
@@ -30,7 +30,7 @@ class GssEngine:
         self.graph, self.x = graph, x
         self.n, self.d, self.num_layers = n, d, int(num_layers)
         self.shard, self.comm = shard, comm
-        self.n_global = int(shard[3][-1]) if shard is not None else n
+        self.n_global = int(shard.bounds[-1]) if shard is not None else n
         self.max_batch = int(max_batch or self.n_global)
         self.params = list(params)
         shapes = [(d, d), (d,), (d, d), (d,)]
@@ -52,9 +52,7 @@ class GssEngine:
         if shard is None:
             _lib.check(self.lib.gss_plan_create(C.byref(h), C.byref(self.desc), graph.a.handle, at_h, C.byref(io)), "gss_plan_create")
         else:
-            world, rank, max_rows, bounds = shard
-            self._bounds = np.ascontiguousarray(bounds, dtype=np.int64)
-            sd = _lib.ShardDesc(int(world), int(rank), int(max_rows), self._bounds.ctypes.data)
+            sd = shard.c_desc()           # borrows host arrays / device tensors owned by `shard`, which this engine keeps alive
             _lib.check(self.lib.gss_plan_create_sharded(C.byref(h), C.byref(self.desc), C.byref(sd), comm.handle if comm is not None else None,
                                                         graph.a.handle, at_h, C.byref(io)), "gss_plan_create_sharded")
         self.handle = h

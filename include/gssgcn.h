@@ -144,6 +144,11 @@ int gss_allgather_rows(gss_comm *c, int32_t d, int32_t max_rows, const float *sr
 int gss_allgather_bytes(gss_comm *c, const void *src, void *dst, size_t bytes_per_rank, void *stream);
 /* C2/C3: buf <- sum over ranks, in place, the same bits on every rank */
 int gss_allreduce_sum(gss_comm *c, float *buf, int64_t count, void *stream);
+/* C1, boundary form: rows [h_send_off[q], h_send_off[q+1]) of `send` ([..][d]) go to rank q; the rows rank q sends land at
+ * rows [h_recv_off[q], h_recv_off[q+1]) of `recv`.  Offsets are HOST arrays of world + 1 entries (own range empty); one
+ * fused group of ncclSend / ncclRecv, pairs with nothing to exchange are skipped. */
+int gss_exchange_rows(gss_comm *c, int32_t d, const float *send, const int64_t *h_send_off, float *recv, const int64_t *h_recv_off,
+                      void *stream);
 
 /* ---- K10  torch.optim.Adam.step, train.py:139-141,184 -----------------------------------------
  * One tensor of `count` floats; step is the 1-based step number.  lr, betas, eps as torch defaults.
@@ -244,19 +249,33 @@ int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a,
                     const gss_plan_io *io);
 
 /* One shard of a node-range sharded replica.  Rank r owns the node range [bounds[r], bounds[r+1]) -- the rows
- * of A_hat and A_hat^T (every column) and the matching rows of every activation and gradient; weights are replicated.
- *   desc->n = rows of THIS shard; a / at: CSR handles of the shard's rows with n_cols = world * max_rows and PADDED column
- *   ids  col' = owner(col) * max_rows + (col - bounds[owner(col)])  (operands are gathered into [world][max_rows][d]);
- *   io->x / io->emb: this shard's rows; the weights / gradients / loss in io are full-size and end up identical on every rank.
+ * of A_hat and A_hat^T and the matching rows of every activation and gradient; weights are replicated.
+ *
+ * Operand layout ("halo" form of C1): an SpMM operand of this shard is a [n + n_halo][d] buffer -- its own n rows first,
+ * then the rows of other shards that its CSR actually references (the boundary features), grouped by owner in ascending
+ * node order.  The CSR handles carry LOCAL OPERAND ROW ids as column ids (n_cols = n + n_halo).  A_hat and A_hat^T
+ * reference different nodes, so each has its own halo.  Before a hop every rank packs the rows its peers reference
+ * (d_send_rows) and one fused group of point-to-point transfers (gss_exchange_rows) delivers exactly those rows:
+ * nothing is padded and pairs of shards that share no edge exchange nothing.
+ *   desc->n = rows of THIS shard; io->x / io->emb: this shard's rows; the weights / gradients / loss in io are full-size
+ *   and end up identical on every rank.
  * Every gss_plan_* call then is a collective: all ranks call it with the same batch.  Per step the plan enqueues, on the
- * caller's stream, 2L - 1 + max(0, 2L - 3) all-gathers of a [N][d] operand (C1), one all-reduce of the B gathered batch rows
- * and one of their 2 B d input gradients (C3), and one grouped all-reduce of the four weight gradients (C2); no host
- * round trip in between.  world == 1 is exactly gss_plan_create.  gss_plan_backward (external upstream gradient) is not
- * available on a sharded plan. */
+ * caller's stream, 2L - 1 + max(0, 2L - 3) halo exchanges (C1; the input features' halo is fetched once), one all-reduce of
+ * the B gathered batch rows and one of their 2 B d input gradients (C3), and one grouped all-reduce of the four weight
+ * gradients (C2); no host round trip in between.  world == 1 is exactly gss_plan_create.  gss_plan_backward (external
+ * upstream gradient) is not available on a sharded plan. */
+typedef struct gss_halo_desc {
+  const int64_t *h_recv_off;   /* host [world + 1]: halo rows [recv_off[q], recv_off[q+1]) are owned by rank q; n_halo = recv_off[world] */
+  const int64_t *h_send_off;   /* host [world + 1]: packed rows [send_off[q], send_off[q+1]) go to rank q */
+  const int32_t *d_send_rows;  /* device [send_off[world]]: the local row behind every packed row (borrowed: keep it alive) */
+} gss_halo_desc;
 typedef struct gss_shard_desc {
   int32_t world, rank;
-  int32_t max_rows;          /* largest shard's row count */
-  const int64_t *h_bounds;   /* host, [world + 1], bounds[0] = 0, bounds[world] = N */
+  const int64_t *h_bounds;     /* host, [world + 1], bounds[0] = 0, bounds[world] = N */
+  gss_halo_desc halo_a;        /* operand halo of A_hat's columns */
+  gss_halo_desc halo_at;       /* operand halo of A_hat^T's columns (ignored when num_layers == 1) */
+  const int32_t *d_gid2op_t;   /* device [N], borrowed: node id -> operand row of A_hat^T's column space ([0, n) own rows, then
+                                  halo), -1 where this shard never reads the node.  NULL when num_layers == 1 */
 } gss_shard_desc;
 int gss_plan_create_sharded(gss_plan **out, const gss_plan_desc *desc, const gss_shard_desc *shard, gss_comm *comm,
                             const gss_csr *a, const gss_csr *at, const gss_plan_io *io);

@@ -90,3 +90,39 @@ def test_partition_and_padded_ids():
     lo, hi = part.rows(2)
     sub = sp.csr_matrix((dv, ix, ip), shape=(hi - lo, 4 * part.max_rows))
     np.testing.assert_allclose(sub @ padded, (a[lo:hi] @ x), rtol=1e-5, atol=1e-5)
+
+
+def test_halo_layout_reproduces_the_global_product():
+    """Halo (dist.py): own rows first, then the referenced rows of other shards grouped by owner; a shard's CSR with
+    operand-row column ids times the assembled operand equals its rows of the global product.  The send side is derived
+    here the way Halo.exchange derives it on the device: every rank's request list, regrouped by owner."""
+    from gcn_drug_repurposing_amd.dist import Halo, Partition, nnz_balanced_ranges
+    rng = np.random.RandomState(1)
+    n, P, d = 400, 4, 3
+    a = sp.random(n, n, density=0.01, random_state=rng, format="csr") + sp.eye(n, format="csr")
+    a = sp.csr_matrix(a)
+    a[5, :] = 0.5                      # a hub row that references every node
+    a = sp.csr_matrix(a)
+    part = Partition(nnz_balanced_ranges(a.indptr, P))
+    x = rng.randn(n, d)
+    halos = []
+    for r in range(P):
+        lo, hi = part.rows(r)
+        halos.append(Halo(a[lo:hi].indices, part, r))
+    for r, h in enumerate(halos):
+        lo, hi = part.rows(r)
+        assert h.recv_off[0] == 0 and h.recv_off[-1] == h.n_halo and h.recv_off[r + 1] == h.recv_off[r]      # nothing from itself
+        assert np.all(np.diff(h.remote) > 0) and not np.any((h.remote >= lo) & (h.remote < hi))
+        for q in range(P):                                                 # the block of owner q holds rows of q only
+            blk = h.remote[h.recv_off[q]:h.recv_off[q + 1]]
+            assert np.all((blk >= part.bounds[q]) & (blk < part.bounds[q + 1]))
+        # what the peers would pack for this shard: rows (ids - their lo) of their local x, in this shard's request order
+        operand = np.concatenate([x[lo:hi]] + [x[part.bounds[q]:part.bounds[q + 1]][h.remote[h.recv_off[q]:h.recv_off[q + 1]] - part.bounds[q]]
+                                               for q in range(P)])
+        sub = a[lo:hi]
+        loc = sp.csr_matrix((sub.data, h.local_cols(sub.indices), sub.indptr), shape=(hi - lo, (hi - lo) + h.n_halo))
+        np.testing.assert_allclose(loc @ operand, (a @ x)[lo:hi], rtol=1e-12, atol=1e-12)
+        assert np.array_equal(h.gid2op[lo:hi], np.arange(hi - lo)) and (h.gid2op >= 0).sum() == (hi - lo) + h.n_halo
+    # the hub's shard reads every node; shards that share no edge exchange nothing
+    hub_rank = int(part.owner(np.array([5]))[0])
+    assert halos[hub_rank].n_halo == n - halos[hub_rank].nl
