@@ -53,6 +53,8 @@ SIGNATURES = {
     "gss_abi_version": (C.c_int, []),
     "gss_last_error": (C.c_char_p, []),
     "gss_normalize_adj": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P]),
+    "gss_rowsum_dinv": (C.c_int, [_I32, _P, _P, _P, _P, _P]),
+    "gss_scale_adj_shard": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _I32, _P, _P]),
     "gss_csr_create": (C.c_int, [C.POINTER(_P), _I32, _I32, _I64, _P, _P, _P, _P]),
     "gss_csr_destroy": (None, [_P]),
     "gss_spmm": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P]),
@@ -73,6 +75,7 @@ SIGNATURES = {
     "gss_comm_create_rccl": (C.c_int, [C.POINTER(_P), _I32, _I32, _P]),
     "gss_comm_create_local": (C.c_int, [C.POINTER(_P), _I32]),
     "gss_comm_destroy": (None, [_P]),
+    "gss_comm_abort": (None, [_P]),
     "gss_comm_world": (_I32, [_P]),
     "gss_comm_rank": (_I32, [_P]),
     "gss_allgather_rows": (C.c_int, [_P, _I32, _I32, _P, _P, _P]),

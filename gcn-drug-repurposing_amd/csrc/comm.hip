@@ -82,6 +82,11 @@ struct LocalShared {
   std::vector<const void *> src;
   std::vector<const int64_t *> off;  // exchange_rows: every rank's send offsets (host arrays, valid between the two barriers)
   explicit LocalShared(int w) : world(w), src((size_t)w, nullptr), off((size_t)w, nullptr) {}
+  void abort() {
+    std::lock_guard<std::mutex> lk(mu);
+    broken = true;
+    cv.notify_all();
+  }
   // timed barrier: a rank that failed elsewhere must not hang the others forever
   int wait() {
     std::unique_lock<std::mutex> lk(mu);
@@ -113,6 +118,7 @@ __global__ __launch_bounds__(256) void local_sum_kernel(size_t count, int world,
 
 struct LocalComm final : gss_comm {
   std::shared_ptr<LocalShared> sh;
+  void abort() override { sh->abort(); }
   float *tmp = nullptr;
   size_t tmp_floats = 0;
   ~LocalComm() override {
@@ -217,6 +223,9 @@ int gss_comm_create_local(gss_comm **out, int32_t world) {
 }
 
 void gss_comm_destroy(gss_comm *c) { delete c; }
+void gss_comm_abort(gss_comm *c) {
+  if (c) c->abort();
+}
 int32_t gss_comm_world(const gss_comm *c) { return c ? c->world : 0; }
 int32_t gss_comm_rank(const gss_comm *c) { return c ? c->rank : -1; }
 

@@ -21,6 +21,7 @@ struct gss_csr {
 struct gss_comm {
   int world = 1, rank = 0;
   virtual ~gss_comm() {}
+  virtual void abort() {}  // local backend: release every rank blocked in a collective (they return an error)
   // rank r's `bytes_per_rank` land at recv + r * bytes_per_rank; in place when send == recv + rank * bytes_per_rank
   virtual int all_gather(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) = 0;
   // in place, nbuf tensors as one fused operation; identical bits on every rank

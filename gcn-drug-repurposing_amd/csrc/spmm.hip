@@ -624,11 +624,48 @@ __global__ __launch_bounds__(256) void scale_kernel(int n, const int32_t *__rest
   for (int e = e0 + lane; e < e1; e += 64) out[e] = (float)((val[e] * dinv[col[e]]) * di);
 }
 
+// sharded form of scale_kernel: the shard holds rows [row0, row0 + n) of A + I (or of its transpose) with GLOBAL column ids;
+// dinv is the all-gathered D^-1/2 of every node.  The rounding sequence is the single-GPU kernel's: (val * dinv[column of
+// A]) * dinv[row of A]; for a transposed shard the entry (i, j) is A[j][i], so the roles of the shard's row and column swap
+// and the result is bit-identical to the matching entry of A_hat.
+__global__ __launch_bounds__(256) void scale_shard_kernel(int n, int row0, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                          const double *__restrict__ val, const double *__restrict__ dinv, int transposed,
+                                                          float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int e0 = rowptr[row], e1 = rowptr[row + 1];
+  const double di = dinv[row0 + row];
+  if (transposed) {
+    for (int e = e0 + lane; e < e1; e += 64) out[e] = (float)((val[e] * di) * dinv[col[e]]);
+  } else {
+    for (int e = e0 + lane; e < e1; e += 64) out[e] = (float)((val[e] * dinv[col[e]]) * di);
+  }
+}
+
 }  // namespace gss
 
 using namespace gss;
 
 extern "C" {
+
+int gss_rowsum_dinv(int32_t n, const int32_t *rowptr, const double *val, double *dinv_out, double *rowsum_out, void *stream) {
+  if (n == 0) return GSS_OK;  // an empty shard
+  GSS_REQUIRE(n > 0 && rowptr && val && dinv_out, "rowsum_dinv: null operand");
+  hipLaunchKernelGGL(rowsum_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, as_stream(stream), n, rowptr, val, dinv_out, rowsum_out);
+  GSS_LAUNCH_CHECK("rowsum_kernel");
+  return GSS_OK;
+}
+
+int gss_scale_adj_shard(int32_t n, int32_t row0, const int32_t *rowptr, const int32_t *col, const double *val, const double *dinv_global,
+                        int32_t transposed, float *val_out, void *stream) {
+  if (n == 0) return GSS_OK;  // an empty shard
+  GSS_REQUIRE(n > 0 && row0 >= 0 && rowptr && dinv_global && val_out && col && val, "scale_adj_shard: null operand");
+  hipLaunchKernelGGL(scale_shard_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, as_stream(stream), n, row0, rowptr, col, val, dinv_global,
+                     transposed, val_out);
+  GSS_LAUNCH_CHECK("scale_shard_kernel");
+  return GSS_OK;
+}
 
 int gss_normalize_adj(int32_t n, const int32_t *rowptr, const int32_t *col, const double *val, float *val_out,
                       double *rowsum_out, void *stream) {

@@ -151,6 +151,11 @@ class Comm:
             self._destroy(h)
             self.handle = None
 
+    def abort(self):
+        """in-process ranks: release the peers blocked in a collective (call from a rank that failed)"""
+        if self.handle:
+            _lib.load().gss_comm_abort(self.handle)
+
     def all_gather_rows(self, src, dst_padded):
         """C1: src [max_rows, d] -> dst_padded [world * max_rows, d] on torch's current stream"""
         _lib.check(_lib.load().gss_allgather_rows(self.handle, src.shape[1], src.shape[0], src.data_ptr(), dst_padded.data_ptr(),
@@ -207,11 +212,11 @@ class Halo:
     (`remote`, ascending = grouped by owner), where they land behind the shard's own rows, and -- after exchange() -- which
     of its own rows every peer wants."""
 
-    def __init__(self, cols_global, part: Partition, rank):
+    def __init__(self, cols_global, part: Partition, rank, uniq=None):
         self.part, self.rank = part, rank
         lo, hi = part.rows(rank)
         self.lo, self.nl = lo, hi - lo
-        uniq = np.unique(np.asarray(cols_global, dtype=np.int64))
+        uniq = np.unique(np.asarray(cols_global, dtype=np.int64)) if uniq is None else np.asarray(uniq, dtype=np.int64)
         self.remote = uniq[(uniq < lo) | (uniq >= hi)]
         owner = part.owner(self.remote) if len(self.remote) else np.zeros(0, np.int64)
         self.recv_off = np.zeros(part.parts + 1, dtype=np.int64)
@@ -290,7 +295,13 @@ def sharded_plan_engine(adj, x_host, params_host, comm, num_layers=2, layer_deca
     world, rank = comm.world, comm.rank
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     if a_hat is None:
-        a_hat = ShardedEngine._normalize_host(adj)
+        # the regular path: this rank's rows only, normalised on the device (shards.py) -- the same bits as GssGraph's A_hat
+        from .shards import ScipySource, build_shard, shard_engine
+        shard = build_shard(ScipySource(adj), comm, need_transpose=num_layers > 1, device=dev)
+        lo, hi = shard.part.rows(rank)
+        return shard_engine(shard, x_host[lo:hi], params_host, comm, num_layers=num_layers, layer_decay=layer_decay, alpha=alpha, lr=lr,
+                            max_batch=max_batch, betas=betas, eps=eps, cache_layer1=cache_layer1)
+    # a_hat given (an already normalised matrix, e.g. the reference's preprocess_graph output in tests): slice it on the host
     a_hat = sp.csr_matrix(a_hat)
     a_hat.sort_indices()
     part = partition_for(a_hat, world)

@@ -104,9 +104,12 @@ class DeviceCSR:
         self.h_indptr = np.ascontiguousarray(indptr, dtype=np.int32)
         self.nnz = int(self.h_indptr[-1])
         self.rowptr = torch.from_numpy(self.h_indptr).to(device)
-        self.col = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int32)).to(device)
+        self.col = (indices.to(device=device, dtype=torch.int32).contiguous() if torch.is_tensor(indices)
+                    else torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int32)).to(device))
+        if self.col.numel() == 0:
+            self.col = torch.zeros(1, dtype=torch.int32, device=device)     # a non-null pointer for an empty shard
         self.val = values32 if torch.is_tensor(values32) else torch.from_numpy(np.ascontiguousarray(values32, np.float32)).to(device)
-        assert self.val.dtype == torch.float32 and self.val.numel() == self.nnz
+        assert self.val.dtype == torch.float32 and self.val.numel() >= self.nnz
         lib = _lib.load()
         h = C.c_void_p()
         _lib.check(lib.gss_csr_create(C.byref(h), self.n_rows, self.n_cols, self.nnz, self.h_indptr.ctypes.data,

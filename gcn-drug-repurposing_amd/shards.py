@@ -1,0 +1,301 @@
+"""Building one node-range shard of A_hat / A_hat^T without any rank holding the whole graph.
+
+The reference normalises one scipy matrix on the host (helpers/helper.py:82-89).  Here every rank
+  1. learns the per-node work (stored entries of its row of A + I and of (A + I)^T) from a *row source* and derives the
+     same nnz-balanced node ranges as every other rank,
+  2. takes only ITS rows of A + I and of (A + I)^T from the source (global column ids, fp64 values),
+  3. computes D_ii^-1/2 of its rows on the device (gss_rowsum_dinv), all-gathers the N scalars, and scales its entries
+     with the single-GPU kernel's rounding sequence (gss_scale_adj_shard) -- bit-identical values to GssGraph's,
+  4. finds the boundary rows its entries reference (dist.Halo), tells their owners, and renumbers its columns to
+     operand rows (own rows first, then the halo).
+Row sources: ScipySource (a matrix in memory: small graphs, tests) and RmatSource (BASELINE config 5: the RMAT edge
+stream generated chunk by chunk on the GPU, every rank keeping only the edges of its own rows; host memory per rank is
+O(N) scalars, not O(nnz)).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _lib
+from .dist import Comm, Halo, Partition, ShardLayout, nnz_balanced_ranges
+
+
+# ---------------------------------------------------------------------------------------------------------
+# small host collectives over a gss_comm (setup time only; device buffers underneath, so both backends serve them)
+# ---------------------------------------------------------------------------------------------------------
+def allgather_host(comm: Comm, arr: np.ndarray, device) -> np.ndarray:
+    """[world, *arr.shape] of every rank's `arr` (same shape and dtype everywhere)"""
+    arr = np.ascontiguousarray(arr)
+    if comm.world == 1:
+        return arr[None].copy()
+    src = torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(device)
+    dst = torch.empty(comm.world * src.numel(), dtype=torch.uint8, device=device)
+    _lib.check(_lib.load().gss_allgather_bytes(comm.handle, src.data_ptr(), dst.data_ptr(), src.numel(), _lib.current_stream()),
+               "gss_allgather_bytes")
+    torch.cuda.current_stream().synchronize()
+    return dst.cpu().numpy().view(arr.dtype).reshape((comm.world,) + arr.shape)
+
+
+def allgather_ranges(comm: Comm, local: torch.Tensor, bounds, device) -> torch.Tensor:
+    """local [rows of this rank] (1-D device tensor) of every rank, concatenated in node order -> [N] on the device"""
+    P = comm.world
+    if P == 1:
+        return local
+    sizes = np.diff(np.asarray(bounds, dtype=np.int64))
+    maxr = int(max(1, sizes.max()))
+    pad = torch.zeros(maxr, dtype=local.dtype, device=device)
+    pad[:local.numel()] = local
+    out = torch.empty(P * maxr, dtype=local.dtype, device=device)
+    _lib.check(_lib.load().gss_allgather_bytes(comm.handle, pad.data_ptr(), out.data_ptr(), maxr * local.element_size(), _lib.current_stream()),
+               "gss_allgather_bytes")
+    return torch.cat([out[r * maxr: r * maxr + int(sizes[r])] for r in range(P)])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# row sources
+# ---------------------------------------------------------------------------------------------------------
+class ScipySource:
+    """rows of A + I and of (A + I)^T from a matrix in memory (every rank holds it: for graphs that fit, and for tests)"""
+
+    def __init__(self, adj):
+        adj = sp.csr_matrix(adj, dtype=np.float64)
+        self.n = adj.shape[0]
+        self.a = (adj + sp.eye(self.n, dtype=np.float64, format="csr")).tocsr()     # helper.py:83
+        self.a.sort_indices()
+        self.at = self.a.T.tocsr()
+        self.at.sort_indices()
+        self.nnz = int(self.a.nnz)
+
+    def work(self, comm, device):
+        return (np.diff(self.a.indptr) + np.diff(self.at.indptr)).astype(np.int64)
+
+    def _rows(self, m, lo, hi, device):
+        sub = m[lo:hi]
+        return (torch.from_numpy(sub.indptr.astype(np.int32)).to(device), torch.from_numpy(sub.indices.astype(np.int32)).to(device),
+                torch.from_numpy(sub.data.astype(np.float64)).to(device))
+
+    def rows(self, lo, hi, device):
+        return self._rows(self.a, lo, hi, device)
+
+    def rows_t(self, lo, hi, device):
+        return self._rows(self.at, lo, hi, device)
+
+
+def _mix64(x: torch.Tensor) -> torch.Tensor:
+    """splitmix64 finaliser on int64 tensors (wrapping multiplies, logical shifts), result masked to 63 bits"""
+    def lsr(v, s):
+        return (v >> s) & ((1 << (64 - s)) - 1)
+    x = (x ^ lsr(x, 30)) * (-4658895280553007687)       # 0xbf58476d1ce4e5b9
+    x = (x ^ lsr(x, 27)) * (-7723592293110705685)       # 0x94d049bb133111eb
+    x = x ^ lsr(x, 31)
+    return x & 0x7FFFFFFFFFFFFFFF
+
+
+class RmatSource:
+    """BASELINE config 5: RMAT (a, b, c, d) on `n` node ids (sampled on the next power of two, endpoints >= n and self loops
+    rejected), `m` unique directed entries with unit weights, + the n self loops of A + I.  The sample stream comes from a
+    seeded device generator and is therefore the same on every rank; a rank keeps only the samples of its own rows.
+    Exactly m entries: samples are drawn in rounds until at least m distinct ones exist (counted over all ranks), then the
+    ones with the smallest 63-bit hash of (u, v) are kept -- a cut every rank can apply on its own."""
+
+    def __init__(self, n, m, seed=4, abcd=(0.57, 0.19, 0.19, 0.05), device="cuda", chunk=None):
+        self.n, self.m, self.seed, self.abcd = int(n), int(m), int(seed), abcd
+        self.device = torch.device(device)
+        self.bits = int(np.ceil(np.log2(self.n)))
+        self.chunk = int(chunk or min(1 << 26, max(1 << 16, int(self.m * 0.35))))
+        self.rounds = None
+        self.cut = None            # keep entries with hash < cut
+        self.nnz = self.m + self.n
+        self._cache = None         # (lo, hi, keys_by_u, keys_by_v) of the preparation pass, reused when the ranges match
+
+    # -- the sample stream ---------------------------------------------------------------------------------
+    def _chunks(self, rounds=None):
+        g = torch.Generator(device=self.device)
+        g.manual_seed(self.seed)
+        a, b, c, _ = self.abcd
+        r = 0
+        while rounds is None or r < rounds:
+            k = self.chunk
+            u = torch.zeros(k, dtype=torch.int64, device=self.device)
+            v = torch.zeros(k, dtype=torch.int64, device=self.device)
+            for _ in range(self.bits):
+                p = torch.rand(k, generator=g, device=self.device)
+                right = ((p >= a) & (p < a + b)) | (p >= a + b + c)
+                down = p >= a + b
+                u = (u << 1) | down.to(torch.int64)
+                v = (v << 1) | right.to(torch.int64)
+            keep = (u < self.n) & (v < self.n) & (u != v)
+            yield u[keep], v[keep]
+            r += 1
+
+    def _collect(self, lo, hi, rounds, comm=None, want=None):
+        """distinct samples with u in [lo, hi) (keyed u * n + v) and with v in [lo, hi) (keyed v * n + u), over `rounds` rounds,
+        or -- rounds None -- until the job holds at least `want` distinct samples"""
+        ku = torch.zeros(0, dtype=torch.int64, device=self.device)
+        kv = torch.zeros(0, dtype=torch.int64, device=self.device)
+        used = 0
+        for u, v in self._chunks(rounds):
+            mu, mv = (u >= lo) & (u < hi), (v >= lo) & (v < hi)
+            ku = torch.unique(torch.cat([ku, u[mu] * self.n + v[mu]]))
+            kv = torch.unique(torch.cat([kv, v[mv] * self.n + u[mv]]))
+            used += 1
+            if rounds is None:
+                total = int(allgather_host(comm, np.array([ku.numel()], dtype=np.int64), self.device).sum())
+                if total >= want:
+                    break
+                if used > 64:
+                    raise RuntimeError(f"RMAT: {total} distinct entries after {used} rounds, {want} wanted (graph too dense for its id space)")
+        return ku, kv, used
+
+    def _uv_key(self, k_by_v):
+        """(v * n + u) -> (u * n + v), the key the hash is taken of"""
+        return (k_by_v % self.n) * self.n + k_by_v // self.n
+
+    def prepare(self, comm: Comm):
+        """collective: number of rounds, the hash cut that leaves exactly m entries, and every node's work"""
+        P, rank = comm.world, comm.rank
+        lo, hi = rank * self.n // P, (rank + 1) * self.n // P
+        ku, kv, used = self._collect(lo, hi, None, comm, self.m)
+        self.rounds = used
+        hu = _mix64(ku)
+        # smallest cut with count(hash < cut) >= m, by bisection over the 63-bit range (counts summed over the ranks)
+        a_, b_ = 0, 1 << 63
+        while a_ < b_:
+            mid = (a_ + b_) // 2
+            cnt = int(allgather_host(comm, np.array([int((hu < mid).sum())], dtype=np.int64), self.device).sum())
+            if cnt >= self.m:
+                b_ = mid
+            else:
+                a_ = mid + 1
+        self.cut = a_
+        ku = ku[hu < self.cut]
+        kv = kv[_mix64(self._uv_key(kv)) < self.cut]
+        total = int(allgather_host(comm, np.array([ku.numel()], dtype=np.int64), self.device).sum())
+        self.nnz = total + self.n
+        deg = (torch.bincount(ku // self.n - lo, minlength=hi - lo) + torch.bincount(kv // self.n - lo, minlength=hi - lo) + 2)
+        bounds = np.array([r * self.n // P for r in range(P + 1)], dtype=np.int64)
+        self._work = allgather_ranges(comm, deg, bounds, self.device).cpu().numpy().astype(np.int64)
+        self._cache = (lo, hi, ku, kv)
+        return self
+
+    def work(self, comm, device):
+        if self.rounds is None:
+            self.prepare(comm)
+        return self._work
+
+    def _csr(self, keys, lo, hi):
+        """distinct keys (row * n + col, rows in [lo, hi)) + the diagonal -> CSR of those rows of A + I (unit values)"""
+        diag = torch.arange(lo, hi, dtype=torch.int64, device=self.device) * (self.n + 1)
+        keys = torch.sort(torch.cat([keys, diag])).values
+        rows = keys // self.n - lo
+        rowptr = torch.zeros(hi - lo + 1, dtype=torch.int64, device=self.device)
+        rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=hi - lo), 0)
+        return rowptr.to(torch.int32), (keys % self.n).to(torch.int32), torch.ones(keys.numel(), dtype=torch.float64, device=self.device)
+
+    def _keys(self, lo, hi):
+        if self._cache is not None and self._cache[0] == lo and self._cache[1] == hi:
+            return self._cache[2], self._cache[3]
+        ku, kv, _ = self._collect(lo, hi, self.rounds)
+        ku = ku[_mix64(ku) < self.cut]
+        kv = kv[_mix64(self._uv_key(kv)) < self.cut]
+        self._cache = (lo, hi, ku, kv)
+        return ku, kv
+
+    def rows(self, lo, hi, device):
+        return self._csr(self._keys(lo, hi)[0], lo, hi)
+
+    def rows_t(self, lo, hi, device):
+        return self._csr(self._keys(lo, hi)[1], lo, hi)
+
+    def release(self):
+        self._cache = None
+
+
+def gaussian_rows(lo, hi, d, seed, block=1 << 16):
+    """rows [lo, hi) of a unit-variance Gaussian feature matrix that any rank can generate for its own range: block k
+    (rows k * block ...) comes from RandomState(seed * 1000003 + k)"""
+    out = np.empty((hi - lo, d), dtype=np.float32)
+    for k in range(lo // block, (max(hi, lo + 1) - 1) // block + 1):
+        b0, b1 = k * block, (k + 1) * block
+        s0, s1 = max(lo, b0), min(hi, b1)
+        if s1 <= s0:
+            continue
+        rows = np.random.RandomState((seed * 1000003 + k) % (2 ** 32)).randn(block, d).astype(np.float32)
+        out[s0 - lo:s1 - lo] = rows[s0 - b0:s1 - b0]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the builder
+# ---------------------------------------------------------------------------------------------------------
+class Shard:
+    """one rank's part of the graph on the device: a / at (DeviceCSR with operand-row column ids), layout, part"""
+
+    def __init__(self, a, at, layout, part, nnz_global, rowsum):
+        self.a, self.at, self.layout, self.part, self.nnz_global, self.rowsum = a, at, layout, part, nnz_global, rowsum
+        self.n = a.n_rows
+
+    @property
+    def nnz(self):
+        return self.a.nnz
+
+
+def build_shard(source, comm: Comm, need_transpose=True, device=None) -> Shard:
+    from .graph import DeviceCSR
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    lib = _lib.load()
+    P, rank = comm.world, comm.rank
+    work = np.asarray(source.work(comm, dev), dtype=np.int64)
+    n = len(work)
+    part = Partition(nnz_balanced_ranges(np.concatenate([[0], np.cumsum(work)]), P))
+    lo, hi = part.rows(rank)
+    nl = hi - lo
+    st = _lib.current_stream
+
+    rowptr, col, val = source.rows(lo, hi, dev)
+    dinv_local = torch.empty(max(nl, 1), dtype=torch.float64, device=dev)
+    rowsum = torch.empty(max(nl, 1), dtype=torch.float64, device=dev)
+    _lib.check(lib.gss_rowsum_dinv(nl, rowptr.data_ptr(), _lib.ptr(val), dinv_local.data_ptr(), rowsum.data_ptr(), st()), "gss_rowsum_dinv")
+    dinv = allgather_ranges(comm, dinv_local[:nl], part.bounds, dev).contiguous()            # D^-1/2 of every node
+
+    def finish(rowptr, col, val, transposed):
+        val32 = torch.empty(max(col.numel(), 1), dtype=torch.float32, device=dev)
+        _lib.check(lib.gss_scale_adj_shard(nl, lo, rowptr.data_ptr(), _lib.ptr(col), _lib.ptr(val), dinv.data_ptr(), transposed,
+                                           val32.data_ptr(), st()), "gss_scale_adj_shard")
+        uniq = torch.unique(col).cpu().numpy() if col.numel() else np.zeros(0, np.int64)
+        halo = Halo(None, part, rank, uniq=uniq).exchange(comm, dev)
+        g2o = torch.from_numpy(halo.gid2op).to(dev)
+        col_local = g2o[col.long()].contiguous() if col.numel() else col
+        csr = DeviceCSR(rowptr.cpu().numpy(), col_local, val32[:col.numel()], nl, nl + halo.n_halo, dev)
+        return csr, halo
+
+    a, halo_a = finish(rowptr, col, val, 0)
+    del rowptr, col, val
+    at, halo_at = None, None
+    if need_transpose:
+        rowptr, col, val = source.rows_t(lo, hi, dev)
+        at, halo_at = finish(rowptr, col, val, 1)
+        del rowptr, col, val
+    if hasattr(source, "release"):
+        source.release()
+    layout = ShardLayout(part, rank, halo_a, halo_at, dev)
+    return Shard(a, at, layout, part, int(source.nnz), rowsum[:nl])
+
+
+def shard_engine(shard: Shard, x_local, params_host, comm: Comm, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4, max_batch=None,
+                 betas=(0.9, 0.999), eps=1e-8, cache_layer1=False):
+    """GssEngine over a built shard (gss_plan_create_sharded): x_local = this shard's feature rows (numpy or device tensor)"""
+    from .engine import GssEngine
+    dev = shard.a.rowptr.device
+    x = x_local if torch.is_tensor(x_local) else torch.from_numpy(np.ascontiguousarray(x_local, dtype=np.float32))
+    x = x.to(dev).contiguous()
+    params = [torch.from_numpy(np.ascontiguousarray(params_host[k], dtype=np.float32)).to(dev) for k in ("W1", "b1", "W2", "b2")]
+    n_global = int(shard.part.bounds[-1])
+    eng = GssEngine(shard, x, params, num_layers=num_layers, layer_decay=layer_decay, alpha=alpha, lr=lr, max_batch=max_batch or n_global,
+                    cache_layer1=cache_layer1, betas=betas, eps=eps, shard=shard.layout, comm=comm)
+    eng.global_nnz, eng.part, eng.layout = shard.nnz_global, shard.part, shard.layout
+    return eng

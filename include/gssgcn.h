@@ -46,6 +46,14 @@ const char *gss_last_error(void);
 int gss_normalize_adj(int32_t n, const int32_t *rowptr, const int32_t *col, const double *val,
                       float *val_out, double *rowsum_out, void *stream);
 
+/* The same for one node-range shard: the shard holds rows [row0, row0 + n) of A + I -- or, transposed != 0, of
+ * (A + I)^T -- with GLOBAL column ids.  gss_rowsum_dinv: D_ii and D_ii^-1/2 of the shard's rows of A + I;
+ * gss_scale_adj_shard: the normalised values from the all-gathered D^-1/2 of every node, with the rounding sequence of
+ * gss_normalize_adj, so a shard's values are bit-identical to the matching entries of the single-GPU A_hat / A_hat^T. */
+int gss_rowsum_dinv(int32_t n, const int32_t *rowptr, const double *val, double *dinv_out, double *rowsum_out, void *stream);
+int gss_scale_adj_shard(int32_t n, int32_t row0, const int32_t *rowptr, const int32_t *col, const double *val, const double *dinv_global,
+                        int32_t transposed, float *val_out, void *stream);
+
 /* ---- CSR handle ---------------------------------------------------------------------------
  * Borrows d_rowptr/d_col/d_val (caller keeps them alive).  h_rowptr is a HOST copy of rowptr used
  * once to bin rows by length (long rows get a whole workgroup).  n_cols is the height of the dense
@@ -136,6 +144,9 @@ int gss_comm_unique_id(void *id_out);
 int gss_comm_create_rccl(gss_comm **out, int32_t world, int32_t rank, const void *id);
 int gss_comm_create_local(gss_comm **out /* [world] */, int32_t world);
 void gss_comm_destroy(gss_comm *c);
+/* in-process backend: make every rank that is (or will be) blocked in a collective of this group return an error -- call it
+ * from a rank that failed, so that its peers do not wait for the 120 s barrier timeout.  No-op for an RCCL communicator. */
+void gss_comm_abort(gss_comm *c);
 int32_t gss_comm_world(const gss_comm *c);
 int32_t gss_comm_rank(const gss_comm *c);
 /* C1: src [max_rows][d] (this rank's rows first, the rest don't-care) -> dst_padded [world * max_rows][d], rank r's rows at

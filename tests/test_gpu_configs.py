@@ -108,7 +108,7 @@ def test_config3_full_size_step_matches_cpu_port(config3):
     assert 0 < (eng.params[0] - w0).abs().max().item() < 2.5 * LR
 
 
-def _threaded(world, fn):
+def _threaded(world, fn, comms=None):
     out, errors = [None] * world, []
 
     def worker(rank):
@@ -120,6 +120,8 @@ def _threaded(world, fn):
         except Exception as e:  # noqa: BLE001
             import traceback
             errors.append((rank, repr(e), traceback.format_exc()))
+            if comms is not None:
+                comms[rank].abort()           # release the peers now instead of after the barrier timeout
 
     ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
     [t.start() for t in ts]
@@ -136,14 +138,14 @@ def test_config4_sharded_plan_equals_single_gpu_plan(config3, world):
     from gcn_drug_repurposing_amd.dist import local_comms, sharded_plan_engine
     c = config3
     _, _, g_cpu, g64, _, a_hat = c["ref"]
-    single, _ = _single_gpu(c, a_hat)
+    single, _ = _single_gpu(c)                # GssGraph and the shard builder normalise on the device: the same A_hat bits
     emb1, loss1 = single.emb.cpu().numpy(), single.loss.item()
     comms = local_comms(world)
     idx32 = c["idx"].astype(np.int32)
 
     def rank_fn(rank):
         eng = sharded_plan_engine(c["adj"], c["X"], c["p"], comms[rank], num_layers=c["L"], layer_decay=DECAY, alpha=ALPHA, lr=LR,
-                                  max_batch=c["B"], device=torch.device("cuda:0"), a_hat=a_hat)
+                                  max_batch=c["B"], device=torch.device("cuda:0"))
         t = torch.from_numpy(idx32).cuda()
         eng.forward()
         eng.loss_backward(t, BETA)
@@ -155,7 +157,7 @@ def test_config4_sharded_plan_equals_single_gpu_plan(config3, world):
         res["w1"] = eng.params[0].cpu().numpy()
         return res
 
-    out = _threaded(world, rank_fn)
+    out = _threaded(world, rank_fn, comms)
     assert sum(o["rows"] for o in out) == c["n"]
     for o in out:
         np.testing.assert_array_equal(o["emb"], emb1)

@@ -85,6 +85,7 @@ def _run_native(adj, X, params, L, batches, beta, world, decay=0.3, alpha=1.0, l
         except Exception as e:  # noqa: BLE001
             import traceback
             errors.append((rank, repr(e), traceback.format_exc()))
+            comms[rank].abort()               # release the peers now instead of after the barrier timeout
 
     ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
     [t.start() for t in ts]
@@ -124,8 +125,8 @@ def test_native_sharded_plan_first_step_equals_single_gpu_plan():
     n, d, L = (int(v) for v in g["meta"])
     idx = golden_batches(g)[0]
     res = _run_native(golden_csr(g, "A"), g["X"], golden_params(g, "init"), L, [idx], float(g["beta"]), 3, decay=float(g["decay"]),
-                      alpha=float(g["alpha"]), lr=float(g["lr"]), fused_step=False, a_hat=golden_csr(g, "Ahat"))
-    graph = GssGraph.from_normalized(golden_csr(g, "Ahat"))
+                      alpha=float(g["alpha"]), lr=float(g["lr"]), fused_step=False)
+    graph = GssGraph(golden_csr(g, "A"))        # both normalise on the device: the same A_hat bits
     params = [torch.from_numpy(g["init_" + k].copy()).cuda() for k in ("W1", "b1", "W2", "b2")]
     eng = GssEngine(graph, torch.from_numpy(g["X"]).cuda(), params, num_layers=L, layer_decay=float(g["decay"]), alpha=float(g["alpha"]),
                     lr=float(g["lr"]))
@@ -161,6 +162,7 @@ def test_native_collectives_local_backend():
                 out[rank] = (dst.cpu(), t.cpu())
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
+            comms[rank].abort()
 
     ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
     [t.start() for t in ts]
@@ -204,6 +206,7 @@ def test_native_halo_exchange_local_backend():
                 out[rank] = (recv.cpu(), recv_off)
         except Exception as e:  # noqa: BLE001
             errors.append((rank, repr(e)))
+            comms[rank].abort()
 
     ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
     [t.start() for t in ts]

@@ -1,0 +1,142 @@
+"""-m gpu: building shards without the whole graph on any rank (gcn_drug_repurposing_amd/shards.py) -- device normalisation
+of a shard is bit-identical to the single-GPU A_hat (helpers/helper.py:82-95 semantics), the RMAT row source gives the same
+graph whatever the number of ranks, and a sharded step on it equals the single-GPU plan."""
+import threading
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import golden_csr, load_golden
+from oracle import gss_oracle as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _threaded(world, fn, comms=None):
+    out, errors = [None] * world, []
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                out[rank] = fn(rank)
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+            if comms is not None:
+                comms[rank].abort()           # release the peers now instead of after the barrier timeout
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(900) for t in ts]
+    assert not errors, errors
+    assert all(o is not None for o in out), "a rank thread did not finish"
+    return out
+
+
+def _assemble(out, n):
+    """per-rank (lo, indptr, global cols, vals) -> scipy CSR [n, n]"""
+    rows, cols, vals = [], [], []
+    for lo, ip, gc, v in out:
+        cnt = np.diff(ip)
+        rows.append(np.repeat(np.arange(lo, lo + len(cnt)), cnt))
+        cols.append(gc)
+        vals.append(v)
+    m = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    m.sort_indices()
+    return m
+
+
+def _shard_dump(shard, rank, which="a"):
+    csr = shard.a if which == "a" else shard.at
+    halo = shard.layout.halo_a if which == "a" else shard.layout.halo_at
+    lo, hi = shard.part.rows(rank)
+    op2gid = np.concatenate([np.arange(lo, hi), halo.remote]).astype(np.int64)
+    col = csr.col.cpu().numpy()[:csr.nnz]
+    return lo, csr.h_indptr.copy(), op2gid[col], csr.val.cpu().numpy()[:csr.nnz].copy()
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_device_normalised_shards_are_bit_identical_to_single_gpu_a_hat(world):
+    from gcn_drug_repurposing_amd.dist import local_comms
+    from gcn_drug_repurposing_amd.graph import GssGraph
+    from gcn_drug_repurposing_amd.shards import ScipySource, build_shard
+    g = load_golden("edge_n600_d128_L2")           # an asymmetric weighted edgelist adjacency
+    adj = golden_csr(g, "A")
+    n = adj.shape[0]
+    ref = GssGraph(adj)
+    comms = local_comms(world)
+
+    def fn(rank):
+        shard = build_shard(ScipySource(adj), comms[rank], need_transpose=True, device="cuda:0")
+        return _shard_dump(shard, rank, "a"), _shard_dump(shard, rank, "at"), shard.rowsum.cpu().numpy(), shard.layout.halo_fraction()
+
+    out = _threaded(world, fn, comms)
+    a = _assemble([o[0] for o in out], n)
+    at = _assemble([o[1] for o in out], n)
+    ra, rat = ref.a.to_scipy(), ref.at.to_scipy()
+    ra.sort_indices(), rat.sort_indices()
+    for got, want in ((a, ra), (at, rat)):
+        assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+        assert np.array_equal(got.data, want.data)                                   # the same bits as gss_normalize_adj
+    assert np.array_equal(np.concatenate([o[2] for o in out]), ref.rowsum.cpu().numpy())
+    a_hat, _ = O.preprocess_graph(adj)                                               # and the reference's values to 1 ulp
+    assert np.abs(a.toarray() - a_hat.toarray().astype(np.float32)).max() <= np.spacing(np.float32(np.abs(a.data).max()))
+    if world > 1:
+        assert all(0.0 < o[3][0] <= 1.0 for o in out)
+
+
+def test_rmat_source_is_the_same_graph_on_any_number_of_ranks_and_trains_like_one_gpu():
+    from gcn_drug_repurposing_amd.dist import local_comms
+    from gcn_drug_repurposing_amd.engine import GssEngine
+    from gcn_drug_repurposing_amd.graph import GssGraph
+    from gcn_drug_repurposing_amd.shards import RmatSource, build_shard, gaussian_rows, shard_engine
+    n, m, d, L, B = 6000, 70000, 64, 2, 512
+    np.random.seed(3)
+    p = O.init_layer_weights(d, 1e-2)
+    idx = np.random.RandomState(2).permutation(n)[:B].astype(np.int32)
+    graphs, runs = {}, {}
+    for world in (1, 3):
+        comms = local_comms(world)
+
+        def fn(rank):
+            src = RmatSource(n, m, seed=4, device="cuda:0", chunk=1 << 15)        # several rounds
+            shard = build_shard(src, comms[rank], need_transpose=True, device="cuda:0")
+            lo, hi = shard.part.rows(rank)
+            eng = shard_engine(shard, gaussian_rows(lo, hi, d, 5), p, comms[rank], num_layers=L, layer_decay=0.3, alpha=1.0, lr=1e-3, max_batch=B)
+            t = torch.from_numpy(idx).cuda()
+            eng.forward()
+            eng.loss_backward(t, 0.25)
+            res = dict(dump=_shard_dump(shard, rank, "a"), dump_t=_shard_dump(shard, rank, "at"), nnz=shard.nnz_global, rounds=src.rounds,
+                       emb=eng.gather_embeddings().cpu().numpy(), loss=eng.loss.item(), grads=[g_.cpu().numpy() for g_ in eng.grads])
+            return res
+
+        out = _threaded(world, fn, comms)
+        graphs[world] = (_assemble([o["dump"] for o in out], n), _assemble([o["dump_t"] for o in out], n))
+        runs[world] = out[0]
+        assert all(o["nnz"] == m + n for o in out) and out[0]["rounds"] >= 2
+    a1, at1 = graphs[1]
+    assert a1.nnz == m + n                                                       # exactly m entries + n self loops
+    assert (a1 != at1.T).nnz == 0                                                # the transposed shards are the transpose
+    for k in (0, 1):
+        assert np.array_equal(graphs[3][k].indptr, graphs[1][k].indptr) and np.array_equal(graphs[3][k].indices, graphs[1][k].indices)
+        assert np.array_equal(graphs[3][k].data, graphs[1][k].data)
+    assert a1.diagonal().min() > 0
+    deg = np.diff(a1.indptr)
+    assert deg.max() > 20 * np.median(deg)                                       # RMAT skew
+    # the sharded step equals the one-rank step bit for bit in everything row-wise, and the plain single-GPU plan on the
+    # assembled matrix
+    np.testing.assert_array_equal(runs[3]["emb"], runs[1]["emb"])
+    assert runs[3]["loss"] == runs[1]["loss"]
+    for a, b in zip(runs[3]["grads"], runs[1]["grads"]):
+        assert np.abs(a - b).max() < 1e-5 * np.abs(b).max() + 1e-12
+    graph = GssGraph.from_normalized(a1)
+    params = [torch.from_numpy(p[k].copy()).cuda() for k in ("W1", "b1", "W2", "b2")]
+    eng = GssEngine(graph, torch.from_numpy(gaussian_rows(0, n, d, 5)).cuda(), params, num_layers=L, layer_decay=0.3, alpha=1.0, lr=1e-3, max_batch=B)
+    eng.forward()
+    eng.loss_backward(torch.from_numpy(idx).cuda(), 0.25)
+    np.testing.assert_array_equal(eng.emb.cpu().numpy(), runs[1]["emb"])
+    assert eng.loss.item() == runs[1]["loss"]
