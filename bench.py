@@ -81,13 +81,14 @@ def build_workload(name, d_override=None):
         d, L, B = 256, 3, 2048
         x = synth.gaussian_features(adj.shape[0], d_override or d, seed=3)
     elif name.startswith("rmat"):
-        # rmat:<nodes>:<edges>, default a 1/10-scale version of BASELINE config 5 that builds in ~1 minute
+        # rmat:<nodes>:<edges>, default a 1/10-scale version of BASELINE config 5.  No matrix on the host: the edge stream is
+        # generated on the device and every rank keeps the rows it owns (shards.RmatSource); features per row block
+        from gcn_drug_repurposing_amd.shards import RmatSource
         parts = name.split(":")
         n = int(parts[1]) if len(parts) > 1 else 1_000_000
         m = int(parts[2]) if len(parts) > 2 else 20_000_000
-        adj = synth.rmat_adj(n, m, seed=4)
         d, L, B = 128, 2, 2048
-        x = synth.gaussian_features(n, d_override or d, seed=5)
+        return RmatSource(n, m, seed=4), None, (d_override or d), L, B
     else:
         raise SystemExit(f"unknown workload {name}")
     return adj, x, (d_override or d), L, B
@@ -232,7 +233,8 @@ def main():
     pkg.load()
 
     adj, x_host, d, L, B = build_workload(args.workload, args.hidden_units)
-    n = adj.shape[0]
+    from_source = x_host is None           # a row source instead of a matrix in memory (RMAT)
+    n = adj.n if from_source else adj.shape[0]
     B = min(B, n)
     steps_per_epoch = (n + B - 1) // B
     rng = np.random.RandomState(1234)
@@ -253,14 +255,30 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-    if sharded and not args.python_sharded:
-        # the native path: a gss_plan per rank that owns an RCCL communicator (gss_plan_create_sharded); torch.distributed
-        # only hands the communicator's 128-byte id around and takes the MAX of the timings
-        from gcn_drug_repurposing_amd.dist import rccl_comm, sharded_plan_engine
-        comm = rccl_comm(world, rank)
-        engine = sharded_plan_engine(adj, x_host, params_host, comm, num_layers=L, layer_decay=decay, alpha=alpha, lr=lr, max_batch=B)
+    halo_info = None
+    if from_source or (sharded and not args.python_sharded):
+        # the native sharded path (also world = 1 for a row source): a gss_plan per rank that owns an RCCL communicator
+        # (gss_plan_create_sharded); torch.distributed only hands the communicator's 128-byte id around and takes the MAX of
+        # the timings.  Every rank builds its own rows only (shards.build_shard).
+        from gcn_drug_repurposing_amd.dist import local_comms, rccl_comm
+        from gcn_drug_repurposing_amd.shards import ScipySource, build_shard, gaussian_rows, shard_engine
+        comm = rccl_comm(world, rank) if sharded else local_comms(1)[0]
+        t_setup = time.perf_counter()
+        shard = build_shard(adj if from_source else ScipySource(adj), comm, need_transpose=L > 1)
+        lo_, hi_ = shard.part.rows(rank)
+        x_rows = gaussian_rows(lo_, hi_, d, 5) if from_source else x_host[lo_:hi_]
+        engine = shard_engine(shard, x_rows, params_host, comm, num_layers=L, layer_decay=decay, alpha=alpha, lr=lr, max_batch=B)
+        torch.cuda.synchronize()
         nnz = engine.global_nnz
-        parallelism = f"node-range shards x{world}, native plan, RCCL all-gather per SpMM hop"
+        fa, ft = shard.layout.halo_fraction()
+        halo_info = {"rows": int(hi_ - lo_), "halo_rows_a": int(shard.layout.halo_a.n_halo),
+                     "halo_rows_at": int(shard.layout.halo_at.n_halo) if shard.layout.halo_at is not None else 0,
+                     "halo_fraction_a": fa, "halo_fraction_at": ft, "setup_s": time.perf_counter() - t_setup,
+                     "plan_bytes": engine.device_bytes()}
+        parallelism = (f"node-range shards x{world}, native plan, boundary rows by grouped ncclSend/ncclRecv per SpMM hop" if sharded
+                       else "single (native plan on a one-rank shard)")
+        if shard.relabel is not None:
+            parallelism += "; nodes relabelled hub-first"
     elif not sharded:
         from gcn_drug_repurposing_amd.engine import GssEngine
         graph = GssGraph(adj, need_transpose=L > 1)
@@ -334,12 +352,15 @@ def main():
                                f"visits only entries whose neighbour is a batch row)",
                    "parallelism": parallelism, "final_loss": loss_end},
     }
+    if halo_info is not None:
+        # what this rank exchanges per SpMM hop (rank 0's shard; shards are nnz-balanced, so their row counts differ)
+        out["shard"] = halo_info
     if long_run:
         out["long_run"] = long_run
         out["long_run"]["edges_per_s"] = spmm_per_step * nnz / (long_run["ms_per_step"] * 1e-3)
 
     # ---- roofline leg: HIP events around every kernel class over the same steps (rank 0) ----
-    single = not sharded
+    single = world == 1 and not os.environ.get("GSS_FORCE_SHARDED") == "1"
     if single or not args.python_sharded:
         engine.profile(True)
         run(args.warmup, args.warmup + args.steps)
@@ -380,7 +401,7 @@ def main():
             out["mfma_dense_fwd"] = {"achieved": fl / (dense_ms / dense_cnt * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                                      "unit": "TFLOP/s"}
             out["mfma_dense_fwd"]["frac"] = out["mfma_dense_fwd"]["achieved"] / MFMA_F32_PEAK_TFLOPS
-        if args.cache_layer1:
+        if args.cache_layer1 and not from_source:
             from gcn_drug_repurposing_amd.engine import GssEngine
             eng2 = GssEngine(graph, feats, [p.clone() for p in params], num_layers=L, layer_decay=decay, alpha=alpha, lr=lr,
                              max_batch=B, cache_layer1=True)
@@ -394,7 +415,7 @@ def main():
             out["ms_per_step_layer1_cached"] = (time.perf_counter() - t1) / args.steps * 1e3
 
     # ---- CPU baseline leg (rank 0, N=1 only): the reference's torch-CPU op sequence on the host cores ----
-    if rank == 0 and not sharded and not args.no_cpu_baseline:
+    if rank == 0 and not sharded and not from_source and not args.no_cpu_baseline:
         from oracle import gss_oracle as O
         from oracle.torch_cpu_path import TorchCpuPath
         a_hat, _ = O.preprocess_graph(adj)

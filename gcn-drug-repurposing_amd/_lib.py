@@ -21,7 +21,8 @@ class GssError(RuntimeError):
 class PlanDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("d", C.c_int32), ("num_layers", C.c_int32), ("max_batch", C.c_int32),
                 ("layer_decay", C.c_float), ("alpha", C.c_float), ("lr", C.c_float), ("beta1", C.c_float),
-                ("beta2", C.c_float), ("eps", C.c_float), ("cache_layer1", C.c_int32), ("pipeline_layer1", C.c_int32)]
+                ("beta2", C.c_float), ("eps", C.c_float), ("cache_layer1", C.c_int32), ("pipeline_layer1", C.c_int32),
+                ("node_map", C.c_void_p)]
 
 
 class PprDesc(C.Structure):
@@ -57,6 +58,7 @@ SIGNATURES = {
     "gss_scale_adj_shard": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _I32, _P, _P]),
     "gss_csr_create": (C.c_int, [C.POINTER(_P), _I32, _I32, _I64, _P, _P, _P, _P]),
     "gss_csr_destroy": (None, [_P]),
+    "gss_csr_set_hot": (C.c_int, [_P, _I32, _I32, _I32]),
     "gss_spmm": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P]),
     "gss_spmm_bwd1": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "gss_spmm_bwd2": (C.c_int, [_P, _I32, _P, _P, _P, _F, _P, _P, _P, _P]),

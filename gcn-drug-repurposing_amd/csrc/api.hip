@@ -6,6 +6,8 @@ thread_local char g_err[512] = "";
 extern int g_spmm_variant;  // spmm.hip
 extern int g_spmm_slices;
 extern int g_spmm_pin;
+extern int g_spmm_hot;
+extern int g_spmm_fly;
 extern int g_seg_edges;
 extern int g_gemm_variant;  // dense.hip
 }  // namespace gss
@@ -27,6 +29,16 @@ int gss_debug_set_option(const char *name, int value) {
   if (strcmp(name, "spmm_pin") == 0) {
     GSS_REQUIRE(value == 0 || value == 1, "spmm_pin must be 0 or 1");
     g_spmm_pin = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "spmm_fly") == 0) {
+    GSS_REQUIRE(value == 4 || value == 8, "spmm_fly must be 4 or 8");
+    g_spmm_fly = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "spmm_hot_rows") == 0) {
+    GSS_REQUIRE(value >= -1, "spmm_hot_rows must be >= -1");
+    g_spmm_hot = value;
     return GSS_OK;
   }
   if (strcmp(name, "spmm_slices") == 0) {

@@ -12,6 +12,7 @@ struct gss_csr {
   int32_t n_long;
   int32_t *d_long_rows;
   int32_t max_row;
+  int32_t hot_own, hot_halo0, hot_halo1;  // gss_csr_set_hot: operand rows [0, hot_own) and [hot_halo0, hot_halo1) are the hubs' (-1: no split)
   std::vector<int32_t> h_rowptr;  // host copy, used to build segment descriptors lazily
   int32_t *d_segs[5];             // balanced SpMM: int4 descriptors per lane group, by log2(groups per wave)
   int32_t n_seg_blocks[5];
@@ -67,8 +68,8 @@ int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b,
 // dst[rows[r]] += src[r] unless rows[r] < 0 or keep[r] == 0 (keep nullable); pos_clear != NULL: also pos_clear[pos_ids[r]] = -1
 int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, const float *keep, int32_t b, float *dst, int32_t *pos_clear,
                      const int32_t *pos_ids, void *stream);
-int shard_batch_ids(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int32_t *gid2op, int32_t *pid, int32_t *rloc, float *keep,
-                    void *stream);
+int shard_batch_ids(const int32_t *idx, int32_t b, const int32_t *node_map, int32_t lo, int32_t nl, const int32_t *gid2op, int32_t *pid,
+                    int32_t *rloc, float *keep, void *stream);
 int pack_rows(int32_t d, const float *src, const int32_t *rows, int64_t n, float *out, void *stream);
 int shard_batch_maps(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
                      int32_t *rows_all, int32_t *rows_own, float *keep, int32_t *pos_col, int32_t *pos_row, void *stream);

@@ -127,8 +127,9 @@ void carve(gss_plan *p, Carver &c) {
   const size_t n_send = (size_t)std::max(p->halo_a.n_send, p->halo_t.n_send);
   p->sendbuf = sharded ? c.take<float>((n_send ? n_send : 1) * D.d) : nullptr;
   p->x0op = sharded ? c.take<float>(nd_a) : const_cast<float *>(p->x);
-  p->pid = sharded ? c.take<int32_t>(D.max_batch) : nullptr;
-  p->rloc = sharded ? c.take<int32_t>(D.max_batch) : nullptr;
+  const bool maps = sharded || D.node_map != nullptr;   // per-batch index maps are needed
+  p->pid = maps ? c.take<int32_t>(D.max_batch) : nullptr;
+  p->rloc = maps ? c.take<int32_t>(D.max_batch) : nullptr;
   p->keep = sharded ? c.take<float>(D.max_batch) : nullptr;
   p->ax.assign(L, nullptr);
   p->am.assign(L, nullptr);
@@ -440,13 +441,13 @@ struct BatchView {
 };
 
 int plan_batch_view(gss_plan *p, const int32_t *idx, int32_t b, BatchView &v, void *stream) {
-  if (p->P == 1) {
+  if (p->P == 1 && !p->desc.node_map) {
     v = BatchView{idx, idx, nullptr};
     return GSS_OK;
   }
   PROF(GSS_PROF_ELEMENTWISE);
-  v = BatchView{p->rloc, p->pid, p->keep};
-  return shard_batch_ids(idx, b, p->lo, p->desc.n, p->gid2op_t, p->pid, p->rloc, p->keep, stream);
+  v = BatchView{p->rloc, p->pid, p->keep};   // keep stays NULL on one GPU (every row is owned)
+  return shard_batch_ids(idx, b, p->desc.node_map, p->lo, p->desc.n, p->gid2op_t, p->pid, p->rloc, p->keep, stream);
 }
 
 int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float *de_rows, bool top_done, bool wt_ok, void *stream,
@@ -655,7 +656,7 @@ int gss_plan_loss_backward(gss_plan *p, const int32_t *idx, int32_t b, float bet
 }
 int gss_plan_backward(gss_plan *p, const int32_t *rows, int32_t b, const float *de_rows, void *stream) {
   GSS_REQUIRE(p && rows, "plan_backward: null argument");
-  GSS_REQUIRE(p->P == 1, "plan_backward: an external upstream gradient is not supported on a sharded plan");
+  GSS_REQUIRE(p->P == 1 && !p->desc.node_map, "plan_backward: an external upstream gradient is not supported on a sharded or relabelled plan");
   p->wt_valid = false;
   const BatchView bv{rows, rows, nullptr};
   return plan_backward_impl(p, bv, b, de_rows, false, false, stream);
@@ -684,7 +685,7 @@ int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *
     PROF(GSS_PROF_ADAM);
     float *params[4] = {p->w1, p->b1, p->w2, p->b2};
     if (int rc = wgrad_reduce_adam(D.d, p->wgrad_ws, p->wg_total, slices, p->grad, params, p->adam_m, p->adam_v, p->step, D.lr, D.beta1,
-                                   D.beta2, D.eps, wt ? p->w1t : nullptr, wt ? p->w2t : nullptr, sparse_top ? p->pos : nullptr, idx, b,
+                                   D.beta2, D.eps, wt ? p->w1t : nullptr, wt ? p->w2t : nullptr, sparse_top ? p->pos : nullptr, bv.ids, b,
                                    stream))
       return rc;
   } else {

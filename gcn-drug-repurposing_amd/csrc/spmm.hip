@@ -227,9 +227,9 @@ __device__ __forceinline__ long compact_off(const SpmmEpi &ep, int row, int d4, 
   return pr >= 0 ? ((long)pr * d4 + f4) * 4 : -1;
 }
 
-template <int MODE, int LPR_LOG2, int VPL, bool NARROW>
+template <int MODE, int LPR_LOG2, int VPL, bool NARROW, int FLY = 4>
 __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, const int4 *__restrict__ segs, int d4,
-                                                                   const float *__restrict__ x, SpmmEpi ep, int rowstride_f, int pin_ns) {
+                                                                   const float *__restrict__ x, SpmmEpi ep, int rowstride_f, int pin_ns, int3 hot) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *part = reinterpret_cast<float4 *>(smem);  // [16 waves][d4]
   // pin_ns > 0: 1-D grid, slice = blockIdx.x % pin_ns.  Workgroups go to the XCDs round-robin by linear id, so XCD k
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
     // kFly row gathers in flight per lane group.  Measured at config 2 (d = 128): 16 -> 44.1 us, 8 -> 39.5 us,
     // 4 -> 36.2 us, 2 -> 37.7 us.  Deeper queues only add L2 thrash; at 4 the kernel needs 48 VGPRs, so two
     // 1024-thread workgroups share a CU (32 waves) instead of one.
-    constexpr int kFly = 4;
+    constexpr int kFly = FLY;
     for (int t = 0; __any(t < cnt); t += kFly) {
       float4 xv[kFly][VPL];
       float wv[kFly];
@@ -327,10 +327,24 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
           continue;
         }
         const float *xr = x + (size_t)cc * rowstride;
+        // a CSR with a declared hot set (gss_csr_set_hot: nodes relabelled hub-first; operand rows [0, hot.x) and
+        // [hot.y, hot.z) belong to the hubs): every other row is fetched with the non-temporal policy, so that the
+        // once-read cold rows do not evict the hubs' rows from L2 / the Infinity Cache
+        const bool cold = hot.x >= 0 && !(cc < hot.x || (cc >= hot.y && cc < hot.z));
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
           const int f4 = li + v * 64;
-          xv[u][v] = (ok && (VPL == 1 || f4 < d4)) ? ld4(xr + (size_t)f4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float *src = xr + (size_t)f4 * 4;
+          float4 got = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok && (VPL == 1 || f4 < d4)) {
+            if (cold) {
+              const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src));
+              got = make_float4(t[0], t[1], t[2], t[3]);
+            } else {
+              got = ld4(src);
+            }
+          }
+          xv[u][v] = got;
         }
       }
 #pragma unroll
@@ -480,6 +494,8 @@ int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks
   return GSS_OK;
 }
 
+int g_spmm_fly = 4;     // debug knob "spmm_fly": row gathers in flight per lane group on the large-table path (4 or 8)
+int g_spmm_hot = -1;    // debug knob "spmm_hot_rows": overrides every CSR's hot set with rows [0, value) (-1 = use the CSR's own, 0 = none)
 int g_spmm_slices = 0;  // 0 = automatic (see launch_balanced)
 int g_spmm_pin = 0;     // with a manual "spmm_slices": slices pinned to XCDs (1) or time-separated (0)
 
@@ -491,13 +507,20 @@ static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool p
   if (nblk == 0) return GSS_OK;
   CsrView v{a->rowptr, a->col, a->val, a->n_rows};
   const size_t lds = (size_t)kBalWaves * d4_slice * sizeof(float4);
-  const bool narrow = (double)a->n_cols * d4_slice * nslices * 16.0 < 4.0e9 && a->n_cols < (1 << 24);
+  int3 hot = make_int3(a->hot_own, a->hot_halo0, a->hot_halo1);
+  if (g_spmm_hot >= 0) hot = g_spmm_hot > 0 ? make_int3(g_spmm_hot, 0, 0) : make_int3(-1, 0, 0);
+  // the hot / cold split pays where the table is far beyond the caches; below that every row is "hot"
+  if ((double)a->n_cols * d4_slice * nslices * 16.0 < 256.0 * 1024 * 1024 && g_spmm_hot < 0) hot = make_int3(-1, 0, 0);
+  const bool narrow = (double)a->n_cols * d4_slice * nslices * 16.0 < 4.0e9 && a->n_cols < (1 << 24) && hot.x < 0 && g_spmm_fly == 4;
   if (narrow)
     hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, true>), pin ? dim3(nblk * nslices) : dim3(nblk, nslices), dim3(kBalThreads),
-                       lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0);
+                       lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, make_int3(-1, 0, 0));
+  else if (g_spmm_fly == 8)
+    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, false, 8>), pin ? dim3(nblk * nslices) : dim3(nblk, nslices), dim3(kBalThreads),
+                       lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, hot);
   else
     hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, false>), pin ? dim3(nblk * nslices) : dim3(nblk, nslices), dim3(kBalThreads),
-                       lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0);
+                       lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, hot);
   GSS_LAUNCH_CHECK("spmm_balanced_kernel");
   return GSS_OK;
 }
@@ -698,6 +721,8 @@ int gss_csr_create(gss_csr **out, int32_t n_rows, int32_t n_cols, int64_t nnz, c
   a->col = d_col;
   a->val = d_val;
   a->n_long = 0;
+  a->hot_own = -1;
+  a->hot_halo0 = a->hot_halo1 = 0;
   a->d_long_rows = nullptr;
   a->max_row = 0;
   for (int k = 0; k < 5; ++k) {
@@ -739,6 +764,16 @@ int gss_csr_create(gss_csr **out, int32_t n_rows, int32_t n_cols, int64_t nnz, c
   }
   a->h_rowptr.assign(h_rowptr, h_rowptr + (size_t)n_rows + 1);
   *out = a;
+  return GSS_OK;
+}
+
+int gss_csr_set_hot(gss_csr *a, int32_t own_hot, int32_t halo_begin, int32_t halo_end) {
+  GSS_REQUIRE(a, "csr_set_hot: null handle");
+  GSS_REQUIRE(own_hot >= -1 && halo_begin >= 0 && halo_end >= halo_begin && halo_end <= a->n_cols, "csr_set_hot: bad ranges %d [%d, %d)", own_hot,
+              halo_begin, halo_end);
+  a->hot_own = own_hot;
+  a->hot_halo0 = halo_begin;
+  a->hot_halo1 = halo_end;
   return GSS_OK;
 }
 

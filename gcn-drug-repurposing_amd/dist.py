@@ -285,7 +285,7 @@ class ShardLayout:
 
 
 def sharded_plan_engine(adj, x_host, params_host, comm, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4, max_batch=None,
-                        betas=(0.9, 0.999), eps=1e-8, device=None, a_hat=None, cache_layer1=False):
+                        betas=(0.9, 0.999), eps=1e-8, device=None, a_hat=None, cache_layer1=False, relabel="auto"):
     """One rank of the node-range sharded trainer on the NATIVE path: a gss_plan created with gss_plan_create_sharded
     that holds the communicator and enqueues kernels and collectives from C++ (no Python between kernels).  The shard's
     CSRs carry operand-row column ids: own rows first, then the boundary rows its entries reference (Halo).  Returns a
@@ -296,10 +296,9 @@ def sharded_plan_engine(adj, x_host, params_host, comm, num_layers=2, layer_deca
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     if a_hat is None:
         # the regular path: this rank's rows only, normalised on the device (shards.py) -- the same bits as GssGraph's A_hat
-        from .shards import ScipySource, build_shard, shard_engine
-        shard = build_shard(ScipySource(adj), comm, need_transpose=num_layers > 1, device=dev)
-        lo, hi = shard.part.rows(rank)
-        return shard_engine(shard, x_host[lo:hi], params_host, comm, num_layers=num_layers, layer_decay=layer_decay, alpha=alpha, lr=lr,
+        from .shards import ScipySource, build_shard, shard_engine, shard_rows
+        shard = build_shard(ScipySource(adj), comm, need_transpose=num_layers > 1, device=dev, relabel=relabel)
+        return shard_engine(shard, shard_rows(shard, x_host), params_host, comm, num_layers=num_layers, layer_decay=layer_decay, alpha=alpha, lr=lr,
                             max_batch=max_batch, betas=betas, eps=eps, cache_layer1=cache_layer1)
     # a_hat given (an already normalised matrix, e.g. the reference's preprocess_graph output in tests): slice it on the host
     a_hat = sp.csr_matrix(a_hat)

@@ -18,7 +18,8 @@ PARAM_NAMES = ("W1", "b1", "W2", "b2")
 
 class GssEngine:
     def __init__(self, graph, x: torch.Tensor, params, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4,
-                 max_batch=None, cache_layer1=False, betas=(0.9, 0.999), eps=1e-8, pipeline_layer1=False, shard=None, comm=None):
+                 max_batch=None, cache_layer1=False, betas=(0.9, 0.999), eps=1e-8, pipeline_layer1=False, shard=None, comm=None,
+                 node_map=None):
         """shard = dist.ShardLayout + comm (dist.Comm): one shard of a node-range sharded replica
         (gss_plan_create_sharded); graph.a / graph.at then hold this shard's rows with operand-row column ids and
         x / emb this shard's rows.  Every method is then a collective over the shards."""
@@ -30,6 +31,9 @@ class GssEngine:
         self.graph, self.x = graph, x
         self.n, self.d, self.num_layers = n, d, int(num_layers)
         self.shard, self.comm = shard, comm
+        # relabelled graphs (shards.build_shard(relabel=...)): node_map[original id] = row the node lives in (device int32 [N]);
+        # batches keep naming original ids, gather_embeddings() returns original order
+        self.node_map = node_map
         self.n_global = int(shard.bounds[-1]) if shard is not None else n
         self.max_batch = int(max_batch or self.n_global)
         self.params = list(params)
@@ -43,7 +47,7 @@ class GssEngine:
         self.lib = _lib.load()
         self.desc = _lib.PlanDesc(n, d, self.num_layers, self.max_batch, float(layer_decay), float(alpha), float(lr),
                                   float(betas[0]), float(betas[1]), float(eps), 1 if cache_layer1 else 0,
-                                  1 if (pipeline_layer1 and not cache_layer1) else 0)
+                                  1 if (pipeline_layer1 and not cache_layer1) else 0, _lib.ptr(node_map))
         io = _lib.PlanIO(x.data_ptr(), *[p.data_ptr() for p in self.params], self.emb.data_ptr(), self.loss.data_ptr(),
                          *[g.data_ptr() for g in self.grads])
         self._param_ptrs = [p.data_ptr() for p in self.params]
@@ -93,14 +97,21 @@ class GssEngine:
     def gather_embeddings(self) -> torch.Tensor:
         """the full [N][d] embeddings in node order (a collective on a sharded plan; the plan's own tensor otherwise)"""
         if self.shard is None:
-            return self.emb
-        out = torch.empty(self.n_global, self.d, dtype=torch.float32, device=self.x.device)
-        _lib.check(self.lib.gss_plan_gather_embeddings(self.handle, out.data_ptr(), _lib.current_stream()), "gss_plan_gather_embeddings")
+            out = self.emb
+        else:
+            out = torch.empty(self.n_global, self.d, dtype=torch.float32, device=self.x.device)
+            _lib.check(self.lib.gss_plan_gather_embeddings(self.handle, out.data_ptr(), _lib.current_stream()), "gss_plan_gather_embeddings")
+        if self.node_map is not None:
+            out = out.index_select(0, self.node_map.long())       # row of original node i = row node_map[i] of the relabelled graph
         return out
 
     def percentile(self, q: float) -> float:
         """beta = np.percentile(E E^T, q) of the current embeddings (train.py:165-167), exact, on device."""
-        e = self.gather_embeddings()
+        nm, self.node_map = self.node_map, None               # the percentile of E E^T does not depend on the row order
+        try:
+            e = self.gather_embeddings()
+        finally:
+            self.node_map = nm
         out = C.c_float()
         _lib.check(self.lib.gss_percentile(self.n_global, self.d, e.data_ptr(), float(q), C.byref(out), _lib.current_stream()),
                    "gss_percentile")

@@ -73,16 +73,23 @@ class ScipySource:
     def work(self, comm, device):
         return (np.diff(self.a.indptr) + np.diff(self.at.indptr)).astype(np.int64)
 
-    def _rows(self, m, lo, hi, device):
-        sub = m[lo:hi]
-        return (torch.from_numpy(sub.indptr.astype(np.int32)).to(device), torch.from_numpy(sub.indices.astype(np.int32)).to(device),
+    def _rows(self, m, lo, hi, device, relabel):
+        if relabel is None:
+            sub = m[lo:hi]
+            cols = sub.indices
+        else:
+            # rows lo..hi of the relabelled matrix = old rows perm[lo:hi]; entries stay in ascending OLD column order
+            sub = m[relabel.perm[lo:hi]]
+            sub.sort_indices()
+            cols = relabel.inv[sub.indices]
+        return (torch.from_numpy(sub.indptr.astype(np.int32)).to(device), torch.from_numpy(cols.astype(np.int32)).to(device),
                 torch.from_numpy(sub.data.astype(np.float64)).to(device))
 
-    def rows(self, lo, hi, device):
-        return self._rows(self.a, lo, hi, device)
+    def rows(self, lo, hi, device, relabel=None):
+        return self._rows(self.a, lo, hi, device, relabel)
 
-    def rows_t(self, lo, hi, device):
-        return self._rows(self.at, lo, hi, device)
+    def rows_t(self, lo, hi, device, relabel=None):
+        return self._rows(self.at, lo, hi, device, relabel)
 
 
 def _mix64(x: torch.Tensor) -> torch.Tensor:
@@ -132,16 +139,18 @@ class RmatSource:
             yield u[keep], v[keep]
             r += 1
 
-    def _collect(self, lo, hi, rounds, comm=None, want=None):
+    def _collect(self, lo, hi, rounds, comm=None, want=None, inv=None):
         """distinct samples with u in [lo, hi) (keyed u * n + v) and with v in [lo, hi) (keyed v * n + u), over `rounds` rounds,
-        or -- rounds None -- until the job holds at least `want` distinct samples"""
+        or -- rounds None -- until the job holds at least `want` distinct samples.  inv (relabelled graph): the row ids are
+        inv[u] / inv[v] (range test and key), the column half of the key stays the generator's id"""
         ku = torch.zeros(0, dtype=torch.int64, device=self.device)
         kv = torch.zeros(0, dtype=torch.int64, device=self.device)
         used = 0
         for u, v in self._chunks(rounds):
-            mu, mv = (u >= lo) & (u < hi), (v >= lo) & (v < hi)
-            ku = torch.unique(torch.cat([ku, u[mu] * self.n + v[mu]]))
-            kv = torch.unique(torch.cat([kv, v[mv] * self.n + u[mv]]))
+            ru, rv = (u, v) if inv is None else (inv[u], inv[v])
+            mu, mv = (ru >= lo) & (ru < hi), (rv >= lo) & (rv < hi)
+            ku = torch.unique(torch.cat([ku, ru[mu] * self.n + v[mu]]))
+            kv = torch.unique(torch.cat([kv, rv[mv] * self.n + u[mv]]))
             used += 1
             if rounds is None:
                 total = int(allgather_host(comm, np.array([ku.numel()], dtype=np.int64), self.device).sum())
@@ -151,9 +160,13 @@ class RmatSource:
                     raise RuntimeError(f"RMAT: {total} distinct entries after {used} rounds, {want} wanted (graph too dense for its id space)")
         return ku, kv, used
 
-    def _uv_key(self, k_by_v):
-        """(v * n + u) -> (u * n + v), the key the hash is taken of"""
-        return (k_by_v % self.n) * self.n + k_by_v // self.n
+    def _uv_key(self, k_by_v, perm=None):
+        """(v * n + u) -> (u * n + v), the key the hash is taken of (generator ids: a relabelled row id goes through perm)"""
+        v = k_by_v // self.n
+        return (k_by_v % self.n) * self.n + (v if perm is None else perm[v])
+
+    def _u_key(self, k_by_u, perm=None):
+        return k_by_u if perm is None else perm[k_by_u // self.n] * self.n + k_by_u % self.n
 
     def prepare(self, comm: Comm):
         """collective: number of rounds, the hash cut that leaves exactly m entries, and every node's work"""
@@ -179,7 +192,7 @@ class RmatSource:
         deg = (torch.bincount(ku // self.n - lo, minlength=hi - lo) + torch.bincount(kv // self.n - lo, minlength=hi - lo) + 2)
         bounds = np.array([r * self.n // P for r in range(P + 1)], dtype=np.int64)
         self._work = allgather_ranges(comm, deg, bounds, self.device).cpu().numpy().astype(np.int64)
-        self._cache = (lo, hi, ku, kv)
+        self._cache = ((lo, hi, False), ku, kv)
         return self
 
     def work(self, comm, device):
@@ -187,29 +200,37 @@ class RmatSource:
             self.prepare(comm)
         return self._work
 
-    def _csr(self, keys, lo, hi):
-        """distinct keys (row * n + col, rows in [lo, hi)) + the diagonal -> CSR of those rows of A + I (unit values)"""
-        diag = torch.arange(lo, hi, dtype=torch.int64, device=self.device) * (self.n + 1)
+    def _csr(self, keys, lo, hi, relabel):
+        """distinct keys (row * n + generator column id, rows in [lo, hi)) + the diagonal -> CSR of those rows of A + I (unit
+        values); a row's entries are in ascending generator-id order, the column ids returned are the relabelled ones"""
+        r = torch.arange(lo, hi, dtype=torch.int64, device=self.device)
+        diag = r * self.n + (r if relabel is None else relabel.perm_dev(self.device)[r])
         keys = torch.sort(torch.cat([keys, diag])).values
         rows = keys // self.n - lo
         rowptr = torch.zeros(hi - lo + 1, dtype=torch.int64, device=self.device)
         rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=hi - lo), 0)
-        return rowptr.to(torch.int32), (keys % self.n).to(torch.int32), torch.ones(keys.numel(), dtype=torch.float64, device=self.device)
+        cols = keys % self.n
+        if relabel is not None:
+            cols = relabel.inv_dev(self.device)[cols]
+        return rowptr.to(torch.int32), cols.to(torch.int32), torch.ones(keys.numel(), dtype=torch.float64, device=self.device)
 
-    def _keys(self, lo, hi):
-        if self._cache is not None and self._cache[0] == lo and self._cache[1] == hi:
-            return self._cache[2], self._cache[3]
-        ku, kv, _ = self._collect(lo, hi, self.rounds)
-        ku = ku[_mix64(ku) < self.cut]
-        kv = kv[_mix64(self._uv_key(kv)) < self.cut]
-        self._cache = (lo, hi, ku, kv)
+    def _keys(self, lo, hi, relabel):
+        tag = (lo, hi, relabel is not None)
+        if self._cache is not None and self._cache[0] == tag:
+            return self._cache[1], self._cache[2]
+        inv = relabel.inv_dev(self.device) if relabel is not None else None
+        perm = relabel.perm_dev(self.device) if relabel is not None else None
+        ku, kv, _ = self._collect(lo, hi, self.rounds, inv=inv)
+        ku = ku[_mix64(self._u_key(ku, perm)) < self.cut]
+        kv = kv[_mix64(self._uv_key(kv, perm)) < self.cut]
+        self._cache = (tag, ku, kv)
         return ku, kv
 
-    def rows(self, lo, hi, device):
-        return self._csr(self._keys(lo, hi)[0], lo, hi)
+    def rows(self, lo, hi, device, relabel=None):
+        return self._csr(self._keys(lo, hi, relabel)[0], lo, hi, relabel)
 
-    def rows_t(self, lo, hi, device):
-        return self._csr(self._keys(lo, hi)[1], lo, hi)
+    def rows_t(self, lo, hi, device, relabel=None):
+        return self._csr(self._keys(lo, hi, relabel)[1], lo, hi, relabel)
 
     def release(self):
         self._cache = None
@@ -232,11 +253,42 @@ def gaussian_rows(lo, hi, d, seed, block=1 << 16):
 # ---------------------------------------------------------------------------------------------------------
 # the builder
 # ---------------------------------------------------------------------------------------------------------
-class Shard:
-    """one rank's part of the graph on the device: a / at (DeviceCSR with operand-row column ids), layout, part"""
+class Relabel:
+    """hub-first node order: perm[new id] = old id by descending work (stored entries of the node's row of A + I and of its
+    transpose), ties in old-id order; inv = its inverse.  Every rank derives the same permutation from the same work array.
+    Why: with the hubs' feature rows contiguous at the head of the operand, the gathers of an SpMM over a table far larger
+    than the caches run 20-30 % faster (tools/spmm_hot_cold.py, profiles/r02_spmm_hot_cold_*.txt)."""
 
-    def __init__(self, a, at, layout, part, nnz_global, rowsum):
+    def __init__(self, work):
+        work = np.asarray(work, dtype=np.int64)
+        self.perm = np.argsort(-work, kind="stable").astype(np.int64)
+        self.inv = np.empty_like(self.perm)
+        self.inv[self.perm] = np.arange(len(work), dtype=np.int64)
+        self._dev = {}
+
+    def perm_dev(self, device):
+        key = ("perm", str(device))
+        if key not in self._dev:
+            self._dev[key] = torch.from_numpy(self.perm).to(device)
+        return self._dev[key]
+
+    def inv_dev(self, device):
+        key = ("inv", str(device))
+        if key not in self._dev:
+            self._dev[key] = torch.from_numpy(self.inv).to(device)
+        return self._dev[key]
+
+
+HOT_ROWS = 65536     # the hubs whose rows are kept in the caches (32 MB at d = 128): measured optimum at RMAT 10M / 200M
+
+
+class Shard:
+    """one rank's part of the graph on the device: a / at (DeviceCSR with operand-row column ids), layout, part; relabel
+    (or None) + node_map (device int32 [N], original id -> row) when the nodes were relabelled"""
+
+    def __init__(self, a, at, layout, part, nnz_global, rowsum, relabel=None, node_map=None):
         self.a, self.at, self.layout, self.part, self.nnz_global, self.rowsum = a, at, layout, part, nnz_global, rowsum
+        self.relabel, self.node_map = relabel, node_map
         self.n = a.n_rows
 
     @property
@@ -244,19 +296,28 @@ class Shard:
         return self.a.nnz
 
 
-def build_shard(source, comm: Comm, need_transpose=True, device=None) -> Shard:
+def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="auto") -> Shard:
+    """relabel: True / False / "auto" (hub-first node order when the graph has >= 250,000 nodes, i.e. when a [N][128] fp32
+    operand no longer fits the Infinity Cache).  Relabelling is invisible in the results: a row's entries keep their original
+    order, so every sum is taken in the same order, batches name original ids (gss_plan_desc.node_map) and
+    GssEngine.gather_embeddings returns original order."""
     from .graph import DeviceCSR
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     lib = _lib.load()
     P, rank = comm.world, comm.rank
     work = np.asarray(source.work(comm, dev), dtype=np.int64)
     n = len(work)
+    if relabel == "auto":
+        relabel = n >= 250_000
+    rl = Relabel(work) if relabel else None
+    if rl is not None:
+        work = work[rl.perm]
     part = Partition(nnz_balanced_ranges(np.concatenate([[0], np.cumsum(work)]), P))
     lo, hi = part.rows(rank)
     nl = hi - lo
     st = _lib.current_stream
 
-    rowptr, col, val = source.rows(lo, hi, dev)
+    rowptr, col, val = source.rows(lo, hi, dev, relabel=rl)
     dinv_local = torch.empty(max(nl, 1), dtype=torch.float64, device=dev)
     rowsum = torch.empty(max(nl, 1), dtype=torch.float64, device=dev)
     _lib.check(lib.gss_rowsum_dinv(nl, rowptr.data_ptr(), _lib.ptr(val), dinv_local.data_ptr(), rowsum.data_ptr(), st()), "gss_rowsum_dinv")
@@ -271,24 +332,37 @@ def build_shard(source, comm: Comm, need_transpose=True, device=None) -> Shard:
         g2o = torch.from_numpy(halo.gid2op).to(dev)
         col_local = g2o[col.long()].contiguous() if col.numel() else col
         csr = DeviceCSR(rowptr.cpu().numpy(), col_local, val32[:col.numel()], nl, nl + halo.n_halo, dev)
+        if rl is not None:
+            # the hubs are nodes [0, HOT_ROWS): this shard's own rows among them, and the head of its halo (ascending ids)
+            own_hot = int(min(max(HOT_ROWS - lo, 0), nl))
+            halo_hot = int(np.searchsorted(halo.remote, HOT_ROWS))
+            _lib.check(lib.gss_csr_set_hot(csr.handle, own_hot, nl, nl + halo_hot), "gss_csr_set_hot")
         return csr, halo
 
     a, halo_a = finish(rowptr, col, val, 0)
     del rowptr, col, val
     at, halo_at = None, None
     if need_transpose:
-        rowptr, col, val = source.rows_t(lo, hi, dev)
+        rowptr, col, val = source.rows_t(lo, hi, dev, relabel=rl)
         at, halo_at = finish(rowptr, col, val, 1)
         del rowptr, col, val
     if hasattr(source, "release"):
         source.release()
     layout = ShardLayout(part, rank, halo_a, halo_at, dev)
-    return Shard(a, at, layout, part, int(source.nnz), rowsum[:nl])
+    node_map = rl.inv_dev(dev).to(torch.int32).contiguous() if rl is not None else None
+    return Shard(a, at, layout, part, int(source.nnz), rowsum[:nl], rl, node_map)
+
+
+def shard_rows(shard: Shard, x_all):
+    """this shard's feature rows out of a full [N][d] host matrix in ORIGINAL node order"""
+    lo, hi = shard.part.rows(shard.layout.rank)
+    return x_all[lo:hi] if shard.relabel is None else x_all[shard.relabel.perm[lo:hi]]
 
 
 def shard_engine(shard: Shard, x_local, params_host, comm: Comm, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4, max_batch=None,
                  betas=(0.9, 0.999), eps=1e-8, cache_layer1=False):
-    """GssEngine over a built shard (gss_plan_create_sharded): x_local = this shard's feature rows (numpy or device tensor)"""
+    """GssEngine over a built shard (gss_plan_create_sharded): x_local = this shard's feature rows (numpy or device tensor;
+    shard_rows() picks them out of a full matrix)"""
     from .engine import GssEngine
     dev = shard.a.rowptr.device
     x = x_local if torch.is_tensor(x_local) else torch.from_numpy(np.ascontiguousarray(x_local, dtype=np.float32))
@@ -296,6 +370,6 @@ def shard_engine(shard: Shard, x_local, params_host, comm: Comm, num_layers=2, l
     params = [torch.from_numpy(np.ascontiguousarray(params_host[k], dtype=np.float32)).to(dev) for k in ("W1", "b1", "W2", "b2")]
     n_global = int(shard.part.bounds[-1])
     eng = GssEngine(shard, x, params, num_layers=num_layers, layer_decay=layer_decay, alpha=alpha, lr=lr, max_batch=max_batch or n_global,
-                    cache_layer1=cache_layer1, betas=betas, eps=eps, shard=shard.layout, comm=comm)
+                    cache_layer1=cache_layer1, betas=betas, eps=eps, shard=shard.layout, comm=comm, node_map=shard.node_map)
     eng.global_nnz, eng.part, eng.layout = shard.nnz_global, shard.part, shard.layout
     return eng

@@ -61,6 +61,12 @@ int gss_scale_adj_shard(int32_t n, int32_t row0, const int32_t *rowptr, const in
 int gss_csr_create(gss_csr **out, int32_t n_rows, int32_t n_cols, int64_t nnz, const int32_t *h_rowptr,
                    const int32_t *d_rowptr, const int32_t *d_col, const float *d_val);
 void gss_csr_destroy(gss_csr *a);
+/* Optional, for graphs whose nodes were relabelled hub-first (descending degree): declare which rows of the dense operand
+ * belong to the hubs -- rows [0, own_hot) and [halo_begin, halo_end) (the second range is for a shard, whose operand holds
+ * the other shards' boundary rows behind its own).  Where the operand is far larger than the caches the SpMM then fetches
+ * every other row with the non-temporal policy, so that once-read rows do not evict the hubs' rows.  own_hot = -1: no split
+ * (the default).  Speed only: results are unchanged. */
+int gss_csr_set_hot(gss_csr *a, int32_t own_hot, int32_t halo_begin, int32_t halo_end);
 
 /* ---- K1/K2  torch.sparse.mm + torch.mul, modules/model.py:163,168-169 -----------------------
  * y = A x  (x: [n_cols][d], y: [n_rows][d]).  If m != NULL also m = y (.) h, h: [n_rows][d]
@@ -245,6 +251,9 @@ typedef struct gss_plan_desc {
   int32_t pipeline_layer1; /* 1: gss_plan_step runs the NEXT step's layer-1 SpMMs (constant inputs) on an internal second
                               stream underneath this step's MFMA-bound kernels; all work still executes every step and
                               the results are bitwise unchanged */
+  const int32_t *node_map; /* NULL, or device int32 [N] (borrowed): the row of every node id a batch may name.  For graphs whose
+                              nodes were relabelled (hub-first, for gather locality): callers keep naming nodes by their
+                              original ids, the plan looks the batch up in this map first */
 } gss_plan_desc;
 
 /* caller-owned tensors the plan reads and writes (all device pointers, fp32) */

@@ -140,3 +140,70 @@ def test_rmat_source_is_the_same_graph_on_any_number_of_ranks_and_trains_like_on
     eng.loss_backward(torch.from_numpy(idx).cuda(), 0.25)
     np.testing.assert_array_equal(eng.emb.cpu().numpy(), runs[1]["emb"])
     assert eng.loss.item() == runs[1]["loss"]
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_hub_first_relabelling_is_invisible_in_the_results(world):
+    """build_shard(relabel=True): nodes renumbered by descending degree (a gather-locality measure for graphs far larger than
+    the caches).  Rows keep the original order of their entries, batches keep naming original ids and the embeddings come back
+    in original order -> embeddings and loss are BIT-identical to the un-relabelled single-GPU plan, gradients equal up to the
+    order in which rows are summed."""
+    from gcn_drug_repurposing_amd.dist import local_comms
+    from gcn_drug_repurposing_amd.engine import GssEngine
+    from gcn_drug_repurposing_amd.graph import GssGraph
+    from gcn_drug_repurposing_amd.shards import RmatSource, ScipySource, build_shard, gaussian_rows, shard_engine, shard_rows
+    from conftest import golden_batches, golden_params
+    g = load_golden("knn_n2000_d64_L3")
+    n, d, L = (int(v) for v in g["meta"])
+    adj, X, p0 = golden_csr(g, "A"), g["X"], golden_params(g, "init")
+    batches = golden_batches(g)
+    kw = dict(num_layers=L, layer_decay=float(g["decay"]), alpha=float(g["alpha"]), lr=float(g["lr"]))
+    ref = GssEngine(GssGraph(adj), torch.from_numpy(X).cuda(), [torch.from_numpy(p0[k].copy()).cuda() for k in ("W1", "b1", "W2", "b2")], **kw)
+    ref.forward()
+    ref.loss_backward(torch.from_numpy(batches[0].astype(np.int32)).cuda(), float(g["beta"]))
+    ref_emb, ref_loss, ref_grads = ref.emb.cpu().numpy().copy(), ref.loss.item(), [t.cpu().numpy().copy() for t in ref.grads]
+    comms = local_comms(world)
+
+    def fn(rank):
+        shard = build_shard(ScipySource(adj), comms[rank], need_transpose=True, device="cuda:0", relabel=True)
+        assert shard.relabel is not None and shard.node_map is not None
+        eng = shard_engine(shard, shard_rows(shard, X), p0, comms[rank], **kw)
+        t = torch.from_numpy(batches[0].astype(np.int32)).cuda()
+        eng.forward()
+        eng.loss_backward(t, float(g["beta"]))
+        res = dict(emb=eng.gather_embeddings().cpu().numpy(), loss=eng.loss.item(), grads=[x.cpu().numpy() for x in eng.grads],
+                   beta=eng.percentile(float(g["beta_pct"])), perm=shard.relabel.perm.copy())
+        eng.adam()
+        losses = [res["loss"]]
+        for idx in batches[1:]:
+            eng.step(torch.from_numpy(idx.astype(np.int32)).cuda(), float(g["beta"]))
+            losses.append(eng.loss.item())
+        res["losses"] = losses
+        return res
+
+    out = _threaded(world, fn, comms)
+    deg = np.diff(sp.csr_matrix(adj).indptr) + np.diff(sp.csr_matrix(adj.T).indptr)
+    assert np.all(np.diff(deg[out[0]["perm"]]) <= 0)                       # hubs first
+    for o in out:
+        np.testing.assert_array_equal(o["emb"], ref_emb)
+        assert o["loss"] == ref_loss
+        assert abs(o["beta"] - float(g["beta"])) < 2e-6
+        for a, b in zip(o["grads"], ref_grads):
+            assert np.abs(a - b).max() < 1e-5 * np.abs(b).max() + 1e-12
+    np.testing.assert_allclose(out[0]["losses"], g["losses"], rtol=2e-4, atol=1e-8)
+    # the RMAT source relabelled = the RMAT source as generated
+    n2, m2, d2 = 5000, 50000, 32
+    np.random.seed(1)
+    p2 = O.init_layer_weights(d2, 1e-2)
+    idx = np.random.RandomState(3).permutation(n2)[:300].astype(np.int32)
+    embs = []
+    for rl in (False, True):
+        c1 = local_comms(1)[0]
+        shard = build_shard(RmatSource(n2, m2, seed=4, device="cuda:0", chunk=1 << 14), c1, need_transpose=True, device="cuda:0", relabel=rl)
+        x_all = gaussian_rows(0, n2, d2, 5)
+        eng = shard_engine(shard, shard_rows(shard, x_all), p2, c1, num_layers=2, lr=1e-3, max_batch=300)
+        eng.forward()
+        eng.loss_backward(torch.from_numpy(idx).cuda(), 0.25)
+        embs.append((eng.gather_embeddings().cpu().numpy(), eng.loss.item(), shard.nnz_global))
+    np.testing.assert_array_equal(embs[0][0], embs[1][0])
+    assert embs[0][1] == embs[1][1] and embs[0][2] == embs[1][2] == m2 + n2

@@ -4,6 +4,6 @@ tag=$1; ctrs=$2; shift 2
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc/$tag; rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 echo "== $tag [$ctrs]"
-timeout -k 5 120 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O -- python3 $R/"$1" "${@:2}" > $O/log.txt 2>&1
+timeout -k 5 ${PMC_TIMEOUT:-300} rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O -- python3 $R/"$1" "${@:2}" > $O/log.txt 2>&1
 echo "rc=$?"
 python3 $R/tools/pmc_summary.py $O ${PMC_FILTER:-spmm}
