@@ -296,7 +296,12 @@ class Shard:
         return self.a.nnz
 
 
-def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="auto") -> Shard:
+ROW_WEIGHT = 12      # what a row costs besides its stored entries (dense projection, weight gradient, epilogue streams), in units
+                     # of one stored entry of A_hat + A_hat^T: measured at RMAT 10M / 200M, d = 128 (2.15 ns per row and step against
+                     # 0.064 ns per entry visit, 3 visits per entry)
+
+
+def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="auto", row_weight=ROW_WEIGHT) -> Shard:
     """relabel: True / False / "auto" (hub-first node order when the graph has >= 250,000 nodes, i.e. when a [N][128] fp32
     operand no longer fits the Infinity Cache).  Relabelling is invisible in the results: a row's entries keep their original
     order, so every sum is taken in the same order, batches name original ids (gss_plan_desc.node_map) and
@@ -312,7 +317,8 @@ def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="a
     rl = Relabel(work) if relabel else None
     if rl is not None:
         work = work[rl.perm]
-    part = Partition(nnz_balanced_ranges(np.concatenate([[0], np.cumsum(work)]), P))
+    # contiguous node ranges of equal cost: stored entries + a per-row share for the dense kernels
+    part = Partition(nnz_balanced_ranges(np.concatenate([[0], np.cumsum(work + max(0, int(row_weight) - 1))]), P))
     lo, hi = part.rows(rank)
     nl = hi - lo
     st = _lib.current_stream

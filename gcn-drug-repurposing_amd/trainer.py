@@ -133,8 +133,11 @@ def main(argv=None):
         adj = edgelist_adj(src, dst, w, n)
     else:
         adj = knn_descriptor_adj_device(X, args.k, device=dev)   # train.py:93 -> helper.py:39-53, similarity + top-k on device
+    # graphs whose [N][d] operand is far beyond the caches go through the shard builder even on one GPU: it relabels the
+    # nodes hub-first for gather locality (shards.build_shard; invisible in the results)
+    shard_path = sharded or n >= 250_000
     graph = None
-    if not sharded:
+    if not shard_path:
         graph = GssGraph(adj, device=dev, need_transpose=args.num_layers > 1)   # train.py:100-101
         print('Created G with [k={}] [shape=[{}, {}]] [nnz(A_hat)={}] in {:.2f}s'.format(args.k, n, n, graph.nnz, time.time() - t0))
 
@@ -156,11 +159,12 @@ def main(argv=None):
             host_params[k] = w
         for k in ("b1", "b2"):
             host_params[k] = np.concatenate([host_params[k], np.zeros(d_pad - d, np.float32)])
-    if sharded:
+    if shard_path:
         # one process per GPU, node-range shards: a native gss_plan per rank that owns the RCCL communicator and enqueues
         # kernels and collectives from C++ (dist.sharded_plan_engine); same step semantics
-        from .dist import rccl_comm, sharded_plan_engine
-        engine = sharded_plan_engine(adj, X32, host_params, rccl_comm(world, rank), num_layers=args.num_layers, layer_decay=args.layer_decay,
+        from .dist import local_comms, rccl_comm, sharded_plan_engine
+        comm = rccl_comm(world, rank) if sharded else local_comms(1)[0]
+        engine = sharded_plan_engine(adj, X32, host_params, comm, num_layers=args.num_layers, layer_decay=args.layer_decay,
                                      alpha=args.alpha, lr=args.lr, max_batch=min(bsz, n), device=dev, cache_layer1=args.cache_layer1)
         if rank == 0:
             print('Created G with [k={}] [shape=[{}, {}]] [nnz(A_hat)={}] in {:.2f}s; {} node-range shards'.format(
@@ -175,7 +179,7 @@ def main(argv=None):
         params = [torch.from_numpy(host_params[k]).to(dev) for k in ("W1", "b1", "W2", "b2")]
         engine = GssEngine(graph, feats, params, num_layers=args.num_layers, layer_decay=args.layer_decay, alpha=args.alpha,
                            lr=args.lr, max_batch=min(bsz, n), cache_layer1=args.cache_layer1)
-        full_embeddings = lambda: engine.emb          # noqa: E731
+        full_embeddings = engine.gather_embeddings
         percentile = engine.percentile
     loader = DataLoader(_IndexDataset(n), batch_size=bsz, shuffle=True, num_workers=0, drop_last=False)
 

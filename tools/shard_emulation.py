@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""A sharded job on a ONE-GPU box: `world` ranks as threads of this process (gss_comm_create_local), each building only its
+own rows of an RMAT graph (shards.RmatSource / build_shard) and running the native sharded plan.
+usage: shard_emulation.py <nodes> <edges> <world> [steps] [d]
+Reports per rank: rows, stored entries, boundary rows per hop (halo) and their fraction of the other shards' rows, plan
+bytes; for the job: host peak RSS, setup time, ms/step (NOT a performance figure: the ranks share one GPU and the exchanges
+are host-synchronised copies), and the loss after the steps -- compare it with the world = 1 run of the same command."""
+import json
+import os
+import resource
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import gcn_drug_repurposing_amd as pkg  # noqa: E402
+from gcn_drug_repurposing_amd.dist import local_comms  # noqa: E402
+from gcn_drug_repurposing_amd.shards import RmatSource, build_shard, gaussian_rows, shard_engine  # noqa: E402
+
+pkg.load()
+n, m, world = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+d = int(sys.argv[5]) if len(sys.argv) > 5 else 128
+L, B = 2, 2048
+np.random.seed(7)
+w = np.random.randn(d, d) * 1e-5
+np.fill_diagonal(w, 1.0)
+params = {"W1": w.astype(np.float32), "b1": np.zeros(d, np.float32), "W2": w.astype(np.float32).copy(), "b2": np.zeros(d, np.float32)}
+rng = np.random.RandomState(1234)
+batches = [rng.permutation(n)[:B].astype(np.int32) for _ in range(steps + 1)]
+comms = local_comms(world)
+out, errors = [None] * world, []
+rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+
+
+def worker(rank):
+    try:
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            t0 = time.perf_counter()
+            shard = build_shard(RmatSource(n, m, seed=4, device="cuda:0"), comms[rank], need_transpose=True, device="cuda:0")
+            lo, hi = shard.part.rows(rank)
+            eng = shard_engine(shard, gaussian_rows(lo, hi, d, 5), params, comms[rank], num_layers=L, layer_decay=0.3, alpha=1.0, lr=3e-4, max_batch=B)
+            torch.cuda.current_stream().synchronize()
+            setup = time.perf_counter() - t0
+            idx = [torch.from_numpy(b).cuda() for b in batches]
+            eng.step(idx[0], 0.25)
+            torch.cuda.current_stream().synchronize()
+            t1 = time.perf_counter()
+            for k in range(1, steps + 1):
+                eng.step(idx[k], 0.25)
+            torch.cuda.current_stream().synchronize()
+            fa, ft = shard.layout.halo_fraction()
+            out[rank] = dict(rank=rank, rows=hi - lo, nnz=shard.a.nnz, halo_rows_a=shard.layout.halo_a.n_halo, halo_rows_at=shard.layout.halo_at.n_halo,
+                             halo_fraction_a=round(fa, 4), halo_fraction_at=round(ft, 4), send_rows_a=int(shard.layout.halo_a.send_off[-1]),
+                             plan_gb=round(eng.device_bytes() / 2 ** 30, 2), setup_s=round(setup, 1),
+                             ms_per_step=round((time.perf_counter() - t1) / steps * 1e3, 2), loss=eng.loss.item(), relabelled=shard.relabel is not None)
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        errors.append((rank, repr(e), traceback.format_exc()))
+        comms[rank].abort()
+
+
+ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+[t.start() for t in ts]
+[t.join() for t in ts]
+if errors:
+    print(errors[0][2])
+    raise SystemExit(1)
+peak = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+res = dict(nodes=n, edges=m, world=world, d=d, steps=steps, host_peak_rss_gb=round(peak / 2 ** 20, 2), host_rss_before_gb=round(rss0 / 2 ** 20, 2),
+           host_rss_per_rank_gb=round((peak - rss0) / 2 ** 20 / world, 2), gpu_peak_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), ranks=out)
+assert len({o["loss"] for o in out}) == 1, "the replicas disagree on the loss"
+print(json.dumps(res, indent=1))
