@@ -206,3 +206,64 @@ def test_config5_rmat_1m_20m_properties_and_step_vs_cpu_port(rmat1m):
     assert np.abs(emb - e_cpu).max() < 1e-5 and np.abs(emb - emb64).max() < 1e-5
     assert abs(eng.loss.item() - l_cpu) < 1e-5 * abs(l_cpu)
     _check_grads({k: g.cpu().numpy() for k, g in zip(("W1", "b1", "W2", "b2"), eng.grads)}, emb, g64, "rmat 1M")
+
+
+def test_config5_rmat_10m_200m_full_size_sampled_rows():
+    """BASELINE config 5 at FULL size on one GPU (the device row source builds it in ~20 s): exactly 210M stored entries, SpMM
+    adjointness over the whole graph, and a sample of rows of A_hat's row sums, of AX = A_hat X and of the first layer's P
+    recomputed on the host in fp64 from the device's own CSR rows (a full host oracle at this size would take minutes)."""
+    from gcn_drug_repurposing_amd import _lib
+    from gcn_drug_repurposing_amd.dist import local_comms
+    from gcn_drug_repurposing_amd.shards import RmatSource, build_shard, gaussian_rows, shard_engine
+    n, m, d, L, B = 10_000_000, 200_000_000, 128, 2, 2048
+    comm = local_comms(1)[0]
+    shard = build_shard(RmatSource(n, m, seed=4, device="cuda:0"), comm, need_transpose=True, device="cuda:0")
+    assert shard.nnz_global == m + n and shard.a.nnz == m + n and shard.at.nnz == m + n and shard.relabel is not None
+    lib, st = _lib.load(), _lib.current_stream()
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(n, 16, device="cuda", generator=gen)
+    y = torch.randn(n, 16, device="cuda", generator=gen)
+    ax, aty = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(lib.gss_spmm(shard.a.handle, 16, x.data_ptr(), ax.data_ptr(), None, None, st))
+    _lib.check(lib.gss_spmm(shard.at.handle, 16, y.data_ptr(), aty.data_ptr(), None, None, st))
+    lhs, rhs = (ax.double() * y.double()).sum().item(), (x.double() * aty.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), abs(rhs), 1.0)                     # <A x, y> = <x, A^T y>
+    del x, y, ax, aty
+    p = _init(d, 7)
+    X = gaussian_rows(0, n, d, 5)                                                    # rows of the relabelled graph
+    eng = shard_engine(shard, X, p, comm, num_layers=L, layer_decay=DECAY, alpha=ALPHA, lr=LR, max_batch=B)
+    idx = np.random.RandomState(1).permutation(n)[:B].astype(np.int32)
+    eng.forward()
+    eng.loss_backward(torch.from_numpy(idx).cuda(), BETA)
+    torch.cuda.synchronize()
+    assert np.isfinite(eng.loss.item()) and all(torch.isfinite(g).all().item() for g in eng.grads)
+    emb_norm = torch.linalg.norm(eng.emb, dim=1)
+    assert (emb_norm - 1).abs().max().item() < 2e-6
+    # sampled rows (hubs, a stride through the rest, the tail) against fp64 on the host
+    rows = np.unique(np.concatenate([np.arange(0, 40), np.arange(1000, n, n // 300), np.arange(n - 40, n)]))
+    rp = shard.a.h_indptr
+    col = shard.a.col
+    val = shard.a.val
+    AX = eng.activation(0, "AX")
+    AM = eng.activation(0, "AM")
+    P = eng.activation(0, "P")
+    w1, w2 = p["W1"].astype(np.float64), p["W2"].astype(np.float64)
+    worst = 0.0
+    for r in rows:
+        e0, e1 = int(rp[r]), int(rp[r + 1])
+        c = col[e0:e1].cpu().numpy().astype(np.int64)
+        v = val[e0:e1].cpu().numpy().astype(np.float64)
+        ref_ax = v @ X[c].astype(np.float64)
+        got_ax = AX[r].cpu().numpy().astype(np.float64)
+        assert np.abs(got_ax - ref_ax).max() < 1e-5 * max(1.0, np.abs(ref_ax).max()), r
+        # P = AX W1^T + AM W2^T (+ zero biases) from the device's AX / AM rows: checks the projection kernel at this size
+        ref_p = got_ax @ w1.T + AM[r].cpu().numpy().astype(np.float64) @ w2.T
+        worst = max(worst, np.abs(P[r].cpu().numpy() - ref_p).max() / max(1.0, np.abs(ref_p).max()))
+    assert worst < 1e-5
+    # row sums of A_hat of the sampled rows against D^-1/2 (A + I) D^-1/2 recomputed from the unit-weight structure
+    deg = np.diff(rp).astype(np.float64)                                             # row sums of A + I (unit weights)
+    for r in rows[::8]:
+        e0, e1 = int(rp[r]), int(rp[r + 1])
+        c = col[e0:e1].cpu().numpy().astype(np.int64)
+        ref = (deg[r] ** -0.5) * (deg[c] ** -0.5)
+        assert np.abs(val[e0:e1].cpu().numpy() - ref.astype(np.float32)).max() <= 1.2e-7 * ref.max() + 1e-12, r
