@@ -140,6 +140,54 @@ def test_native_sharded_plan_first_step_equals_single_gpu_plan():
         assert np.abs(got - ref).max() < 1e-5 * np.abs(ref).max() + 1e-12
 
 
+@pytest.mark.parametrize("world,L,cache", [(2, 1, False), (5, 3, False), (3, 2, True)])
+def test_native_sharded_plan_other_depths_and_layer1_cache(world, L, cache):
+    """depths the fixtures do not have (L = 1: no A_hat^T, no halo of it; L = 3 at an odd world) and cache_layer1 on shards,
+    against the single-GPU plan: embeddings and losses bit-identical over three steps"""
+    from gcn_drug_repurposing_amd.dist import local_comms, sharded_plan_engine
+    from gcn_drug_repurposing_amd.engine import GssEngine
+    from gcn_drug_repurposing_amd.graph import GssGraph
+    g = load_golden("knn_n2000_d64_L3")
+    adj, X, p0 = golden_csr(g, "A"), g["X"], golden_params(g, "init")
+    batches = golden_batches(g)[:3]
+    kw = dict(num_layers=L, layer_decay=0.4, alpha=1.0, lr=1e-3)
+    ref = GssEngine(GssGraph(adj, need_transpose=L > 1), torch.from_numpy(X).cuda(),
+                    [torch.from_numpy(p0[k].copy()).cuda() for k in ("W1", "b1", "W2", "b2")], cache_layer1=cache, **kw)
+    ref_out = []
+    for idx in batches:
+        ref.step(torch.from_numpy(idx.astype(np.int32)).cuda(), 0.3)
+        ref_out.append((ref.loss.item(), ref.emb.cpu().numpy().copy()))
+    comms = local_comms(world)
+    results, errors = [None] * world, []
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                eng = sharded_plan_engine(adj, X, p0, comms[rank], device=torch.device("cuda:0"), cache_layer1=cache, **kw)
+                out = []
+                for idx in batches:
+                    eng.step(torch.from_numpy(idx.astype(np.int32)).cuda(), 0.3)
+                    out.append((eng.loss.item(), eng.gather_embeddings().cpu().numpy()))
+                results[rank] = out
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+            comms[rank].abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    assert not errors, errors
+    for rank in range(world):
+        for (l_ref, e_ref), (l_got, e_got) in zip(ref_out, results[rank]):
+            # step 1 is bit-identical; later steps see weights whose gradients were summed in another order (fp32)
+            assert abs(l_got - l_ref) < 1e-6 * abs(l_ref) + 1e-9
+            assert np.abs(e_got - e_ref).max() < 2e-6
+        assert results[rank][0][0] == ref_out[0][0]
+        np.testing.assert_array_equal(results[rank][0][1], ref_out[0][1])
+
+
 def test_native_collectives_local_backend():
     """gss_allgather_rows / gss_allreduce_sum through the in-process backend, uneven shards"""
     from gcn_drug_repurposing_amd.dist import local_comms

@@ -88,3 +88,32 @@ def test_cli_argument_errors_match_reference():
         trainer.main(["--emb-file", "x"])
     args = trainer.build_parser().parse_args(["--emb-file", "x", "--dataset", "rparis6k", "--report-hard", "--kq", "7"])
     assert args.epochs == 200 and args.lr == 0.0001 and args.layer_decay == 0.3 and args.hidden_units == 128
+
+
+def test_bench_self_launch_builds_a_torchrun_command(monkeypatch):
+    """python bench.py --gpus N outside a torch.distributed job: N ranks are started as a CHILD torch.distributed.run (never an
+    exec of a process that touched the GPU), the child's JSON line and exit code are relayed"""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=0, stdout='noise\n{"metric": "gcn_spmm_edges_per_s", "n_gpus": 4}\n')
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(types.SimpleNamespace(gpus=4))
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
