@@ -67,6 +67,8 @@ struct gss_plan {
   float *sendbuf;          // packed rows for the peers, [max n_send][d]
   float *x0op;             // the input features with their halo (constant: exchanged once); io.x itself on one GPU
   bool x0_ready;
+  float *m0op;             // layer 1's M = AX (.) X as an operand: its OWN rows are recomputed every step, its halo rows -- the same
+  bool m0_ready;           // constants computed by their owners -- are fetched once (m_tmp itself on one GPU)
   int32_t *pid, *rloc;     // per batch: operand row in A_hat^T's column space (or -1) / local row (clamped) of every member
   float *keep;             // per batch: 1.0 where this shard owns the member
   float *gab;              // [2 * max_batch][d]: the top layer's compact input gradients, all-reduced as one buffer
@@ -142,6 +144,7 @@ void carve(gss_plan *p, Carver &c) {
     p->xin[l] = l == 0 ? p->x0op : c.take<float>(nd_a);       // layer inputs are operands of A_hat
   }
   p->m_tmp = c.take<float>(nd_a);
+  p->m0op = sharded ? c.take<float>(nd_a) : p->m_tmp;
   p->ax0[0] = p->ax[0];
   p->am0[0] = p->am[0];
   const bool pipe = D.pipeline_layer1 != 0;
@@ -252,6 +255,7 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
   p->rows_t = (size_t)desc->n + (size_t)hat;
   p->gid2op_t = (P > 1 && desc->num_layers > 1) ? shard->d_gid2op_t : nullptr;
   p->x0_ready = false;
+  p->m0_ready = false;
   p->a = a;
   p->at = at;
   p->x = io->x;
@@ -405,15 +409,21 @@ int plan_forward_impl(gss_plan *p, void *stream) {
       } else {
         if (int rc = plan_halo(p, p->halo_a, xl, stream)) return rc;
       }
+      // layer 1's inputs are constants, so are the boundary rows of its M: every shard recomputes its own rows each step
+      // (the SpMM is executed), the boundary rows are exchanged once
+      float *m = l == 0 ? p->m0op : p->m_tmp;
       {
         PROF(GSS_PROF_SPMM_FWD_HAD);
-        if (int rc = spmm_fwd(p->a, D.d, xl, p->ax[l], xl, p->m_tmp, stream)) return rc;
+        if (int rc = spmm_fwd(p->a, D.d, xl, p->ax[l], xl, m, stream)) return rc;
       }
       // AM = A M                      (model.py:169)
-      if (int rc = plan_halo(p, p->halo_a, p->m_tmp, stream)) return rc;
+      if (l > 0 || !p->m0_ready) {
+        if (int rc = plan_halo(p, p->halo_a, m, stream)) return rc;
+        if (l == 0) p->m0_ready = true;
+      }
       {
         PROF(GSS_PROF_SPMM_FWD);
-        if (int rc = spmm_fwd(p->a, D.d, p->m_tmp, p->am[l], nullptr, nullptr, stream)) return rc;
+        if (int rc = spmm_fwd(p->a, D.d, m, p->am[l], nullptr, nullptr, stream)) return rc;
       }
       if (l == 0) p->layer1_valid = true;
     }

@@ -280,7 +280,8 @@ int gss_plan_create(gss_plan **out, const gss_plan_desc *desc, const gss_csr *a,
  *   desc->n = rows of THIS shard; io->x / io->emb: this shard's rows; the weights / gradients / loss in io are full-size
  *   and end up identical on every rank.
  * Every gss_plan_* call then is a collective: all ranks call it with the same batch.  Per step the plan enqueues, on the
- * caller's stream, 2L - 1 + max(0, 2L - 3) halo exchanges (C1; the input features' halo is fetched once), one all-reduce of
+ * caller's stream, 2L - 2 + max(0, 2L - 3) halo exchanges (C1; the boundary rows of the input features and of layer 1's M --
+ * constants -- are fetched once; every shard still recomputes its own rows of them each step), one all-reduce of
  * the B gathered batch rows and one of their 2 B d input gradients (C3), and one grouped all-reduce of the four weight
  * gradients (C2); no host round trip in between.  world == 1 is exactly gss_plan_create.  gss_plan_backward (external
  * upstream gradient) is not available on a sharded plan. */
