@@ -87,6 +87,14 @@ SIGNATURES = {
     "gss_adam_step": (C.c_int, [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P, _I32, _P]),
     "gss_percentile": (C.c_int, [_I32, _I32, _P, _D, C.POINTER(_F), _P]),
     "gss_knn_topk": (C.c_int, [_I32, _I32, _P, _I32, _P, _P, _P]),
+    "gss_write_embs_text": (C.c_int, [C.c_char_p, _P, _I64, _I32, _I32]),
+    "gss_format_e18": (C.c_int, [_F, C.c_char_p]),
+    "gss_embs_open": (C.c_int, [C.POINTER(_P), C.c_char_p, _I32]),
+    "gss_embs_rows": (_I64, [_P]),
+    "gss_embs_cols": (_I32, [_P]),
+    "gss_embs_names_bytes": (_I64, [_P]),
+    "gss_embs_copy": (C.c_int, [_P, _P, C.c_char_p, _I64, C.POINTER(_I64)]),
+    "gss_embs_close": (None, [_P]),
     "gss_plan_create": (C.c_int, [C.POINTER(_P), C.POINTER(PlanDesc), _P, _P, C.POINTER(PlanIO)]),
     "gss_plan_create_sharded": (C.c_int, [C.POINTER(_P), C.POINTER(PlanDesc), C.POINTER(ShardDesc), _P, _P, _P, C.POINTER(PlanIO)]),
     "gss_plan_gather_embeddings": (C.c_int, [_P, _P, _P]),

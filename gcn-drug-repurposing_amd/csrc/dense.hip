@@ -350,8 +350,9 @@ static int launch_gemm(const GemmArgs &g, int d, hipStream_t st) {
   if (g_gemm_variant >= 2) {
     const int nt = (d % 128 == 0) ? 8 : (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
     // 64-node tiles give 2-3 co-resident workgroups per CU (epilogue traffic overlaps MFMA); at d >= 256 the
-    // W-staging redundancy of small tiles costs more than that buys (measured, tools/gemm_bench.py)
-    const int mt = g_gemm_variant == 3 ? 2 : g_gemm_variant == 4 ? 1 : (d >= 256 ? 2 : 1);
+    // W-staging redundancy of small tiles costs more than that buys (measured, tools/gemm_bench.py), and so it does once
+    // the grid is many waves of workgroups deep (d = 128: N = 1M 791 -> 753 us, N = 4M 3061 -> 2913 us with 128-node tiles)
+    const int mt = g_gemm_variant == 3 ? 2 : g_gemm_variant == 4 ? 1 : ((d >= 256 || g.n >= 262144) ? 2 : 1);
     dim3 grid(ceil_div(g.n, 64 * mt), g.J / (16 * nt));
     const size_t lds = 4 * (size_t)(64 * mt * 16 + 16 * nt * 16) * sizeof(float);
 #define GSS_GEMM_CASE(NTV)                                                                              \

@@ -12,8 +12,32 @@ from __future__ import annotations
 import numpy as np
 
 
-def read_embs(path):
-    """-> (names: list[str], X: float64 [N, d])"""
+def read_embs(path, threads=0):
+    """-> (names: list[str], X: float64 [N, d]).  The native reader of libgssgcn.so parses the lines on all host cores with
+    strtod (correctly rounded, i.e. the values float() gives); a file it does not accept (ragged rows, odd tokens) goes to the
+    line-by-line parser below, which raises the errors."""
+    try:
+        from . import _lib
+        import ctypes as C
+        lib = _lib.load()
+        h = C.c_void_p()
+        if lib.gss_embs_open(C.byref(h), str(path).encode(), int(threads)) == 0:
+            try:
+                n, d, nb = lib.gss_embs_rows(h), lib.gss_embs_cols(h), lib.gss_embs_names_bytes(h)
+                x = np.empty((n, d), dtype=np.float64)
+                buf = C.create_string_buffer(max(int(nb), 1))
+                hdr = C.c_int64(-1)
+                _lib.check(lib.gss_embs_copy(h, x.ctypes.data, buf, nb, C.byref(hdr)), "gss_embs_copy")
+                names = buf.raw[:nb].decode().split("\n")[:n] if n else []
+                if hdr.value >= 0 and hdr.value != n:
+                    raise ValueError(f"{path}: header says {hdr.value} nodes, file has {n}")
+                return names, x
+            finally:
+                lib.gss_embs_close(h)
+    except ValueError:
+        raise
+    except Exception:  # noqa: BLE001  (library not built, ...): the plain parser decides
+        pass
     names, rows = [], []
     with open(path) as f:
         header = f.readline().split()
@@ -37,8 +61,17 @@ def write_embs(path, names, x):
             f.write(f"{n} {' '.join(str(t) for t in v)}\n")
 
 
-def write_graph_embs(path, emb):
-    np.savetxt(path, np.asarray(emb))
+def write_graph_embs(path, emb, threads=0):
+    """np.savetxt(path, emb) (train.py:193).  float32 input (what the trainer produces) goes through the native writer of
+    libgssgcn.so -- the same bytes, formatted exactly on all host cores; anything else through numpy itself."""
+    emb = np.asarray(emb)
+    if emb.dtype == np.float32 and emb.ndim == 2 and emb.shape[1] >= 1:
+        from . import _lib
+        emb = np.ascontiguousarray(emb)
+        _lib.check(_lib.load().gss_write_embs_text(str(path).encode(), emb.ctypes.data, emb.shape[0], emb.shape[1], int(threads)),
+                   "gss_write_embs_text")
+        return
+    np.savetxt(path, emb)
 
 
 def read_edgelist(path, names=None):

@@ -236,6 +236,26 @@ int gss_ppr_run(gss_ppr *p, double alpha, double tol, int32_t max_iter, double *
 /* one product y = M'^T x on the handle's schedule (fp64; the kernel the iteration is built on) */
 int gss_ppr_spmm(gss_ppr *p, const double *x, double *y, void *stream);
 
+/* ---- a13  np.savetxt('graph_embs.txt', hidden_emb), train.py:193 (host-side; h_emb is a HOST pointer) ---------------------
+ * Every value of the float32 matrix as Python prints it with '%.18e' after widening to double (exact decimal expansion, round
+ * half to even -- byte-identical to np.savetxt's output), ' ' between the values of a row, '\n' after each row.  Rows are
+ * formatted by `threads` host threads (0 = all cores) and written in order.  gss_format_e18: one value into a buffer of >= 26
+ * bytes, returns its length (the unit the writer is tested by). */
+int gss_write_embs_text(const char *path, const float *h_emb, int64_t n, int32_t d, int32_t threads);
+int gss_format_e18(float value, char *out26);
+/* ---- a14  the '.embs.txt' reader, train.py:79-80 (np.loadtxt(..., skiprows=1, dtype=object)[:, 1:].astype(float)) -----------
+ * First line '<N> <d>' (multiscale/openne/node2vec.py:42), then '<node> v1 ... vd' per line; blank lines skipped.  Values are
+ * parsed with strtod (correctly rounded: the doubles Python's float() gives) by `threads` host threads (0 = all cores).
+ * gss_embs_copy: x_out HOST fp64 [rows][cols]; names_out: the node names joined by '\n' (gss_embs_names_bytes bytes);
+ * header_n: the N of the header line or -1.  A ragged or non-numeric line makes gss_embs_open fail. */
+typedef struct gss_embs_file gss_embs_file;
+int gss_embs_open(gss_embs_file **out, const char *path, int32_t threads);
+int64_t gss_embs_rows(const gss_embs_file *e);
+int32_t gss_embs_cols(const gss_embs_file *e);
+int64_t gss_embs_names_bytes(const gss_embs_file *e);
+int gss_embs_copy(const gss_embs_file *e, double *x_out, char *names_out, int64_t names_cap, int64_t *header_n);
+void gss_embs_close(gss_embs_file *e);
+
 /* ---- whole training step (train.py:158-184) ---------------------------------------------------
  * A plan owns every activation/gradient buffer of one replica so that a step is ONE host call that
  * enqueues all kernels.  a / at: CSR(A_hat) and CSR(A_hat^T) (at may be NULL for num_layers == 1). */

@@ -117,3 +117,62 @@ def test_bench_self_launch_builds_a_torchrun_command(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_native_writer_is_byte_identical_to_np_savetxt(tmp_path):
+    """gss_write_embs_text / gss_format_e18 (train.py:193's np.savetxt): exact decimal expansion of widened float32s, round
+    half to even -- every value byte for byte what Python's '%.18e' prints, over random bit patterns, denormals, powers of
+    two and their neighbours, infinities and NaNs"""
+    import ctypes as C
+    from gcn_drug_repurposing_amd import _lib, embio
+    lib = _lib.load()
+    rng = np.random.RandomState(5)
+    bits = np.concatenate([rng.randint(0, 2 ** 32, size=60000, dtype=np.uint64).astype(np.uint32),
+                           np.array([0, 0x80000000, 1, 2, 3, 0x007fffff, 0x00800000, 0x7f7fffff, 0x3f800000, 0x7f800000, 0xff800000, 0x7fc00000,
+                                     0xffc00000, 0x3effffff, 0x4b000000, 0x4b7fffff, 0x4b800000], dtype=np.uint32),
+                           np.arange(1, 255, dtype=np.uint32) << 23, (np.arange(1, 255, dtype=np.uint32) << 23) | 1,
+                           (np.arange(1, 255, dtype=np.uint32) << 23) | 0x7fffff, np.arange(1, 600, dtype=np.uint32)])
+    buf = C.create_string_buffer(32)
+    for v in bits.view(np.float32):
+        n = lib.gss_format_e18(C.c_float(float(v)), buf)
+        want = "%.18e" % float(v)
+        assert buf.value.decode() == want and n == len(want), (v, buf.value, want)
+    x = (rng.randn(777, 48) / 9).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x[5, 7], x[6, 0] = 0.0, -0.0
+    a, b, c = tmp_path / "a.txt", tmp_path / "b.txt", tmp_path / "c.txt"
+    np.savetxt(a, x)
+    embio.write_graph_embs(str(b), x)                    # all cores
+    embio.write_graph_embs(str(c), x, threads=3)
+    assert a.read_bytes() == b.read_bytes() == c.read_bytes()
+    np.testing.assert_array_equal(np.loadtxt(b).astype(np.float32), x)       # and it reads back to the same floats
+    x64 = rng.randn(5, 4)                                # not float32: numpy's own path, still np.savetxt's bytes
+    embio.write_graph_embs(str(b), x64)
+    np.savetxt(a, x64)
+    assert a.read_bytes() == b.read_bytes()
+
+
+def test_native_embs_reader_matches_python_float(tmp_path):
+    """gss_embs_open (train.py:79-80): names in order, values the doubles float() parses, header check, blank lines skipped;
+    malformed files fall through to the strict Python parser"""
+    from gcn_drug_repurposing_amd import embio
+    rng = np.random.RandomState(6)
+    n, d = 1500, 24
+    x = rng.randn(n, d) * np.exp(rng.randn(n, 1) * 8)      # wide range of magnitudes, 17 significant digits each
+    names = [f"GO:{i:07d}" if i % 2 else str(100000 - i) for i in range(n)]
+    p = tmp_path / "e.embs.txt"
+    embio.write_embs(str(p), names, x)
+    text = p.read_text().splitlines()
+    text.insert(7, "")                                    # a blank line in the middle, trailing spaces on another
+    text[20] = text[20] + "  "
+    p.write_text("\n".join(text) + "\n")
+    for threads in (1, 4, 0):
+        got_names, got = embio.read_embs(str(p), threads=threads)
+        assert got_names == names and np.array_equal(got, x)
+    p.write_text(f"{n + 1} {d}\n" + "\n".join(text[1:]) + "\n")
+    with pytest.raises(ValueError, match="header says"):
+        embio.read_embs(str(p))
+    bad = tmp_path / "bad.embs.txt"
+    bad.write_text("2 3\na 1 2 3\nb 1 2\n")                   # ragged: the native reader refuses, the Python parser raises
+    with pytest.raises(Exception):
+        embio.read_embs(str(bad))
