@@ -147,6 +147,16 @@ def whole_graph_standin(seed=1, pathway_edges=False, scale=1):
     return adj, ntype, names
 
 
+def standin_drug_indications():
+    """evaluate_auc.py:156-170's labels for the stand-in: {indication id: set of drug ids} from the 5,926 (drug, indication) pairs of
+    the reference's data/drug_indication_df.tsv (all of them name nodes of the graph: 840 indications, 1,661 drugs)"""
+    R = real_layers()
+    out = {}
+    for a, b in zip(R["drug_indication_drug"], R["drug_indication_indication"]):
+        out.setdefault(R["names_indication"][b], set()).add(R["names_drug"][a])
+    return out
+
+
 def standin_tables(seed=1):
     """the stand-in as the five node_1/node_2 tables MSI.load_graph reads (for a test that rebuilds it with
     msi.MsiGraph): {component: [(node_1, node_2), ...]}; the covid rows ride at the end of the indication table"""

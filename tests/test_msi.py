@@ -97,3 +97,9 @@ def test_real_layer_fixture_is_the_reference_tables_verbatim():
         got = [(R["names_" + t1][a], R["names_" + t2][b]) for a, b in zip(R[stem + "_u"], R[stem + "_v"])]
         assert got == [(r[0], r[1]) for r in rows], stem
     assert int(R["covid_pathway_total"]) == 353 and len(R["covid_pathway_idx"]) == 324
+    with open(os.path.join(ref, "drug_indication_df.tsv"), newline="") as f:
+        rows = list(csv.reader(f, delimiter="\t"))[1:]
+    want = {}
+    for r in rows:
+        want.setdefault(r[2], set()).add(r[0])
+    assert synth.standin_drug_indications() == want and sum(len(v) for v in want.values()) == 5926

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Packs the four non-PPI edge tables of the multiscale interactome that the reference ships
 (/root/reference/data/{drug_to_protein, indication_to_protein, protein_to_functional_pathway,
-functional_pathway_to_functional_pathway}.tsv, + covid_to_protein.tsv and the pathway ids of
-config_gcn_pathway.json's perturbation file) into a data-only fixture:
+functional_pathway_to_functional_pathway}.tsv, + covid_to_protein.tsv, the pathway ids of
+config_gcn_pathway.json's perturbation file and the drug-indication pairs of data/drug_indication_df.tsv, the labels of
+evaluate_auc.py) into a data-only fixture:
 
     gcn-drug-repurposing_amd/data/msi_real_layers.npz
 
@@ -61,6 +62,15 @@ def main():
         pw = sorted({r[col] for r in rows if len(r) > col})
     out["covid_pathway_total"] = np.int64(len(pw))
     out["covid_pathway_idx"] = np.asarray(sorted(ids["pathway"][p] for p in pw if p in ids["pathway"]), np.int32)
+    # evaluate_auc.py:156-170's labels: data/drug_indication_df.tsv (drug, indication) pairs whose two nodes are in the graph
+    with open(os.path.join(REF, "data", "drug_indication_df.tsv"), newline="") as f:
+        rows = csv.reader(f, delimiter="\t")
+        header = next(rows)
+        di, ii = header.index("drug"), header.index("indication")
+        pairs = sorted({(ids["drug"][r[di]], ids["indication"][r[ii]]) for r in rows
+                        if len(r) > max(di, ii) and r[di] in ids["drug"] and r[ii] in ids["indication"]})
+    out["drug_indication_drug"] = np.asarray([a for a, _ in pairs], np.int32)
+    out["drug_indication_indication"] = np.asarray([b for _, b in pairs], np.int32)
     for t, table in ids.items():
         out["names_" + t] = np.frombuffer("\n".join(table).encode(), dtype=np.uint8)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
