@@ -11,7 +11,6 @@ import numpy as np
 import torch
 
 from . import _lib
-from .graph import GssGraph
 
 PARAM_NAMES = ("W1", "b1", "W2", "b2")
 

@@ -14,8 +14,6 @@ O(N) scalars, not O(nnz)).
 """
 from __future__ import annotations
 
-import ctypes as C
-
 import numpy as np
 import scipy.sparse as sp
 import torch

@@ -125,6 +125,38 @@ def test_spmm_all_widths_with_hub_and_empty_rows(G, d, spmm_variant):
     assert torch.equal(y, y2)  # bitwise reproducible, with and without the fused epilogue
 
 
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_spmm_hot_cold_split_and_deeper_queues_do_not_change_a_bit(G, d):
+    """gss_csr_set_hot / the large-table kernel path (non-temporal gathers of the rows outside the hubs' set, 8 gathers in
+    flight): cache policy and queue depth only -- the same bits as the default path, for every epilogue"""
+    rng = np.random.RandomState(d + 1)
+    n = 1300
+    a = random_graph(rng, n, 9, hub_rows=(1, 400), hub_deg=900, empty_rows=(7,))
+    a32 = sp.csr_matrix((a.data.astype(np.float32), a.indices, a.indptr), shape=a.shape)
+    csr = G.graph.DeviceCSR(a32.indptr, a32.indices, a32.data, n, n, "cuda")
+    x, h = cu(rng.randn(n, d).astype(np.float32)), cu(rng.randn(n, d).astype(np.float32))
+
+    def run():
+        y, m = torch.empty(n, d, device="cuda"), torch.empty(n, d, device="cuda")
+        G._lib.check(G.lib.gss_spmm(csr.handle, d, x.data_ptr(), y.data_ptr(), h.data_ptr(), m.data_ptr(), G.st()))
+        return y, m
+
+    base = run()
+    try:
+        for hot, fly in ((n // 3, 4), (5, 4), (0, 8), (n // 2, 8)):
+            G._lib.check(G.lib.gss_debug_set_option(b"spmm_hot_rows", hot))      # overrides the size threshold: forces the split path
+            G._lib.check(G.lib.gss_debug_set_option(b"spmm_fly", fly))
+            got = run()
+            assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]), (hot, fly)
+    finally:
+        G._lib.check(G.lib.gss_debug_set_option(b"spmm_hot_rows", -1))
+        G._lib.check(G.lib.gss_debug_set_option(b"spmm_fly", 4))
+    # the per-CSR declaration (what shards.build_shard sets) is accepted and validated
+    G._lib.check(G.lib.gss_csr_set_hot(csr.handle, 100, n, n))
+    assert G.lib.gss_csr_set_hot(csr.handle, 100, n + 1, n) != 0
+    assert torch.equal(run()[0], base[0])
+
+
 def test_spmm_backward_epilogues(G, spmm_variant):
     rng = np.random.RandomState(5)
     n, d = 900, 128
