@@ -95,6 +95,11 @@ SIGNATURES = {
     "gss_embs_names_bytes": (_I64, [_P]),
     "gss_embs_copy": (C.c_int, [_P, _P, C.c_char_p, _I64, C.POINTER(_I64)]),
     "gss_embs_close": (None, [_P]),
+    "gss_edgelist_open": (C.c_int, [C.POINTER(_P), C.c_char_p, C.c_char_p, _I64, _I64, _I32]),
+    "gss_edgelist_edges": (_I64, [_P]),
+    "gss_edgelist_bad_line": (_I64, [_P]),
+    "gss_edgelist_copy": (C.c_int, [_P, _P, _P, _P]),
+    "gss_edgelist_close": (None, [_P]),
     "gss_plan_create": (C.c_int, [C.POINTER(_P), C.POINTER(PlanDesc), _P, _P, C.POINTER(PlanIO)]),
     "gss_plan_create_sharded": (C.c_int, [C.POINTER(_P), C.POINTER(PlanDesc), C.POINTER(ShardDesc), _P, _P, _P, C.POINTER(PlanIO)]),
     "gss_plan_gather_embeddings": (C.c_int, [_P, _P, _P]),

@@ -18,6 +18,7 @@
 
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -201,9 +202,129 @@ bool parse_lines(const char *text, const std::vector<std::pair<size_t, size_t>> 
 }  // namespace
 }  // namespace gss
 
+// ---- reader of a weighted edgelist ('u v w' per line, nx.write_weighted_edgelist, predict_drug.py:224-226) ----------------------
+struct gss_edgelist_file {
+  std::vector<int32_t> src, dst;
+  std::vector<double> w;
+  int64_t bad_line = -1;  // 0-based line of the first unknown node name, -1 if none
+};
+
 using namespace gss;
 
 extern "C" {
+
+int gss_edgelist_open(gss_edgelist_file **out, const char *path, const char *names, int64_t names_bytes, int64_t n_names, int32_t threads) {
+  GSS_REQUIRE(out && path && (names || n_names == 0) && n_names >= 0, "edgelist_open: bad argument");
+  // node name -> row (the .embs.txt order); views into the caller's '\n'-joined name buffer
+  struct Key {
+    const char *p;
+    size_t len;
+    bool operator==(const Key &o) const { return len == o.len && memcmp(p, o.p, len) == 0; }
+  };
+  struct KeyHash {
+    size_t operator()(const Key &k) const {
+      uint64_t h = 1469598103934665603ull;  // FNV-1a
+      for (size_t i = 0; i < k.len; ++i) h = (h ^ (unsigned char)k.p[i]) * 1099511628211ull;
+      return (size_t)h;
+    }
+  };
+  std::unordered_map<Key, int32_t, KeyHash> index;
+  index.reserve((size_t)n_names * 2);
+  {
+    const char *p = names, *end = names + names_bytes;
+    int32_t row = 0;
+    while (p < end && row < n_names) {
+      const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+      const char *e = nl ? nl : end;
+      index.emplace(Key{p, (size_t)(e - p)}, row++);
+      p = e + 1;
+    }
+    GSS_REQUIRE(row == n_names, "edgelist_open: the name buffer holds %d names, %lld announced", row, (long long)n_names);
+  }
+  FILE *f = fopen(path, "rb");
+  if (!f) return fail(GSS_EINVAL, "edgelist_open: cannot open %s: %s", path, strerror(errno));
+  std::string text;
+  {
+    char chunk[1 << 16];
+    size_t got;
+    while ((got = fread(chunk, 1, sizeof(chunk), f)) > 0) text.append(chunk, got);
+    fclose(f);
+  }
+  std::vector<std::pair<size_t, size_t>> lines;
+  for (size_t pos = 0; pos < text.size();) {
+    const char *nl = (const char *)memchr(text.data() + pos, '\n', text.size() - pos);
+    const size_t end = nl ? (size_t)(nl - text.data()) : text.size();
+    size_t s0 = pos;
+    while (s0 < end && is_space(text[s0])) ++s0;
+    if (s0 < end && text[s0] != '#') lines.push_back({s0, end});
+    pos = end + 1;
+  }
+  gss_edgelist_file *e = new gss_edgelist_file();
+  const size_t m = lines.size();
+  e->src.resize(m);
+  e->dst.resize(m);
+  e->w.resize(m);
+  int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+  nt = std::max(1, std::min(nt, 64));
+  nt = (int)std::min<size_t>((size_t)nt, std::max<size_t>(1, m / 4096));
+  std::vector<int64_t> bad((size_t)nt, -1);
+  auto work = [&](int t) {
+    const size_t l0 = m * (size_t)t / (size_t)nt, l1 = m * (size_t)(t + 1) / (size_t)nt;
+    const char *base = text.c_str();
+    for (size_t li = l0; li < l1; ++li) {
+      const char *p = base + lines[li].first, *end = base + lines[li].second;
+      const char *tok[2];
+      size_t len[2];
+      for (int k = 0; k < 2; ++k) {
+        while (p < end && is_space(*p)) ++p;
+        tok[k] = p;
+        while (p < end && !is_space(*p)) ++p;
+        len[k] = (size_t)(p - tok[k]);
+      }
+      const auto iu = index.find(Key{tok[0], len[0]}), iv = index.find(Key{tok[1], len[1]});
+      if (len[1] == 0 || iu == index.end() || iv == index.end()) {
+        if (bad[(size_t)t] < 0) bad[(size_t)t] = (int64_t)li;
+        continue;
+      }
+      while (p < end && is_space(*p)) ++p;
+      double wt = 1.0;  // an edgelist without weights: unit weights
+      if (p < end) {
+        char *q = nullptr;
+        wt = strtod(p, &q);
+        if (q == p) {
+          if (bad[(size_t)t] < 0) bad[(size_t)t] = (int64_t)li;
+          continue;
+        }
+      }
+      e->src[li] = iu->second;
+      e->dst[li] = iv->second;
+      e->w[li] = wt;
+    }
+  };
+  if (nt == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) pool.emplace_back(work, t);
+    for (auto &th : pool) th.join();
+  }
+  for (int64_t b : bad)
+    if (b >= 0 && (e->bad_line < 0 || b < e->bad_line)) e->bad_line = b;
+  *out = e;
+  return GSS_OK;
+}
+int64_t gss_edgelist_edges(const gss_edgelist_file *e) { return e ? (int64_t)e->src.size() : 0; }
+int64_t gss_edgelist_bad_line(const gss_edgelist_file *e) { return e ? e->bad_line : -1; }
+int gss_edgelist_copy(const gss_edgelist_file *e, int32_t *src, int32_t *dst, double *w) {
+  GSS_REQUIRE(e && ((src && dst && w) || e->src.empty()), "edgelist_copy: null argument");
+  if (!e->src.empty()) {
+    memcpy(src, e->src.data(), sizeof(int32_t) * e->src.size());
+    memcpy(dst, e->dst.data(), sizeof(int32_t) * e->dst.size());
+    memcpy(w, e->w.data(), sizeof(double) * e->w.size());
+  }
+  return GSS_OK;
+}
+void gss_edgelist_close(gss_edgelist_file *e) { delete e; }
 
 int gss_embs_open(gss_embs_file **out, const char *path, int32_t threads) {
   GSS_REQUIRE(out && path, "embs_open: null argument");

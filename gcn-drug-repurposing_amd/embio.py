@@ -79,6 +79,26 @@ def read_edgelist(path, names=None):
     given (the .embs.txt row order) ids are mapped to those rows, otherwise in order of appearance.
     A .sif file is undirected: both directions are emitted."""
     sif = path.endswith(".sif") or path.endswith(".sif.lcc")
+    if not sif and names is not None and len(names) > 0 and not any("\n" in n for n in names[:1]):
+        # the trainer's case (ids mapped to the .embs.txt rows): native multi-threaded parser; a file it rejects (an unknown id,
+        # a malformed weight) goes through the Python loop below, which raises the error with its context
+        try:
+            from . import _lib
+            import ctypes as C
+            lib = _lib.load()
+            blob = "\n".join(names).encode()
+            h = C.c_void_p()
+            if lib.gss_edgelist_open(C.byref(h), str(path).encode(), blob, len(blob), len(names), 0) == 0:
+                try:
+                    if lib.gss_edgelist_bad_line(h) < 0:
+                        m = lib.gss_edgelist_edges(h)
+                        src32, dst32, w = np.empty(m, np.int32), np.empty(m, np.int32), np.empty(m, np.float64)
+                        _lib.check(lib.gss_edgelist_copy(h, src32.ctypes.data, dst32.ctypes.data, w.ctypes.data), "gss_edgelist_copy")
+                        return src32.astype(np.int64), dst32.astype(np.int64), w, list(names)
+                finally:
+                    lib.gss_edgelist_close(h)
+        except Exception:  # noqa: BLE001  (library not built ...): the plain parser decides
+            pass
     index = {n: i for i, n in enumerate(names)} if names is not None else {}
     fixed = names is not None
     names = list(names) if names is not None else []

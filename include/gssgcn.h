@@ -256,6 +256,17 @@ int64_t gss_embs_names_bytes(const gss_embs_file *e);
 int gss_embs_copy(const gss_embs_file *e, double *x_out, char *names_out, int64_t names_cap, int64_t *header_n);
 void gss_embs_close(gss_embs_file *e);
 
+/* ---- a2  the weighted edgelist 'u v w' (nx.write_weighted_edgelist, predict_drug.py:224-226) as --adj-file reads it ----------
+ * names: the node ids of the .embs.txt in row order, joined by '\n' (names_bytes bytes, n_names ids): every u / v is mapped to its
+ * row.  Lines are parsed by `threads` host threads; a missing weight is 1.0; blank and '#' lines are skipped.
+ * gss_edgelist_bad_line >= 0: the first line (0-based among the data lines) with an unknown node id or a malformed weight. */
+typedef struct gss_edgelist_file gss_edgelist_file;
+int gss_edgelist_open(gss_edgelist_file **out, const char *path, const char *names, int64_t names_bytes, int64_t n_names, int32_t threads);
+int64_t gss_edgelist_edges(const gss_edgelist_file *e);
+int64_t gss_edgelist_bad_line(const gss_edgelist_file *e);
+int gss_edgelist_copy(const gss_edgelist_file *e, int32_t *src, int32_t *dst, double *w);
+void gss_edgelist_close(gss_edgelist_file *e);
+
 /* ---- whole training step (train.py:158-184) ---------------------------------------------------
  * A plan owns every activation/gradient buffer of one replica so that a step is ONE host call that
  * enqueues all kernels.  a / at: CSR(A_hat) and CSR(A_hat^T) (at may be NULL for num_layers == 1). */

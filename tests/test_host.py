@@ -176,3 +176,29 @@ def test_native_embs_reader_matches_python_float(tmp_path):
     bad.write_text("2 3\na 1 2 3\nb 1 2\n")                   # ragged: the native reader refuses, the Python parser raises
     with pytest.raises(Exception):
         embio.read_embs(str(bad))
+
+
+def test_native_edgelist_reader_matches_the_python_parser(tmp_path):
+    """gss_edgelist_open (the --adj-file reader for 'u v w' lines, predict_drug.py:224-226): same (src, dst, w) as the Python loop,
+    comments / blank lines / missing weights handled, unknown node ids reported by the strict parser"""
+    from gcn_drug_repurposing_amd import embio
+    rng = np.random.RandomState(8)
+    names = [f"GO:{i:07d}" if i % 3 == 0 else (f"DB{i:05d}" if i % 3 == 1 else str(i)) for i in range(700)]
+    m = 20000
+    u, v = rng.randint(0, 700, m), rng.randint(0, 700, m)
+    w = rng.rand(m) * np.exp(rng.randn(m) * 3)
+    p = tmp_path / "g.edgelist"
+    with open(p, "w") as f:
+        f.write("# a comment\n\n")
+        for k in range(m):
+            if k % 997 == 0:
+                f.write(f"{names[u[k]]}\t{names[v[k]]}\n")               # no weight -> 1.0, tab separated
+                w[k] = 1.0
+            else:
+                f.write(f"{names[u[k]]} {names[v[k]]} {float(w[k])!r}\n")
+    src, dst, ww, nm = embio.read_edgelist(str(p), names)
+    assert nm == names and np.array_equal(src, u) and np.array_equal(dst, v) and np.array_equal(ww, w)
+    with open(p, "a") as f:
+        f.write("not_a_node GO:0000000 1.0\n")
+    with pytest.raises(KeyError, match="not_a_node"):
+        embio.read_edgelist(str(p), names)

@@ -40,4 +40,24 @@ with tempfile.TemporaryDirectory() as td:
         t = time.time()
         embio.write_graph_embs(b, emb, threads=thr)
         print(f"write      native threads={thr or 'all'}: {time.time() - t:.3f} s  identical={open(a, 'rb').read() == open(b, 'rb').read()}")
+# the whole_graph edgelist ('u v w', 958,068 lines) against the .embs.txt names
+from gcn_drug_repurposing_amd import synth  # noqa: E402
+adj, _, gnames = synth.whole_graph_standin(1)
+coo = adj.tocoo()
+with tempfile.TemporaryDirectory() as td:
+    p = os.path.join(td, "g.edgelist")
+    with open(p, "w") as f:
+        for u, v, w in zip(coo.row, coo.col, coo.data):
+            f.write(f"{gnames[u]} {gnames[v]} {float(w)!r}\n")
+    t = time.time()
+    src, dst, w, _ = embio.read_edgelist(p, gnames)
+    print(f"edgelist   native: {time.time() - t:.3f} s  equal={np.array_equal(src, coo.row) and np.array_equal(dst, coo.col) and np.array_equal(w, coo.data)}")
+    t = time.time()
+    index = {n: i for i, n in enumerate(gnames)}
+    s2, d2, w2 = [], [], []
+    with open(p) as f:
+        for line in f:
+            q = line.split()
+            s2.append(index[q[0]]); d2.append(index[q[1]]); w2.append(float(q[2]))
+    print(f"edgelist   python loop: {time.time() - t:.3f} s")
 print("host cpus", os.cpu_count())
