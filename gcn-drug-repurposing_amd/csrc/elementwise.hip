@@ -126,6 +126,18 @@ __global__ void shard_batch_ids_kernel(const int32_t *__restrict__ idx, int b, c
   pid[i] = gid2op ? gid2op[id] : (mine ? rel : -1);
 }
 
+// bitmap companion of the batch-position map (spmm.hip SPMM_BWD1S): set the members' bits / zero their words
+__global__ void batch_bits_kernel(const int32_t *__restrict__ ids, int b, uint32_t *__restrict__ bits, int set) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b) return;
+  const int id = ids[i];
+  if (id < 0) return;
+  if (set)
+    atomicOr(&bits[(unsigned)id >> 5], 1u << (id & 31));
+  else
+    bits[(unsigned)id >> 5] = 0u;  // every set bit of the word belongs to a member of this batch
+}
+
 // halo exchange, sender side: out[k] = src[rows[k]] -- the rows the peers reference, packed in peer order
 __global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n, int d4, const float *__restrict__ src, const int32_t *__restrict__ rows,
                                                         float *__restrict__ out) {
@@ -301,6 +313,14 @@ int shard_batch_ids(const int32_t *idx, int32_t b, const int32_t *node_map, int3
   hipLaunchKernelGGL(shard_batch_ids_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, as_stream(stream), idx, b, node_map, lo, nl, gid2op, pid, rloc,
                      keep);
   GSS_LAUNCH_CHECK("shard_batch_ids_kernel");
+  return GSS_OK;
+}
+
+int batch_bits(const int32_t *ids, int32_t b, uint32_t *bits, int set, void *stream) {
+  GSS_REQUIRE(ids && bits && b >= 0, "batch_bits: null operand");
+  if (b == 0) return GSS_OK;
+  hipLaunchKernelGGL(batch_bits_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, as_stream(stream), ids, b, bits, set);
+  GSS_LAUNCH_CHECK("batch_bits_kernel");
   return GSS_OK;
 }
 

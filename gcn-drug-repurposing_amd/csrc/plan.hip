@@ -29,6 +29,7 @@ struct gss_plan {
   float *g_ax, *g_am, *u, *t, *dp, *gx[2];
   float *de_b, *dx_b, *dp_b, *gax_b, *gam_b;
   int32_t *pos;  // operand row of A_hat^T's column space -> batch position (-1 outside the batch), for the sparsity-aware backward SpMM
+  uint32_t *posbits;  // bitmap of pos >= 0, kept only around the sparse backward SpMM and only for huge operands (else NULL)
   float *w1t, *w2t;
   float *grad[4];
   float *adam_m[4], *adam_v[4];
@@ -170,6 +171,8 @@ void carve(gss_plan *p, Carver &c) {
   p->gab = L > 1 ? c.take<float>(2 * bd) : nullptr;            // gax_b = gab, gam_b = gab + b * d: one all-reduce
   p->gax_b = p->gam_b = nullptr;
   p->pos = L > 1 ? c.take<int32_t>(p->rows_t ? p->rows_t : 1) : nullptr;
+  // a 4-byte-per-node map beyond the L2s (>= 500k operand rows = 2 MB): the sparse SpMM tests a bitmap first (zero-initialised slab)
+  p->posbits = (L > 1 && p->rows_t >= (size_t)500000) ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;
   p->w1t = c.take<float>((size_t)D.d * D.d);
   p->w2t = c.take<float>((size_t)D.d * D.d);
   const size_t cnt[4] = {(size_t)D.d * D.d, (size_t)D.d, (size_t)D.d * D.d, (size_t)D.d};
@@ -541,9 +544,19 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
         if (int rc = dense_bwd_input(b, D.d, p->dp_b, p->w1t, p->w2t, nullptr, p->gax_b, p->gam_b, stream)) return rc;
       }
       if (int rc = plan_allreduce(p, p->gab, (size_t)2 * b * D.d, stream)) return rc;
-      PROF(GSS_PROF_SPMM_BWD1);
-      if (int rc = spmm_bwd1_sparse(p->at, D.d, p->gam_b, p->gax_b, p->pos, pos_row, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream))
-        return rc;
+      if (p->posbits) {
+        PROF(GSS_PROF_ELEMENTWISE);
+        if (int rc = batch_bits(bv.ids, b, p->posbits, 1, stream)) return rc;
+      }
+      {
+        PROF(GSS_PROF_SPMM_BWD1);
+        if (int rc = spmm_bwd1_sparse(p->at, D.d, p->gam_b, p->gax_b, p->pos, pos_row, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream, p->posbits))
+          return rc;
+      }
+      if (p->posbits) {
+        PROF(GSS_PROF_ELEMENTWISE);
+        if (int rc = batch_bits(bv.ids, b, p->posbits, 0, stream)) return rc;
+      }
     } else {
       const size_t nd_bytes = sizeof(float) * (size_t)D.n * D.d;
       {

@@ -33,6 +33,8 @@ struct SpmmEpi {
   float c;
   const int32_t *pos;      // SPMM_BWD1S: column id -> row of the compact operands, -1 if not a batch row
   const int32_t *pos_row;  // SPMM_BWD1S: output row -> row of the compact g_ax, -1 if not a batch row
+  const uint32_t *posbits; // SPMM_BWD1S, optional: bit c set <=> pos[c] >= 0.  For huge operands: the bitmap (N / 8 bytes) stays in
+                           // L2 where the int32 map (4 N bytes) does not, and only the rare hits go on to read pos[]
 };
 
 struct CsrView {
@@ -280,7 +282,10 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
     if (MODE == SPMM_BWD1S) {
       // row-sparse operand: only neighbours that are batch rows contribute (about B/N of the entries).  Look
       // the neighbour up in the node -> compact-row map and walk the hits of this group one at a time.
-      const int cp = (ce < e1) ? ep.pos[c] : -1;
+      int cp = -1;
+      if (ce < e1) {
+        if (!ep.posbits || ((ep.posbits[(unsigned)c >> 5] >> (c & 31)) & 1u)) cp = ep.pos[c];
+      }
       const unsigned long long hits = __ballot(cp >= 0);
       unsigned long long gm = LPR == 64 ? hits : ((hits >> (g << LPR_LOG2)) & ((1ull << LPR) - 1ull));
       while (__any(gm != 0ull)) {
@@ -580,25 +585,25 @@ int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float 
   GSS_REQUIRE(y, "spmm: y is null");
   if (m) {
     GSS_REQUIRE(h, "spmm: m given without h");
-    SpmmEpi ep{h, nullptr, nullptr, y, m, 0.f, nullptr, nullptr};
+    SpmmEpi ep{h, nullptr, nullptr, y, m, 0.f, nullptr, nullptr, nullptr};
     return launch_spmm<SPMM_FWD1>(a, d, x, ep, stream);
   }
-  SpmmEpi ep{nullptr, nullptr, nullptr, y, nullptr, 0.f, nullptr, nullptr};
+  SpmmEpi ep{nullptr, nullptr, nullptr, y, nullptr, 0.f, nullptr, nullptr, nullptr};
   return launch_spmm<SPMM_PLAIN>(a, d, x, ep, stream);
 }
 
 int spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
               float *u, float *t, void *stream) {
   GSS_REQUIRE(g_am && g_ax && x_in && ax && u && t, "spmm_bwd1: null operand");
-  SpmmEpi ep{g_ax, x_in, ax, u, t, 0.f, nullptr, nullptr};
+  SpmmEpi ep{g_ax, x_in, ax, u, t, 0.f, nullptr, nullptr, nullptr};
   return launch_spmm<SPMM_BWD1>(at, d, g_am, ep, stream);
 }
 
 int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,
-                     const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream) {
+                     const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream, const uint32_t *posbits) {
   GSS_REQUIRE(g_am_b && g_ax_b && pos && pos_row && x_in && ax && u && t, "spmm_bwd1_sparse: null operand");
   GSS_REQUIRE(g_spmm_variant == 2, "spmm_bwd1_sparse needs the balanced SpMM (spmm_variant 2)");
-  SpmmEpi ep{g_ax_b, x_in, ax, u, t, 0.f, pos, pos_row};
+  SpmmEpi ep{g_ax_b, x_in, ax, u, t, 0.f, pos, pos_row, posbits};
   return launch_spmm<SPMM_BWD1S>(at, d, g_am_b, ep, stream);
 }
 
@@ -606,7 +611,7 @@ int spmm_bwd2_sparse_res(const gss_csr *at, int32_t d, const float *u, const flo
                          const int32_t *pos_row, float *dp, float *gx_out, void *stream) {
   GSS_REQUIRE(u && t && p && res_b && pos_row && dp, "spmm_bwd2_sparse_res: null operand");
   GSS_REQUIRE(g_spmm_variant == 2, "spmm_bwd2_sparse_res needs the balanced SpMM (spmm_variant 2)");
-  SpmmEpi ep{t, p, res_b, dp, gx_out, c, nullptr, pos_row};
+  SpmmEpi ep{t, p, res_b, dp, gx_out, c, nullptr, pos_row, nullptr};
   return launch_spmm<SPMM_BWD2S>(at, d, u, ep, stream);
 }
 
@@ -615,7 +620,7 @@ bool spmm_sparse_available() { return g_spmm_variant == 2; }
 int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
               float *dp, float *gx_out, void *stream) {
   GSS_REQUIRE(u && t && p && dp, "spmm_bwd2: null operand");
-  SpmmEpi ep{t, p, res, dp, gx_out, c, nullptr, nullptr};
+  SpmmEpi ep{t, p, res, dp, gx_out, c, nullptr, nullptr, nullptr};
   return launch_spmm<SPMM_BWD2>(at, d, u, ep, stream);
 }
 
