@@ -480,7 +480,9 @@ int dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t, con
 // through LDS in a fixed order, written per slice and summed in slice order by wgrad_reduce_kernel.
 // Measured at N = 29,960, d = 128 (partial + reduce): 256 workgroups 29.7 us; 128 / 384 / 512 / 1024 workgroups
 // 44 / 35 / 31.5 / 35.6 us; 128 x 64 tiles (every dP row read half as often, 196 VGPRs) 31.5 us -- neither more slices
-// nor less operand traffic helps, the one-workgroup-per-CU geometry stays.
+// nor less operand traffic helps, the one-workgroup-per-CU geometry stays.  Round 2: explicit register double-buffering of the
+// operand loads (trip i + 1 requested before the MFMAs of trip i): 33.8 vs 31.0 us inside the step -- slower, the second operand
+// set costs more in registers than the exposed latency it covers (the SIMD's partner wave already covers it).
 
 constexpr int kWgWaves = 8;
 
