@@ -10,6 +10,7 @@ extern int g_spmm_hot;
 extern int g_spmm_fly;
 extern int g_seg_edges;
 extern int g_gemm_variant;  // dense.hip
+extern int g_gemm_small_nt;
 }  // namespace gss
 
 using namespace gss;
@@ -49,6 +50,11 @@ int gss_debug_set_option(const char *name, int value) {
   if (strcmp(name, "spmm_seg_edges") == 0) {
     GSS_REQUIRE(value >= 4 && value <= 1024, "spmm_seg_edges must be in [4, 1024]");
     g_seg_edges = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "gemm_small_nt") == 0) {
+    GSS_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "gemm_small_nt must be 0, 1, 2, 4 or 8");
+    g_gemm_small_nt = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_variant") == 0) {

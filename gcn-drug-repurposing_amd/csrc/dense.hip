@@ -343,12 +343,17 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
 // all workgroups reach the store phase together.
 
 int g_gemm_variant = 2;
+int g_gemm_small_nt = 2;  // debug knob "gemm_small_nt": narrowest feature tile (in 16-feature units) for small problems, 0 = never narrow
 
 template <int EPI>
 static int launch_gemm(const GemmArgs &g, int d, hipStream_t st) {
   if (g.n <= 0) return GSS_OK;
   if (g_gemm_variant >= 2) {
-    const int nt = (d % 128 == 0) ? 8 : (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
+    int nt = (d % 128 == 0) ? 8 : (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
+    // few node rows (the top layer's batch-row input gradient: 2048 rows): narrower feature tiles so that the grid covers the chip
+    // (64-node x 128-feature tiles give 64 workgroups at B = 2048, d = 128; 32-feature tiles 256)
+    if (EPI == EPI_SPLIT && g_gemm_small_nt > 0)
+      while (nt > g_gemm_small_nt && (int64_t)ceil_div(g.n, 64) * (g.J / (16 * nt)) < 256) nt >>= 1;
     // 64-node tiles give 2-3 co-resident workgroups per CU (epilogue traffic overlaps MFMA); at d >= 256 the
     // W-staging redundancy of small tiles costs more than that buys (measured, tools/gemm_bench.py), and so it does once
     // the grid is many waves of workgroups deep (d = 128: N = 1M 791 -> 753 us, N = 4M 3061 -> 2913 us with 128-node tiles)
