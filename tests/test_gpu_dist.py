@@ -327,3 +327,32 @@ def test_trainer_cli_sharded_mode_writes_the_same_embeddings(tmp_path):
     assert np.abs(outs[0] - outs[1]).max() < 1e-5
     ref = np.loadtxt(bytes(g["graph_embs_txt"]).decode().splitlines())
     assert np.abs(outs[1] - ref).max() < 5e-3
+
+
+def test_trainer_checkpoint_resume_on_the_sharded_path(tmp_path):
+    """--checkpoint / --resume through the native sharded plan (one RCCL rank): 4 epochs in one run == 2 epochs + resume, byte for
+    byte, and equal to the single-GPU trainer's file"""
+    import os
+    import subprocess
+    import sys
+    from gcn_drug_repurposing_amd import embio
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.RandomState(3)
+    n, d = 500, 32
+    emb = tmp_path / "in.embs.txt"
+    embio.write_embs(str(emb), [f"n{i}" for i in range(n)], rng.randn(n, d) / 6)
+    common = [sys.executable, os.path.join(root, "train.py"), "--emb-file", str(emb), "--num-layers", "2", "--hidden-units", str(d), "--k", "5",
+              "--lr", "0.001", "--beta-percentile", "95", "--batch-size", "128", "--seed", "11"]
+    env = dict(os.environ, GSS_FORCE_SHARDED="1")
+
+    def run(extra, env_):
+        r = subprocess.run(common + extra, capture_output=True, text=True, env=env_, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+
+    ck = tmp_path / "ck.npz"
+    run(["--epochs", "4", "--out", str(tmp_path / "a.txt")], env)
+    run(["--epochs", "2", "--out", str(tmp_path / "b2.txt"), "--checkpoint", str(ck)], env)
+    run(["--epochs", "4", "--out", str(tmp_path / "b.txt"), "--resume", str(ck)], env)
+    run(["--epochs", "4", "--out", str(tmp_path / "s.txt")], dict(os.environ))
+    assert (tmp_path / "a.txt").read_bytes() == (tmp_path / "b.txt").read_bytes()
+    assert (tmp_path / "a.txt").read_bytes() == (tmp_path / "s.txt").read_bytes()       # world = 1 shard == plain plan, bit for bit
