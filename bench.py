@@ -258,7 +258,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
     halo_info = None
-    if from_source or (sharded and not args.python_sharded):
+    # one GPU, a matrix in memory: the same builder as the shards (it relabels the nodes hub-first: -1.7 % of a step at config 2);
+    # the A/B options of the plain plan (--cache-layer1, --pipeline) keep the GssGraph path
+    single_via_shard = not sharded and not from_source and not args.cache_layer1 and not args.pipeline
+    if from_source or single_via_shard or (sharded and not args.python_sharded):
         # the native sharded path (also world = 1 for a row source): a gss_plan per rank that owns an RCCL communicator
         # (gss_plan_create_sharded); torch.distributed only hands the communicator's 128-byte id around and takes the MAX of
         # the timings.  Every rank builds its own rows only (shards.build_shard).
@@ -268,7 +271,8 @@ def main():
         t_setup = time.perf_counter()
         shard = build_shard(adj if from_source else ScipySource(adj), comm, need_transpose=L > 1)
         lo_, hi_ = shard.part.rows(rank)
-        x_rows = gaussian_rows(lo_, hi_, d, 5) if from_source else x_host[lo_:hi_]
+        from gcn_drug_repurposing_amd.shards import shard_rows
+        x_rows = gaussian_rows(lo_, hi_, d, 5) if from_source else shard_rows(shard, x_host)
         engine = shard_engine(shard, x_rows, params_host, comm, num_layers=L, layer_decay=decay, alpha=alpha, lr=lr, max_batch=B)
         torch.cuda.synchronize()
         nnz = engine.global_nnz
@@ -278,7 +282,7 @@ def main():
                      "halo_fraction_a": fa, "halo_fraction_at": ft, "setup_s": time.perf_counter() - t_setup,
                      "plan_bytes": engine.device_bytes()}
         parallelism = (f"node-range shards x{world}, native plan, boundary rows by grouped ncclSend/ncclRecv per SpMM hop" if sharded
-                       else "single (native plan on a one-rank shard)")
+                       else "single")
         if shard.relabel is not None:
             parallelism += "; nodes relabelled hub-first"
     elif not sharded:

@@ -277,6 +277,8 @@ class Relabel:
         return self._dev[key]
 
 
+RELABEL_MIN_NODES = 16384   # relabel="auto": from here on the hub-first order pays (config 2, N = 29,960: -3 % per SpMM, -1.7 % per step;
+                            # RMAT 10M: -31 % per SpMM); below it the graphs are test-sized
 HOT_ROWS = 65536     # the hubs whose rows are kept in the caches (32 MB at d = 128): measured optimum at RMAT 10M / 200M
 
 
@@ -300,8 +302,9 @@ ROW_WEIGHT = 12      # what a row costs besides its stored entries (dense projec
 
 
 def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="auto", row_weight=ROW_WEIGHT) -> Shard:
-    """relabel: True / False / "auto" (hub-first node order when the graph has >= 250,000 nodes, i.e. when a [N][128] fp32
-    operand no longer fits the Infinity Cache).  Relabelling is invisible in the results: a row's entries keep their original
+    """relabel: True / False / "auto" (hub-first node order when the graph has >= RELABEL_MIN_NODES nodes; the non-temporal
+    treatment of the cold rows additionally needs an operand far beyond the caches, gss_csr_set_hot).  Relabelling is invisible in
+    the results: a row's entries keep their original
     order, so every sum is taken in the same order, batches name original ids (gss_plan_desc.node_map) and
     GssEngine.gather_embeddings returns original order."""
     from .graph import DeviceCSR
@@ -311,7 +314,7 @@ def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="a
     work = np.asarray(source.work(comm, dev), dtype=np.int64)
     n = len(work)
     if relabel == "auto":
-        relabel = n >= 250_000
+        relabel = n >= RELABEL_MIN_NODES
     rl = Relabel(work) if relabel else None
     if rl is not None:
         work = work[rl.perm]

@@ -133,9 +133,10 @@ def main(argv=None):
         adj = edgelist_adj(src, dst, w, n)
     else:
         adj = knn_descriptor_adj_device(X, args.k, device=dev)   # train.py:93 -> helper.py:39-53, similarity + top-k on device
-    # graphs whose [N][d] operand is far beyond the caches go through the shard builder even on one GPU: it relabels the
-    # nodes hub-first for gather locality (shards.build_shard; invisible in the results)
-    shard_path = sharded or n >= 250_000
+    # all but test-sized graphs go through the shard builder even on one GPU: it relabels the nodes hub-first for gather
+    # locality (shards.build_shard: -2 % of a step at N = 30k, -30 % at 10M; invisible in the results)
+    from .shards import RELABEL_MIN_NODES
+    shard_path = sharded or (n >= RELABEL_MIN_NODES and not args.cache_layer1)
     graph = None
     if not shard_path:
         graph = GssGraph(adj, device=dev, need_transpose=args.num_layers > 1)   # train.py:100-101
