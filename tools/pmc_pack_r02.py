@@ -12,8 +12,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PMC = os.path.join(ROOT, "gpurun_out", "pmc")
 CASES = {  # tag -> (description, n, nnz, d, extra operand rows)
-    "wg_fwd1": ("whole_graph stand-in, spmm_balanced_kernel<FWD1> (AX = A_hat X, M = AX (.) X)", 29960, 988028, 128, 1),
-    "wg_plain": ("whole_graph stand-in, spmm_balanced_kernel<PLAIN> (AM = A_hat M)", 29960, 988028, 128, 0),
+    "wg_fwd1": ("whole_graph stand-in as bench.py runs it (nodes relabelled hub-first), spmm_balanced_kernel<FWD1> (AX = A_hat X, M = AX (.) X)", 29960, 988028, 128, 1),
+    "wg_plain": ("whole_graph stand-in as bench.py runs it (nodes relabelled hub-first), spmm_balanced_kernel<PLAIN> (AM = A_hat M)", 29960, 988028, 128, 0),
+    "wg_norelabel_fwd1": ("whole_graph stand-in in the loader's node order, FWD1", 29960, 988028, 128, 1),
+    "wg_norelabel_plain": ("whole_graph stand-in in the loader's node order, PLAIN", 29960, 988028, 128, 0),
     "r1m_plain": ("RMAT 1M / 20M (+1M self loops), generator node order, PLAIN", 1000000, 21000000, 128, 0),
     "r1m_relabel": ("RMAT 1M / 20M, nodes relabelled hub-first + cold rows non-temporal, PLAIN", 1000000, 21000000, 128, 0),
     "r10m_plain": ("RMAT 10M / 200M (+10M self loops), generator node order, PLAIN", 10000000, 210000000, 128, 0),
