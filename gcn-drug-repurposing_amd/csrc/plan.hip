@@ -1,6 +1,6 @@
 // plan.hip -- one training replica, or one node-range shard of one: owns every activation / gradient buffer and
 // enqueues a whole iteration of train.py:155-184 (forward, gss_loss, backward, Adam) from a single host call, so the
-// kernels of a step (11 launches at L = 2) and, on a shard, the collectives between them (comm.hip: halo exchanges and
+// kernels of a step (14 launches at L = 2) and, on a shard, the collectives between them (comm.hip: halo exchanges and
 // all-reduces over RCCL) are issued back to back from C++ with no Python in between.
 //
 // Layer l (0-based) keeps x_l (input), AX_l, AM_l, P_l for the backward pass (model.py:163-173).
