@@ -11,6 +11,7 @@ extern int g_spmm_fly;
 extern int g_seg_edges;
 extern int g_gemm_variant;  // dense.hip
 extern int g_gemm_small_nt;
+extern int g_loss_wgs;      // loss.hip
 }  // namespace gss
 
 using namespace gss;
@@ -50,6 +51,11 @@ int gss_debug_set_option(const char *name, int value) {
   if (strcmp(name, "spmm_seg_edges") == 0) {
     GSS_REQUIRE(value >= 4 && value <= 1024, "spmm_seg_edges must be in [4, 1024]");
     g_seg_edges = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "loss_wgs") == 0) {
+    GSS_REQUIRE(value >= 64 && value <= 4096, "loss_wgs must be in [64, 4096]");
+    g_loss_wgs = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_small_nt") == 0) {
