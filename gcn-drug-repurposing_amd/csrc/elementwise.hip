@@ -110,21 +110,6 @@ __global__ void shard_batch_maps_kernel(const int32_t *__restrict__ idx, int b, 
   if (mine) pos_row[rel] = i;
 }
 
-// per-batch maps of a sharded plan: pid = the member's operand row in A_hat^T's column space (own rows first, then the
-// halo; -1 where this shard never reads the node), rloc = the local row clamped into this shard (any owned row where the
-// shard has no say), keep = 1.0 / 0.0 for owned / foreign rows
-__global__ void shard_batch_ids_kernel(const int32_t *__restrict__ idx, int b, const int32_t *__restrict__ node_map, int lo, int nl,
-                                       const int32_t *__restrict__ gid2op, int32_t *__restrict__ pid, int32_t *__restrict__ rloc,
-                                       float *__restrict__ keep) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= b) return;
-  const int id = node_map ? node_map[idx[i]] : idx[i];   // relabelled graphs: the caller's node id -> the row it lives in
-  const int rel = id - lo;
-  const bool mine = rel >= 0 && rel < nl;
-  rloc[i] = min(max(rel, 0), max(nl - 1, 0));
-  if (keep) keep[i] = mine ? 1.f : 0.f;
-  pid[i] = gid2op ? gid2op[id] : (mine ? rel : -1);
-}
 
 // bitmap companion of the batch-position map (spmm.hip SPMM_BWD1S): set the members' bits / zero their words
 __global__ void batch_bits_kernel(const int32_t *__restrict__ ids, int b, uint32_t *__restrict__ bits, int set) {
@@ -303,16 +288,6 @@ int adam_step(int64_t count, float *param, const float *grad, float *m, float *v
   hipLaunchKernelGGL(adam_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, as_stream(stream), count, param, grad, m, v,
                      (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, wt, dim > 0 ? dim : 1);
   GSS_LAUNCH_CHECK("adam_kernel");
-  return GSS_OK;
-}
-
-int shard_batch_ids(const int32_t *idx, int32_t b, const int32_t *node_map, int32_t lo, int32_t nl, const int32_t *gid2op, int32_t *pid,
-                    int32_t *rloc, float *keep, void *stream) {
-  GSS_REQUIRE(b >= 0 && nl >= 0 && idx && pid && rloc, "shard_batch_ids: bad argument");
-  if (b == 0) return GSS_OK;
-  hipLaunchKernelGGL(shard_batch_ids_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, as_stream(stream), idx, b, node_map, lo, nl, gid2op, pid, rloc,
-                     keep);
-  GSS_LAUNCH_CHECK("shard_batch_ids_kernel");
   return GSS_OK;
 }
 

@@ -43,6 +43,30 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(int b, int d4, const f
   st4(out + i * 4, mine ? ld4(e + ((size_t)idx[r] * d4 + f4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
+// the same gather for a relabelled graph and/or one node-range shard, with the batch-id translation folded in
+// (it used to be a launch of its own): node id -> row (node_map), row -> local row of
+// this shard (lo, nl), the position-map id (gid2op, or the local row); the thread of a row's first float4 stores the translated ids
+struct BatchMap {
+  const int32_t *idx, *node_map, *gid2op;
+  int lo, nl;
+  int32_t *pid, *rloc;
+  float *keep;  // NULL on one GPU
+};
+__global__ __launch_bounds__(256) void gather_rows_mapped_kernel(int b, int d4, const float *__restrict__ e, BatchMap m, float *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)b * d4) return;
+  const int r = (int)(i / d4), f4 = (int)(i % d4);
+  const int id = m.node_map ? m.node_map[m.idx[r]] : m.idx[r];
+  const int rel = id - m.lo;
+  const bool mine = rel >= 0 && rel < m.nl;
+  if (f4 == 0) {
+    m.rloc[r] = min(max(rel, 0), max(m.nl - 1, 0));
+    if (m.keep) m.keep[r] = mine ? 1.f : 0.f;
+    m.pid[r] = m.gid2op ? m.gid2op[id] : (mine ? rel : -1);
+  }
+  st4(out + i * 4, mine ? ld4(e + ((size_t)rel * d4 + f4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
 template <int NG, bool EXACT>  // EXACT: d == 64 NG, no feature masking anywhere
 __global__ __launch_bounds__(64 * kLossWaves, 2) void loss_fused_kernel(LossArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -393,6 +417,20 @@ int loss_gather_rows(int32_t d, const float *e, const int32_t *rows, const float
   GSS_REQUIRE(b > 0 && (e || keep) && rows && ws && e_b_out, "loss_gather_rows: null operand or empty batch");  // e may be null on an empty shard
   LossLaunch L;
   if (int rc = loss_gather(d, e, rows, keep, b, ws, as_stream(stream), L)) return rc;
+  *e_b_out = L.e_b;
+  return GSS_OK;
+}
+
+// loss_gather_rows with the batch-id translation in the same launch (see gather_rows_mapped_kernel)
+int loss_gather_rows_mapped(int32_t d, const float *e, const int32_t *idx, const int32_t *node_map, int32_t lo, int32_t nl, const int32_t *gid2op,
+                            int32_t *pid, int32_t *rloc, float *keep, int32_t b, void *ws, float **e_b_out, void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(b > 0 && (e || nl == 0) && idx && pid && rloc && ws && e_b_out && nl >= 0, "loss_gather_rows_mapped: null operand or empty batch");
+  LossLaunch L;
+  loss_layout(d, b, ws, L);
+  BatchMap m{idx, node_map, gid2op, lo, nl, pid, rloc, keep};
+  hipLaunchKernelGGL(gather_rows_mapped_kernel, dim3(ceil_div((int64_t)b * d / 4, 256)), dim3(256), 0, as_stream(stream), b, d / 4, e, m, L.e_b);
+  GSS_LAUNCH_CHECK("gather_rows_mapped_kernel");
   *e_b_out = L.e_b;
   return GSS_OK;
 }

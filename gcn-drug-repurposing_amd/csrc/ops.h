@@ -68,8 +68,6 @@ int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b,
 // dst[rows[r]] += src[r] unless rows[r] < 0 or keep[r] == 0 (keep nullable); pos_clear != NULL: also pos_clear[pos_ids[r]] = -1
 int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, const float *keep, int32_t b, float *dst, int32_t *pos_clear,
                      const int32_t *pos_ids, void *stream);
-int shard_batch_ids(const int32_t *idx, int32_t b, const int32_t *node_map, int32_t lo, int32_t nl, const int32_t *gid2op, int32_t *pid,
-                    int32_t *rloc, float *keep, void *stream);
 int pack_rows(int32_t d, const float *src, const int32_t *rows, int64_t n, float *out, void *stream);
 int shard_batch_maps(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
                      int32_t *rows_all, int32_t *rows_own, float *keep, int32_t *pos_col, int32_t *pos_row, void *stream);
@@ -95,6 +93,8 @@ int loss_fwd_bwd_fused(int32_t n, int32_t d, const float *e, const int32_t *idx,
                        const float *inv_den, const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set, void *ws,
                        void *stream);
 int loss_gather_rows(int32_t d, const float *e, const int32_t *rows, const float *keep, int32_t b, void *ws, float **e_b_out, void *stream);
+int loss_gather_rows_mapped(int32_t d, const float *e, const int32_t *idx, const int32_t *node_map, int32_t lo, int32_t nl, const int32_t *gid2op,
+                            int32_t *pid, int32_t *rloc, float *keep, int32_t b, void *ws, float **e_b_out, void *stream);
 int loss_fused_gathered(int32_t d, int32_t b, float beta, float alpha, float *loss_out, const int32_t *idx, const int32_t *pos_ids,
                         const float *keep, const float *inv_den, const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set,
                         void *ws, void *stream);

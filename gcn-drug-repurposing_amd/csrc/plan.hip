@@ -453,14 +453,12 @@ struct BatchView {
   const float *keep;
 };
 
-int plan_batch_view(gss_plan *p, const int32_t *idx, int32_t b, BatchView &v, void *stream) {
-  if (p->P == 1 && !p->desc.node_map) {
-    v = BatchView{idx, idx, nullptr};
-    return GSS_OK;
-  }
-  PROF(GSS_PROF_ELEMENTWISE);
-  v = BatchView{p->rloc, p->pid, p->keep};   // keep stays NULL on one GPU (every row is owned)
-  return shard_batch_ids(idx, b, p->desc.node_map, p->lo, p->desc.n, p->gid2op_t, p->pid, p->rloc, p->keep, stream);
+// the batch as the plan's kernels see it; for a relabelled graph / a shard the translated ids are WRITTEN by the gather launch of
+// plan_loss_backward_impl (loss.hip gather_rows_mapped_kernel), this only says where they live
+static bool plan_batch_mapped(const gss_plan *p) { return p->P > 1 || p->desc.node_map; }
+static BatchView plan_batch_view(gss_plan *p, const int32_t *idx) {
+  if (!plan_batch_mapped(p)) return BatchView{idx, idx, nullptr};
+  return BatchView{p->rloc, p->pid, p->keep};   // keep stays NULL on one GPU (every row is owned)
 }
 
 int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float *de_rows, bool top_done, bool wt_ok, void *stream,
@@ -472,14 +470,19 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
   const gss_plan_desc &D = p->desc;
   GSS_REQUIRE(b >= 1 && b <= D.max_batch, "plan_loss_backward: batch %d out of [1, %d]", b, D.max_batch);
   const int L = D.num_layers;
-  if (int rc = plan_batch_view(p, idx, b, bv, stream)) return rc;
+  bv = plan_batch_view(p, idx);
   const bool sparse_top = L > 1 && spmm_sparse_available();
   GSS_REQUIRE(p->P == 1 || L == 1 || sparse_top, "a sharded plan needs the balanced SpMM (spmm_variant 2)");
   float *e_b = nullptr;
   {
     // E_B = emb[idx] (model.py:216-217): every shard contributes the rows it owns, one all-reduce assembles them (C3)
     PROF(GSS_PROF_LOSS);
-    if (int rc = loss_gather_rows(D.d, p->emb, bv.rows, bv.keep, b, p->loss_ws, &e_b, stream)) return rc;
+    if (plan_batch_mapped(p)) {
+      if (int rc = loss_gather_rows_mapped(D.d, p->emb, idx, D.node_map, p->lo, D.n, p->gid2op_t, p->pid, p->rloc, p->keep, b, p->loss_ws, &e_b,
+                                           stream))
+        return rc;
+    } else if (int rc = loss_gather_rows(D.d, p->emb, bv.rows, bv.keep, b, p->loss_ws, &e_b, stream))
+      return rc;
   }
   if (int rc = plan_allreduce(p, e_b, (size_t)b * D.d, stream)) return rc;
   {
