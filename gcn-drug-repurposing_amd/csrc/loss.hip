@@ -67,8 +67,12 @@ __global__ __launch_bounds__(256) void gather_rows_mapped_kernel(int b, int d4, 
   st4(out + i * 4, mine ? ld4(e + ((size_t)rel * d4 + f4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
-template <int NG, bool EXACT>  // EXACT: d == 64 NG, no feature masking anywhere
-__global__ __launch_bounds__(64 * kLossWaves, 2) void loss_fused_kernel(LossArgs g) {
+// EXACT: d == 64 NG, no feature masking anywhere.  From d = 256 on the operand fragments + accumulators need more than the 256
+// registers two workgroups per CU leave a lane (372 B/lane of scratch at NG = 4): one workgroup per CU with the full 512
+// (accumulators in AGPRs), and at NG = 4 no register prefetch of the next j tile, measured at B = 2048, d = 256:
+// 123 us -> 55 us for gather + sweep + finish (tools/loss_prof.py 256).
+template <int NG, bool EXACT, bool PF = (NG <= 2), int OCC = (NG >= 4 ? 1 : 2)>
+__global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *red = reinterpret_cast<float4 *>(smem);  // [2 slots][NG*4 tiles][64 lanes]
   __shared__ double lsum[kLossWaves];
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(64 * kLossWaves, 2) void loss_fused_kernel(LossArgs
   float lacc = 0.f;
 
   float4 aj[HOLD_I ? NCH : 1];
-  if (HOLD_I && slot < nj) {
+  if (HOLD_I && PF && slot < nj) {
     const float *ej0 = g.e + (size_t)min(B - 1, slot * 16 + c) * d + 4 * q;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) aj[k] = (EXACT || 16 * k < d) ? ld4(ej0 + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -132,7 +136,18 @@ __global__ __launch_bounds__(64 * kLossWaves, 2) void loss_fused_kernel(LossArgs
       }
     }
     f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
-    if (HOLD_I) {
+    if (HOLD_I && !PF) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) aj[k] = (EXACT || 16 * k < d) ? ld4(ej + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        s0 = mfma16l(aj[k].x, bi[k].x, s0);
+        s1 = mfma16l(aj[k].y, bi[k].y, s1);
+        s0 = mfma16l(aj[k].z, bi[k].z, s0);
+        s1 = mfma16l(aj[k].w, bi[k].w, s1);
+      }
+    } else if (HOLD_I) {
       float4 an[NCH];
       const int jn = jt + nslots;
       const float *ejn = g.e + (size_t)min(B - 1, (jn < nj ? jn : jt) * 16 + c) * d + 4 * q;

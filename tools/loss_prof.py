@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""run N launches of gss_loss_fwd_bwd (B=2048, d=128) for rocprofv3"""
+"""gss_loss_fwd_bwd at B = 2048, d = argv[1] (default 128): sweep of the grid-size knob loss_wgs"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -28,7 +28,7 @@ for wgs in (128, 192, 256, 320, 512):
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 100 * 1e3)
     print(f"loss_wgs={wgs}: gather + sweep + finish {best:.1f} us")
-lib.gss_debug_set_option(b"loss_wgs", 512)
+lib.gss_debug_set_option(b"loss_wgs", 256)
 ws = torch.empty(lib.gss_loss_workspace_bytes(b, d), dtype=torch.uint8, device="cuda")
 for _ in range(5):
     lib.gss_loss_fwd_bwd(n, d, e.data_ptr(), idx.data_ptr(), b, 0.25, 1.0, loss.data_ptr(), de.data_ptr(), ws.data_ptr(), _lib.current_stream())
