@@ -16,6 +16,8 @@
 
 #include <algorithm>
 
+#include <exception>
+#include <memory>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -213,7 +215,17 @@ using namespace gss;
 
 extern "C" {
 
-int gss_edgelist_open(gss_edgelist_file **out, const char *path, const char *names, int64_t names_bytes, int64_t n_names, int32_t threads) {
+// a C++ exception (out of memory on a huge file, thread creation refused) must not cross the C boundary: reported as an error code
+#define GSS_NOTHROW(call, name)                                                   \
+  try {                                                                           \
+    return call;                                                                  \
+  } catch (const std::exception &ex) {                                            \
+    return fail(GSS_EINVAL, name ": %s", ex.what());                              \
+  } catch (...) {                                                                 \
+    return fail(GSS_EINVAL, name ": unknown C++ exception");                      \
+  }
+
+static int edgelist_open_impl(gss_edgelist_file **out, const char *path, const char *names, int64_t names_bytes, int64_t n_names, int32_t threads) {
   GSS_REQUIRE(out && path && (names || n_names == 0) && n_names >= 0, "edgelist_open: bad argument");
   // node name -> row (the .embs.txt order); views into the caller's '\n'-joined name buffer
   struct Key {
@@ -259,7 +271,8 @@ int gss_edgelist_open(gss_edgelist_file **out, const char *path, const char *nam
     if (s0 < end && text[s0] != '#') lines.push_back({s0, end});
     pos = end + 1;
   }
-  gss_edgelist_file *e = new gss_edgelist_file();
+  std::unique_ptr<gss_edgelist_file> owner(new gss_edgelist_file());
+  gss_edgelist_file *e = owner.get();
   const size_t m = lines.size();
   e->src.resize(m);
   e->dst.resize(m);
@@ -310,8 +323,11 @@ int gss_edgelist_open(gss_edgelist_file **out, const char *path, const char *nam
   }
   for (int64_t b : bad)
     if (b >= 0 && (e->bad_line < 0 || b < e->bad_line)) e->bad_line = b;
-  *out = e;
+  *out = owner.release();
   return GSS_OK;
+}
+int gss_edgelist_open(gss_edgelist_file **out, const char *path, const char *names, int64_t names_bytes, int64_t n_names, int32_t threads) {
+  GSS_NOTHROW(edgelist_open_impl(out, path, names, names_bytes, n_names, threads), "edgelist_open")
 }
 int64_t gss_edgelist_edges(const gss_edgelist_file *e) { return e ? (int64_t)e->src.size() : 0; }
 int64_t gss_edgelist_bad_line(const gss_edgelist_file *e) { return e ? e->bad_line : -1; }
@@ -326,7 +342,7 @@ int gss_edgelist_copy(const gss_edgelist_file *e, int32_t *src, int32_t *dst, do
 }
 void gss_edgelist_close(gss_edgelist_file *e) { delete e; }
 
-int gss_embs_open(gss_embs_file **out, const char *path, int32_t threads) {
+static int embs_open_impl(gss_embs_file **out, const char *path, int32_t threads) {
   GSS_REQUIRE(out && path, "embs_open: null argument");
   FILE *f = fopen(path, "rb");
   if (!f) return fail(GSS_EINVAL, "embs_open: cannot open %s: %s", path, strerror(errno));
@@ -358,11 +374,12 @@ int gss_embs_open(gss_embs_file **out, const char *path, int32_t threads) {
     }
     pos = end + 1;
   }
-  gss_embs_file *e = new gss_embs_file();
+  std::unique_ptr<gss_embs_file> owner(new gss_embs_file());
+  gss_embs_file *e = owner.get();
   e->header_n = header_n;
   e->n = (int64_t)lines.size();
   if (e->n == 0) {
-    *out = e;
+    *out = owner.release();
     return GSS_OK;
   }
   {  // d = tokens of the first data line - 1
@@ -376,7 +393,6 @@ int gss_embs_open(gss_embs_file **out, const char *path, int32_t threads) {
     e->d = tok - 1;
   }
   if (e->d < 1) {
-    delete e;
     return fail(GSS_EINVAL, "embs_open: %s: the first data line has no values", path);
   }
   e->x.resize((size_t)e->n * (size_t)e->d);
@@ -397,10 +413,7 @@ int gss_embs_open(gss_embs_file **out, const char *path, int32_t threads) {
     for (auto &th : pool) th.join();
   }
   for (char c : ok)
-    if (!c) {
-      delete e;
-      return fail(GSS_EINVAL, "embs_open: %s: a line does not hold a name and %d numbers", path, e->d);
-    }
+    if (!c) return fail(GSS_EINVAL, "embs_open: %s: a line does not hold a name and %d numbers", path, e->d);
   size_t total = 0;
   for (auto &s : span) total += s.second - s.first + 1;
   e->names.reserve(total);
@@ -408,9 +421,10 @@ int gss_embs_open(gss_embs_file **out, const char *path, int32_t threads) {
     e->names.append(text, s.first, s.second - s.first);
     e->names.push_back('\n');
   }
-  *out = e;
+  *out = owner.release();
   return GSS_OK;
 }
+int gss_embs_open(gss_embs_file **out, const char *path, int32_t threads) { GSS_NOTHROW(embs_open_impl(out, path, threads), "embs_open") }
 
 int64_t gss_embs_rows(const gss_embs_file *e) { return e ? e->n : 0; }
 int32_t gss_embs_cols(const gss_embs_file *e) { return e ? e->d : 0; }
@@ -431,7 +445,7 @@ int gss_format_e18(float value, char *out26) {
   return n;
 }
 
-int gss_write_embs_text(const char *path, const float *h_emb, int64_t n, int32_t d, int32_t threads) {
+static int write_embs_text_impl(const char *path, const float *h_emb, int64_t n, int32_t d, int32_t threads) {
   GSS_REQUIRE(path && (h_emb || n == 0) && n >= 0 && d >= 1, "write_embs_text: bad argument");
   FILE *f = fopen(path, "wb");
   if (!f) return fail(GSS_EINVAL, "write_embs_text: cannot open %s: %s", path, strerror(errno));
@@ -474,5 +488,7 @@ int gss_write_embs_text(const char *path, const float *h_emb, int64_t n, int32_t
   }
   if (fclose(f) != 0 && rc == GSS_OK) rc = fail(GSS_EINVAL, "write_embs_text: close of %s failed: %s", path, strerror(errno));
   return rc;
+}int gss_write_embs_text(const char *path, const float *h_emb, int64_t n, int32_t d, int32_t threads) {
+  GSS_NOTHROW(write_embs_text_impl(path, h_emb, n, d, threads), "write_embs_text")
 }
 }
