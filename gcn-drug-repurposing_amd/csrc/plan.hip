@@ -326,6 +326,13 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
       return fail(GSS_EHIP, "plan_create: hipMemset(pos) -> %s", hipGetErrorString(e));
     }
   }
+  // the memsets above ran on the null stream; the caller's stream may be a non-blocking one that does not order behind it
+  e = hipStreamSynchronize(nullptr);
+  if (e != hipSuccess) {
+    (void)hipFree(p->slab);
+    delete p;
+    return fail(GSS_EHIP, "plan_create: hipStreamSynchronize -> %s", hipGetErrorString(e));
+  }
   *out = p;
   return GSS_OK;
 }
