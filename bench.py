@@ -190,7 +190,7 @@ def main():
     ap.add_argument("--pipeline", action="store_true", help="cross-step layer-1 software pipelining on a second HIP stream "
                                                              "(measured: no gain, off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-steps", type=int, default=20, help="timed steps of the CPU baseline (~0.5 s each at config 2)")
     ap.add_argument("--min-time", type=float, default=0.5, help="after the K timed steps of the contract, keep stepping until this many "
                     "seconds have been timed and report that steadier figure as `long_run` (0 = off)")
     ap.add_argument("--spinup-time", type=float, default=0.3, help="seconds of untimed steps BEFORE the W warm-up steps, to bring the GPU to "
@@ -419,6 +419,10 @@ def main():
                     out[key]["traffic"] = z["hbm_traffic"][name]["traffic_bytes_per_launch"]
                     out[key]["traffic_source"] = f"offline rocprofv3 --pmc profile of the same command: profiles/{PMC_FILE}"
         out["spmm_kernel_edges_per_s"] = nnz / avg_s
+        # nnz / t_SpMM per launch, forward and backward kinds separately (HIP events around each launch).  spmm_bwd1 at
+        # L = 2 is the sparsity-aware top-layer hop (it visits only entries whose neighbour is a batch row), counted at nnz like the rest
+        out["spmm_kernel_edges_per_s_by_kind"] = {k: nnz / (prof[k][0] / prof[k][1] * 1e-3)
+                                                  for k in ("spmm_fwd_hadamard", "spmm_fwd", "spmm_bwd1", "spmm_bwd2") if prof.get(k, (0, 0))[1]}
     if single or not args.python_sharded:
         out["kernel_us"] = {k: (v[0] / max(v[1], 1) * 1e3) for k, v in prof.items() if v[1]}
         out["kernel_ms_per_step"] = {k: v[0] / args.steps for k, v in prof.items() if v[1]}
