@@ -194,6 +194,8 @@ bool parse_lines(const char *text, const std::vector<std::pair<size_t, size_t>> 
       char *q = nullptr;
       row[k] = strtod(p, &q);     // the line ends in '\n' or the buffer's terminating NUL: strtod stops there
       if (q == p || q > end) return false;
+      for (const char *c = p; c < q; ++c)
+        if (*c == 'x' || *c == 'X') return false;  // strtod reads C hex floats, Python's float() (np.loadtxt) does not
       p = q;
     }
     while (p < end && is_space(*p)) ++p;
