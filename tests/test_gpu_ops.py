@@ -302,7 +302,8 @@ def test_rownorm_fwd_and_bwd(G, n, d):
 
 
 # ---------------------------------------------------------------- K6 / K7
-@pytest.mark.parametrize("n,d,b", [(3000, 128, 2048), (500, 16, 500), (400, 64, 1), (900, 256, 333), (300, 32, 17), (2000, 128, 1288)])
+@pytest.mark.parametrize("n,d,b", [(3000, 128, 2048), (500, 16, 500), (400, 64, 1), (900, 256, 333), (300, 32, 17), (2000, 128, 1288),
+                                   (700, 192, 200), (600, 512, 130), (500, 320, 77), (400, 48, 50), (2100, 256, 2048)])
 def test_loss_fwd_bwd(G, n, d, b):
     rng = np.random.RandomState(b)
     x = rng.randn(n, d)
