@@ -195,6 +195,8 @@ def main():
                     "seconds have been timed and report that steadier figure as `long_run` (0 = off)")
     ap.add_argument("--spinup-time", type=float, default=0.3, help="seconds of untimed steps BEFORE the W warm-up steps, to bring the GPU to "
                     "its working clocks (a 5-step warm-up is 1.6 ms at this size); reported as spinup_steps")
+    ap.add_argument("--set", action="append", default=[], metavar="KNOB=VALUE", help="gss_debug_set_option before anything runs (A/B runs of "
+                    "a kernel variant, e.g. --set xcd_remap=0); listed in the JSON line as `knobs`")
     ap.add_argument("--python-sharded", action="store_true", help="multi-GPU: the Python-orchestrated ShardedEngine over "
                     "torch.distributed instead of the native sharded plan (A/B)")
     args = ap.parse_args()
@@ -232,7 +234,11 @@ def main():
 
     import gcn_drug_repurposing_amd as pkg
     from gcn_drug_repurposing_amd.graph import GssGraph
-    pkg.load()
+    lib_ = pkg.load()
+    for kv in args.set:
+        name, _, val = kv.partition("=")
+        if lib_.gss_debug_set_option(name.encode(), int(val)) != 0:
+            raise SystemExit(f"--set {kv}: {lib_.gss_last_error().decode()}")
 
     adj, x_host, d, L, B = build_workload(args.workload, args.hidden_units)
     from_source = x_host is None           # a row source instead of a matrix in memory (RMAT)
@@ -376,6 +382,8 @@ def main():
                                f"visits only entries whose neighbour is a batch row)",
                    "parallelism": parallelism, "final_loss": loss_end},
     }
+    if args.set:
+        out["knobs"] = list(args.set)
     if L > 1:
         # gathers actually executed: the top layer's backward SpMM only follows entries whose neighbour is one of the B batch
         # rows (expected nnz * B / N of them for a random batch); every other SpMM follows all nnz

@@ -12,6 +12,7 @@ extern int g_seg_edges;
 extern int g_gemm_variant;  // dense.hip
 extern int g_gemm_small_nt;
 extern int g_loss_wgs;      // loss.hip
+extern int g_xcd_remap;     // dense.hip
 }  // namespace gss
 
 using namespace gss;
@@ -56,6 +57,10 @@ int gss_debug_set_option(const char *name, int value) {
   if (strcmp(name, "loss_wgs") == 0) {
     GSS_REQUIRE(value >= 64 && value <= 4096, "loss_wgs must be in [64, 4096]");
     g_loss_wgs = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "xcd_remap") == 0) {
+    g_xcd_remap = value ? 1 : 0;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_small_nt") == 0) {

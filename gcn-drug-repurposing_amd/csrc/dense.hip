@@ -44,6 +44,7 @@ struct GemmArgs {
   // EPI_SPLIT
   const int32_t *rows;  // scatter map for the output row (nullable)
   float *inv_den;       // EPI_FWD_NORM: 1 / max(||x_row||, eps) per node (x_next then receives the unit-norm rows)
+  int xcd_remap;        // renumber the workgroups so that those sharing input rows sit on one XCD (xcd_ids below)
 };
 
 template <int FT, int EPI>
@@ -215,6 +216,32 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+
+// Workgroups go to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  Workgroups that read the SAME operand
+// rows (the column tiles of one node tile in the projections, the output tiles of one node slice in the weight gradient) are
+// therefore renumbered so that they land on one XCD, next to each other in dispatch order: `spread` indexes the groups (its
+// neighbours go to different XCDs), `share` the members of a group.  Linear id L -> (spread, share); the last (n_spread mod 8)
+// groups keep the plain order.  Knob "xcd_remap" (default 1).
+struct XcdIds {
+  int spread, share;
+};
+__device__ __forceinline__ XcdIds xcd_ids(int L, int n_spread, int n_share, bool on) {
+  const int full = (n_spread / 8) * 8;
+  XcdIds r;
+  if (!on || n_share == 1) {
+    r.spread = L % n_spread;
+    r.share = L / n_spread;
+  } else if (L < full * n_share) {
+    r.share = (L / 8) % n_share;
+    r.spread = (L % 8) + 8 * (L / (8 * n_share));
+  } else {
+    const int rem = L - full * n_share, tail = n_spread - full;
+    r.spread = full + rem % tail;
+    r.share = rem / tail;
+  }
+  return r;
+}
+
 template <int NT, int MT, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -230,8 +257,10 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const int node_base = blockIdx.x * BM;
-  const int j0 = blockIdx.y * BN;
+  // grid = (node tiles, column tiles): the column tiles of a node tile read the same input rows
+  const XcdIds id = xcd_ids((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)gridDim.x, (int)gridDim.y, g.xcd_remap != 0);
+  const int node_base = id.spread * BM;
+  const int j0 = id.share * BN;
   const int jh = j0 >= g.jsplit ? 1 : 0;
   const int jrow0 = j0 - (jh ? g.jsplit : 0);
 
@@ -343,11 +372,14 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
 // all workgroups reach the store phase together.
 
 int g_gemm_variant = 2;
+int g_xcd_remap = 1;    // debug knob "xcd_remap": workgroups that share input rows on one XCD (xcd_ids)
 int g_gemm_small_nt = 2;  // debug knob "gemm_small_nt": narrowest feature tile (in 16-feature units) for small problems, 0 = never narrow
 
 template <int EPI>
-static int launch_gemm(const GemmArgs &g, int d, hipStream_t st) {
-  if (g.n <= 0) return GSS_OK;
+static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
+  if (g_in.n <= 0) return GSS_OK;
+  GemmArgs g = g_in;
+  g.xcd_remap = g_xcd_remap;
   if (g_gemm_variant >= 2) {
     int nt = (d % 128 == 0) ? 8 : (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
     // few node rows (the top layer's batch-row input gradient: 2048 rows): narrower feature tiles so that the grid covers the chip
@@ -498,21 +530,25 @@ struct WgradArgs {
   float *part_w;  // [nslices][d][2d]
   float *part_b;  // [nslices][d]
   int rows_per_slice;
+  int xcd_remap;
 };
 
 // Two problems may share one launch (grid.y = ns0 + slices of the second): the top layer's batch-row gradient is 64
 // latency-bound workgroups on its own (10 us) and rides along with a full-N launch for free.
 __global__ __launch_bounds__(64 * kWgWaves) void wgrad_tn_kernel(WgradArgs g0, WgradArgs g1, int ns0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const bool second = (int)blockIdx.y >= ns0;
+  // grid = (output tiles, node slices): the output tiles of a slice read the same dP / Z rows
+  const XcdIds id = xcd_ids((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)gridDim.y, (int)gridDim.x, true);
+  const int bx = g0.xcd_remap ? id.share : (int)blockIdx.x, by = g0.xcd_remap ? id.spread : (int)blockIdx.y;
+  const bool second = by >= ns0;
   const WgradArgs &g = second ? g1 : g0;
   float4 *red = reinterpret_cast<float4 *>(smem);  // [4 slots][16 tiles][64 lanes] float4
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int fi = lane & 15, q = lane >> 4;
   const int tiles_k = (2 * g.d) / 64;
-  const int G = blockIdx.x / tiles_k, H = blockIdx.x % tiles_k;
-  const int slice = second ? (int)blockIdx.y - ns0 : (int)blockIdx.y;
+  const int G = bx / tiles_k, H = bx % tiles_k;
+  const int slice = second ? by - ns0 : by;
   const int r0 = slice * g.rows_per_slice;
   const int r1 = min(g.n, r0 + g.rows_per_slice);
   const int dh = g.d / 64;
@@ -748,7 +784,7 @@ int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const 
   *nslices_out = ns;
   float *pw = (float *)ws + (size_t)slice0 * d * 2 * d;
   float *pb = (float *)ws + (size_t)total_slices * d * 2 * d + (size_t)slice0 * d;
-  WgradArgs g{n, d, dp, ax, am, rows, pw, pb, rps};
+  WgradArgs g{n, d, dp, ax, am, rows, pw, pb, rps, g_xcd_remap};
   if (n == 0) {  // empty shard: its slices must still read as zero
     GSS_HIP(hipMemsetAsync(pw, 0, sizeof(float) * (size_t)ns * d * 2 * d, st));
     GSS_HIP(hipMemsetAsync(pb, 0, sizeof(float) * (size_t)ns * d, st));
@@ -783,8 +819,8 @@ int wgrad_partial_pair(int32_t d, int32_t n0, const float *dp0, const float *ax0
   *ns0_out = ns0;
   *ns1_out = ns1;
   float *base_w = (float *)ws, *base_b = (float *)ws + (size_t)total_slices * d * 2 * d;
-  WgradArgs g0{n0, d, dp0, ax0, am0, rows0, base_w + (size_t)slice0_0 * d * 2 * d, base_b + (size_t)slice0_0 * d, rps0};
-  WgradArgs g1{n1, d, dp1, ax1, am1, rows1, base_w + (size_t)slice0_1 * d * 2 * d, base_b + (size_t)slice0_1 * d, rps1};
+  WgradArgs g0{n0, d, dp0, ax0, am0, rows0, base_w + (size_t)slice0_0 * d * 2 * d, base_b + (size_t)slice0_0 * d, rps0, g_xcd_remap};
+  WgradArgs g1{n1, d, dp1, ax1, am1, rows1, base_w + (size_t)slice0_1 * d * 2 * d, base_b + (size_t)slice0_1 * d, rps1, g_xcd_remap};
   const int tiles = (d / 64) * (2 * d / 64);
   hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns0 + ns1), dim3(64 * kWgWaves), 4 * 16 * 64 * sizeof(float4), as_stream(stream), g0, g1,
                      ns0);
