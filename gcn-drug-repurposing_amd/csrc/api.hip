@@ -13,6 +13,7 @@ extern int g_gemm_variant;  // dense.hip
 extern int g_gemm_small_nt;
 extern int g_loss_wgs;      // loss.hip
 extern int g_xcd_remap;     // dense.hip
+extern int g_wgrad_wgs;
 }  // namespace gss
 
 using namespace gss;
@@ -57,6 +58,11 @@ int gss_debug_set_option(const char *name, int value) {
   if (strcmp(name, "loss_wgs") == 0) {
     GSS_REQUIRE(value >= 64 && value <= 4096, "loss_wgs must be in [64, 4096]");
     g_loss_wgs = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "wgrad_wgs") == 0) {
+    GSS_REQUIRE(value >= 8 && value <= 4096, "wgrad_wgs must be in [8, 4096]");
+    g_wgrad_wgs = value;   // before any plan is created: the plan sizes its partial buffer with it
     return GSS_OK;
   }
   if (strcmp(name, "xcd_remap") == 0) {

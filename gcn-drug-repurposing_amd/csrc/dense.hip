@@ -372,6 +372,7 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
 // all workgroups reach the store phase together.
 
 int g_gemm_variant = 2;
+int g_wgrad_wgs = 256;  // debug knob "wgrad_wgs": workgroups of a full-size weight-gradient launch (one per CU)
 int g_xcd_remap = 1;    // debug knob "xcd_remap": workgroups that share input rows on one XCD (xcd_ids)
 int g_gemm_small_nt = 2;  // debug knob "gemm_small_nt": narrowest feature tile (in 16-feature units) for small problems, 0 = never narrow
 
@@ -758,7 +759,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int d, int nslices, c
 
 static void wgrad_geometry(int32_t n, int32_t d, int &nslices, int &rows_per_slice) {
   const int tiles = (d % 64 == 0) ? (d / 64) * (2 * d / 64) : ceil_div((int64_t)d * 2 * d + d, 256);
-  int want = ceil_div(256, tiles);
+  int want = ceil_div(g_wgrad_wgs, tiles);
   const int max_slices = n > 0 ? ceil_div(n, 32) : 1;
   if (want > max_slices) want = max_slices;
   if (want < 1) want = 1;
@@ -884,12 +885,12 @@ int wgrad_slices(int32_t n, int32_t d) {
 
 // wgrad_geometry is not monotone in n (rows_per_slice is rounded up to 32, so a slightly smaller n can need more
 // slices: d = 128, n = 1034 -> 17, n = 1008 -> 32).  Upper bound over every n in [1, n_max]: nslices <= want <=
-// min(ceil(256 / tiles), ceil(n_max / 32)).  Plans size the batch-row region with this so that the short last
+// min(ceil(wgrad_wgs / tiles), ceil(n_max / 32)).  Plans size the batch-row region with this so that the short last
 // batch of an epoch always fits.
 int wgrad_slices_max(int32_t n_max, int32_t d) {
   const int tiles = (d % 64 == 0) ? (d / 64) * (2 * d / 64) : ceil_div((int64_t)d * 2 * d + d, 256);
   const int cap = n_max > 0 ? ceil_div(n_max, 32) : 1;
-  const int want = ceil_div(256, tiles);
+  const int want = ceil_div(g_wgrad_wgs, tiles);
   return want < cap ? (want < 1 ? 1 : want) : cap;
 }
 
