@@ -71,6 +71,11 @@ __global__ __launch_bounds__(256) void gather_rows_mapped_kernel(int b, int d4, 
 // registers two workgroups per CU leave a lane (372 B/lane of scratch at NG = 4): one workgroup per CU with the full 512
 // (accumulators in AGPRs), and at NG = 4 no register prefetch of the next j tile, measured at B = 2048, d = 256:
 // 123 us -> 55 us for gather + sweep + finish (tools/loss_prof.py 256).
+// Measured dead ends at d = 128, B = 2048 (gather + sweep + finish 31.6 us, tools/loss_prof.py): 8 waves per workgroup 33.2 us; two j
+// tiles per trip with two operand register sets that swap roles (no copies, every wait a full tile behind its load in the ISA) 34.7 us;
+// the second product's operand loads removed altogether (wrong results, timing only) 30.6 us -- the sweep is bound by neither its
+// loads nor their waits; 1024 MFMAs per SIMD are 13.7 us at 2.4 GHz and ~16.5 us at the ~2.0 GHz an MFMA-saturated loop sustains
+// (tools/micro/mfma_lds.hip: 126-131 of 157 TFLOP/s), the rest is the fixed start (i-tile fragments) and end (wave tree, partial store).
 template <int NG, bool EXACT, bool PF = (NG <= 2), int OCC = (NG >= 4 ? 1 : 2)>
 __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
