@@ -14,6 +14,7 @@ extern int g_gemm_small_nt;
 extern int g_loss_wgs;      // loss.hip
 extern int g_xcd_remap;     // dense.hip
 extern int g_wgrad_wgs;
+extern int g_gemm_nt_cap;
 }  // namespace gss
 
 using namespace gss;
@@ -58,6 +59,11 @@ int gss_debug_set_option(const char *name, int value) {
   if (strcmp(name, "loss_wgs") == 0) {
     GSS_REQUIRE(value >= 64 && value <= 4096, "loss_wgs must be in [64, 4096]");
     g_loss_wgs = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "gemm_nt_cap") == 0) {
+    GSS_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "gemm_nt_cap must be 0, 1, 2, 4 or 8");
+    g_gemm_nt_cap = value;
     return GSS_OK;
   }
   if (strcmp(name, "wgrad_wgs") == 0) {

@@ -372,6 +372,7 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
 // all workgroups reach the store phase together.
 
 int g_gemm_variant = 2;
+int g_gemm_nt_cap = 0;
 int g_wgrad_wgs = 256;  // debug knob "wgrad_wgs": workgroups of a full-size weight-gradient launch (one per CU)
 int g_xcd_remap = 1;    // debug knob "xcd_remap": workgroups that share input rows on one XCD (xcd_ids)
 int g_gemm_small_nt = 2;  // debug knob "gemm_small_nt": narrowest feature tile (in 16-feature units) for small problems, 0 = never narrow
@@ -383,6 +384,8 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
   g.xcd_remap = g_xcd_remap;
   if (g_gemm_variant >= 2) {
     int nt = (d % 128 == 0) ? 8 : (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
+    if (g_gemm_nt_cap > 0 && EPI != EPI_FWD_NORM)   // debug knob "gemm_nt_cap": narrower feature tiles (the fused normalise needs whole rows)
+      while (nt > g_gemm_nt_cap) nt >>= 1;
     // few node rows (the top layer's batch-row input gradient: 2048 rows): narrower feature tiles so that the grid covers the chip
     // (64-node x 128-feature tiles give 64 workgroups at B = 2048, d = 128; 32-feature tiles 256)
     if (EPI == EPI_SPLIT && g_gemm_small_nt > 0)
