@@ -14,6 +14,9 @@ extern int g_gemm_small_nt;
 extern int g_loss_wgs;      // loss.hip
 extern int g_xcd_remap;     // dense.hip
 extern int g_wgrad_wgs;
+}
+extern int g_sparse_bits_rows;  // plan.hip
+namespace gss {
 extern int g_gemm_nt_cap;
 }  // namespace gss
 
@@ -59,6 +62,11 @@ int gss_debug_set_option(const char *name, int value) {
   if (strcmp(name, "loss_wgs") == 0) {
     GSS_REQUIRE(value >= 64 && value <= 4096, "loss_wgs must be in [64, 4096]");
     g_loss_wgs = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "sparse_bits_rows") == 0) {
+    GSS_REQUIRE(value >= 1, "sparse_bits_rows must be >= 1");
+    g_sparse_bits_rows = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_nt_cap") == 0) {

@@ -123,6 +123,15 @@ __global__ void batch_bits_kernel(const int32_t *__restrict__ ids, int b, uint32
     bits[(unsigned)id >> 5] = 0u;  // every set bit of the word belongs to a member of this batch
 }
 
+__global__ void bits_fill_kernel(uint32_t *__restrict__ bits, long long first, long long last) {
+  const long long w = first / 32 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w > (last - 1) / 32) return;
+  const long long b0 = w * 32;
+  const int lo = (int)(first > b0 ? first - b0 : 0), hi = (int)(last < b0 + 32 ? last - b0 : 32);
+  const uint32_t mask = (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+  bits[w] |= mask;   // one thread per word
+}
+
 // halo exchange, sender side: out[k] = src[rows[k]] -- the rows the peers reference, packed in peer order
 __global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n, int d4, const float *__restrict__ src, const int32_t *__restrict__ rows,
                                                         float *__restrict__ out) {
@@ -296,6 +305,15 @@ int batch_bits(const int32_t *ids, int32_t b, uint32_t *bits, int set, void *str
   if (b == 0) return GSS_OK;
   hipLaunchKernelGGL(batch_bits_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, as_stream(stream), ids, b, bits, set);
   GSS_LAUNCH_CHECK("batch_bits_kernel");
+  return GSS_OK;
+}
+
+int bits_fill(uint32_t *bits, int64_t first, int64_t last, void *stream) {
+  GSS_REQUIRE(bits && first >= 0, "bits_fill: bad argument");
+  if (last <= first) return GSS_OK;
+  const int64_t words = (last - 1) / 32 - first / 32 + 1;
+  hipLaunchKernelGGL(bits_fill_kernel, dim3(ceil_div(words, 256)), dim3(256), 0, as_stream(stream), bits, (long long)first, (long long)last);
+  GSS_LAUNCH_CHECK("bits_fill_kernel");
   return GSS_OK;
 }
 

@@ -73,12 +73,14 @@ int shard_batch_maps(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, cons
                      int32_t *rows_all, int32_t *rows_own, float *keep, int32_t *pos_col, int32_t *pos_row, void *stream);
 int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,
                      const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream,
-                     const uint32_t *posbits = nullptr);
+                     const uint32_t *posbits = nullptr, uint32_t *nzbits_out = nullptr, int skip_zero_rows = 0);
 // bitmap companion of a batch-position map: set (value 1) or clear (value 0) the words of ids[0..b) (negative ids skipped)
 int batch_bits(const int32_t *ids, int32_t b, uint32_t *bits, int set, void *stream);
 bool spmm_sparse_available();
 int spmm_bwd2_sparse_res(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res_b,
-                         const int32_t *pos_row, float *dp, float *gx_out, void *stream);
+                         const int32_t *pos_row, float *dp, float *gx_out, void *stream, const uint32_t *nzbits = nullptr);
+// bits [first, last) of a bitmap := 1 (whole and partial words; other bits untouched)
+int bits_fill(uint32_t *bits, int64_t first, int64_t last, void *stream);
 int adam_step(int64_t count, float *param, const float *grad, float *m, float *v, int32_t step, float lr, float beta1,
               float beta2, float eps, float *wt, int32_t dim, void *stream);
 struct AdamTensor {

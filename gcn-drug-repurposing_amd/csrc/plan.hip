@@ -30,6 +30,8 @@ struct gss_plan {
   float *de_b, *dx_b, *dp_b, *gax_b, *gam_b;
   int32_t *pos;  // operand row of A_hat^T's column space -> batch position (-1 outside the batch), for the sparsity-aware backward SpMM
   uint32_t *posbits;  // bitmap of pos >= 0, kept only around the sparse backward SpMM and only for huge operands (else NULL)
+  uint32_t *nzbits;   // huge operands only (else NULL): bit r set <=> row r of u (the top layer's A_hat^T operand) may be non-zero; written by the
+                      // sparse hop, read by the hop after it (which then skips the zero rows); halo rows are always set
   float *w1t, *w2t;
   float *grad[4];
   float *adam_m[4], *adam_v[4];
@@ -74,6 +76,10 @@ struct gss_plan {
   float *keep;             // per batch: 1.0 where this shard owns the member
   float *gab;              // [2 * max_batch][d]: the top layer's compact input gradients, all-reduced as one buffer
 };
+
+// debug knob "sparse_bits_rows": operand rows from which a plan keeps the two bitmaps of the sparsity-aware backward hops (the
+// batch-membership bitmap in front of the position map, the non-zero-row bitmap of u); plans created afterwards
+int g_sparse_bits_rows = 500000;
 
 using namespace gss;
 
@@ -172,7 +178,10 @@ void carve(gss_plan *p, Carver &c) {
   p->gax_b = p->gam_b = nullptr;
   p->pos = L > 1 ? c.take<int32_t>(p->rows_t ? p->rows_t : 1) : nullptr;
   // a 4-byte-per-node map beyond the L2s (>= 500k operand rows = 2 MB): the sparse SpMM tests a bitmap first (zero-initialised slab)
-  p->posbits = (L > 1 && p->rows_t >= (size_t)500000) ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;
+  // (the sizing pass carves from a null base: conditions must not look at the pointers it hands out)
+  const bool bitmaps = L > 1 && p->rows_t >= (size_t)g_sparse_bits_rows;
+  p->posbits = bitmaps ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;
+  p->nzbits = bitmaps ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;
   p->w1t = c.take<float>((size_t)D.d * D.d);
   p->w2t = c.take<float>((size_t)D.d * D.d);
   const size_t cnt[4] = {(size_t)D.d * D.d, (size_t)D.d, (size_t)D.d * D.d, (size_t)D.d};
@@ -300,6 +309,12 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
   Carver real;
   real.base = p->slab;
   carve(p, real);
+  if (real.off != sizing.off) {  // the two passes must carve the same sequence (a condition that looked at a pointer would not)
+    const size_t a_ = sizing.off, b_ = real.off;
+    (void)hipFree(p->slab);
+    delete p;
+    return fail(GSS_EINVAL, "plan_create: internal error, sizing pass %zu bytes but carving pass %zu", a_, b_);
+  }
   if (desc->n == 0) {  // an empty shard: launchers still want non-null operands (they move zero rows)
     if (!p->x) p->x = p->x_last;
     if (!p->emb) p->emb = p->x_last;
@@ -324,6 +339,14 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
       (void)hipFree(p->slab);
       delete p;
       return fail(GSS_EHIP, "plan_create: hipMemset(pos) -> %s", hipGetErrorString(e));
+    }
+  }
+  if (p->nzbits && p->rows_t > (size_t)desc->n) {
+    // rows a peer owns: this shard cannot know whether they are zero
+    if (int rc = bits_fill(p->nzbits, desc->n, (int64_t)p->rows_t, nullptr)) {
+      (void)hipFree(p->slab);
+      delete p;
+      return rc;
     }
   }
   // the memsets above ran on the null stream; the caller's stream may be a non-blocking one that does not order behind it
@@ -558,9 +581,20 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
         PROF(GSS_PROF_ELEMENTWISE);
         if (int rc = batch_bits(bv.ids, b, p->posbits, 1, stream)) return rc;
       }
+      // huge operands: the hop records which rows of u can be non-zero, the hop after it -- fold_res below -- follows only those.
+      // One shard: every bit is cleared and rows whose bit stays clear are not even written (nothing reads them).  Several shards: the
+      // word that straddles the own rows and the always-set halo rows keeps its bits (stale own bits only cost gathers; all rows are
+      // written, a peer may read them)
+      const bool track_nz = p->nzbits && deferred_slices;
+      const size_t nz_words = p->P == 1 ? ((size_t)D.n + 31) / 32 : (size_t)D.n / 32;
+      if (track_nz && nz_words > 0) {
+        PROF(GSS_PROF_ELEMENTWISE);
+        GSS_HIP(hipMemsetAsync(p->nzbits, 0, sizeof(uint32_t) * nz_words, st));
+      }
       {
         PROF(GSS_PROF_SPMM_BWD1);
-        if (int rc = spmm_bwd1_sparse(p->at, D.d, p->gam_b, p->gax_b, p->pos, pos_row, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream, p->posbits))
+        if (int rc = spmm_bwd1_sparse(p->at, D.d, p->gam_b, p->gax_b, p->pos, pos_row, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream, p->posbits,
+                                      track_nz ? p->nzbits : nullptr, track_nz && p->P == 1))
           return rc;
       }
       if (p->posbits) {
@@ -591,7 +625,7 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
         PROF(GSS_PROF_SPMM_BWD2);
         if (fold_res) {
           // dP += dx_b on the batch rows inside the SpMM epilogue (no separate scatter-add launch)
-          if (int rc = spmm_bwd2_sparse_res(p->at, D.d, p->u, p->t, p->p[lp], c, p->dx_b, pos_row, p->dp, gx_out, stream)) return rc;
+          if (int rc = spmm_bwd2_sparse_res(p->at, D.d, p->u, p->t, p->p[lp], c, p->dx_b, pos_row, p->dp, gx_out, stream, p->nzbits)) return rc;
         } else {
           if (int rc = spmm_bwd2(p->at, D.d, p->u, p->t, p->p[lp], c, res, p->dp, gx_out, stream)) return rc;
         }

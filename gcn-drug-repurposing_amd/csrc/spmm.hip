@@ -34,7 +34,13 @@ struct SpmmEpi {
   const int32_t *pos;      // SPMM_BWD1S: column id -> row of the compact operands, -1 if not a batch row
   const int32_t *pos_row;  // SPMM_BWD1S: output row -> row of the compact g_ax, -1 if not a batch row
   const uint32_t *posbits; // SPMM_BWD1S, optional: bit c set <=> pos[c] >= 0.  For huge operands: the bitmap (N / 8 bytes) stays in
-                           // L2 where the int32 map (4 N bytes) does not, and only the rare hits go on to read pos[]
+                           // L2 where the int32 map (4 N bytes) does not, and only the rare hits go on to read pos[].
+                           // SPMM_BWD2S, optional: bit c clear => row c of the gathered operand (u) is all zeros and row c of a0 (t)
+                           // as well: such neighbours are skipped, such output rows do not read t (nor p when their sum is zero too)
+  uint32_t *nzbits_out;    // SPMM_BWD1S, optional: bit r is set for every output row r whose u may be non-zero (the row had a batch-row
+                           // neighbour or is a batch row); the caller clears the map beforehand.  The next hop's posbits.
+  int skip_zero_rows;      // SPMM_BWD1S with nzbits_out: rows whose bit stays clear are not written at all (their u and t are zero and
+                           // every reader consults the bitmap first); only when no peer reads the rows either (single shard)
 };
 
 struct CsrView {
@@ -102,8 +108,10 @@ __device__ __forceinline__ void row_accumulate(const CsrView &a, const float *__
   }
 }
 
+__device__ __forceinline__ bool is_zero4(const float4 &v) { return v.x == 0.f && v.y == 0.f && v.z == 0.f && v.w == 0.f; }
+
 template <int MODE>
-__device__ __forceinline__ void row_epilogue(const SpmmEpi &ep, size_t off, float4 acc, long coff = -1) {
+__device__ __forceinline__ void row_epilogue(const SpmmEpi &ep, size_t off, float4 acc, long coff = -1, bool t_zero = false) {
   if (MODE == SPMM_PLAIN) {
     st4(ep.o0 + off, acc);
   } else if (MODE == SPMM_FWD1) {
@@ -115,14 +123,18 @@ __device__ __forceinline__ void row_epilogue(const SpmmEpi &ep, size_t off, floa
     st4(ep.o1 + off, mul4(acc, ld4(ep.a2 + off)));
   } else if (MODE == SPMM_BWD1S) {
     // same with a row-sparse g_ax held compactly: coff addresses its row (or is < 0)
-    float4 u = mul4(acc, ld4(ep.a1 + off));
+    // a row without a batch-row neighbour (nearly all of them when B << N) has acc == 0: u = g_ax (or 0), t = 0 without reading x / ax
+    const bool z = is_zero4(acc);
+    if (z && coff < 0 && ep.skip_zero_rows) return;
+    float4 u = z ? make_float4(0.f, 0.f, 0.f, 0.f) : mul4(acc, ld4(ep.a1 + off));
     if (coff >= 0) u = add4(u, ld4(ep.a0 + coff));
     st4(ep.o0 + off, u);
-    st4(ep.o1 + off, mul4(acc, ld4(ep.a2 + off)));
+    st4(ep.o1 + off, z ? make_float4(0.f, 0.f, 0.f, 0.f) : mul4(acc, ld4(ep.a2 + off)));
   } else if (MODE == SPMM_BWD2S) {
     // as SPMM_BWD2 with the residual gradient held compactly on the batch rows (coff < 0: not a batch row)
-    const float4 gx = add4(ld4(ep.a0 + off), acc);
-    float4 dp = scale4(ep.c, mul4(gx, elu_grad4(ld4(ep.a1 + off))));
+    // t_zero: the caller knows t's row is zero (posbits); with a zero sum as well the row's gradient is the residual alone
+    const float4 gx = t_zero ? acc : add4(ld4(ep.a0 + off), acc);
+    float4 dp = (t_zero && is_zero4(acc)) ? make_float4(0.f, 0.f, 0.f, 0.f) : scale4(ep.c, mul4(gx, elu_grad4(ld4(ep.a1 + off))));
     if (coff >= 0) dp = add4(dp, ld4(ep.a2 + coff));
     st4(ep.o0 + off, dp);
     if (ep.o1) st4(ep.o1 + off, gx);
@@ -229,6 +241,21 @@ __device__ __forceinline__ long compact_off(const SpmmEpi &ep, int row, int d4, 
   return pr >= 0 ? ((long)pr * d4 + f4) * 4 : -1;
 }
 
+// SPMM_BWD2S with a bitmap: a clear bit says row `row` of t is zero
+template <int MODE>
+__device__ __forceinline__ bool row_t_zero(const SpmmEpi &ep, int row) {
+  if (MODE != SPMM_BWD2S || !ep.posbits) return false;
+  return ((ep.posbits[(unsigned)row >> 5] >> (row & 31)) & 1u) == 0u;
+}
+// SPMM_BWD1S with nzbits_out: u = acc (.) x + g_ax can only be non-zero where the sum is, or on a batch row.  gmask = the lanes of
+// this lane's group (they hold the pieces of one row): its first lane sets the bit when any piece is non-zero
+template <int MODE>
+__device__ __forceinline__ void mark_nonzero(const SpmmEpi &ep, int row, const float4 &sum, long coff, unsigned long long gmask) {
+  if (MODE != SPMM_BWD1S || !ep.nzbits_out) return;
+  const unsigned long long m = __ballot(coff >= 0 || !is_zero4(sum));
+  if ((m & gmask) != 0ull && (int)(threadIdx.x & 63) == __builtin_ctzll(gmask)) atomicOr(&ep.nzbits_out[(unsigned)row >> 5], 1u << (row & 31));
+}
+
 template <int MODE, int LPR_LOG2, int VPL, bool NARROW, int FLY = 4>
 __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, const int4 *__restrict__ segs, int d4,
                                                                    const float *__restrict__ x, SpmmEpi ep, int rowstride_f, int pin_ns, int3 hot) {
@@ -250,6 +277,8 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   const int plog = sd.w & 0xff;
   const bool multiwave = (sd.w & 0x100) != 0;  // workgroup-uniform: some row of this workgroup spans several waves
   const bool col_ok = (VPL > 1) || (li < d4);
+  constexpr unsigned long long kGroupLow = LPR >= 64 ? ~0ull : ((1ull << (LPR & 63)) - 1ull);   // LPR ones
+  const unsigned long long gmask = kGroupLow << ((g << LPR_LOG2) & 63);                          // the lanes of this lane's group
   // feature slicing: this workgroup walks one d4-wide slice of rows that are rowstride_f floats long.  Either
   // time-separated (grid.y, the slow dispatch dimension: slice s+1 starts when slice s drains) or pinned to XCDs
   // (pin_ns, above); launch_balanced picks
@@ -279,37 +308,76 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
     }
     const int ce = base + li;
     const int cnt = min(LPR, e1 - base);  // <= 0 once this group is done
-    if (MODE == SPMM_BWD1S) {
-      // row-sparse operand: only neighbours that are batch rows contribute (about B/N of the entries).  Look
-      // the neighbour up in the node -> compact-row map and walk the hits of this group one at a time.
-      int cp = -1;
-      if (ce < e1) {
-        if (!ep.posbits || ((ep.posbits[(unsigned)c >> 5] >> (c & 31)) & 1u)) cp = ep.pos[c];
-      }
-      const unsigned long long hits = __ballot(cp >= 0);
-      unsigned long long gm = LPR == 64 ? hits : ((hits >> (g << LPR_LOG2)) & ((1ull << LPR) - 1ull));
-      while (__any(gm != 0ull)) {
-        const bool ok = gm != 0ull;
-        const int srcl = ok ? __builtin_ctzll(gm) : 0;
-        gm &= gm - 1ull;
-        const int src = (g << LPR_LOG2) + srcl;
-        const int cc = __shfl(cp, src, 64);
-        const float ww = __shfl(w, src, 64);
-        if (ok && col_ok) {
-          const float *xr = x + (size_t)cc * rowstride;
+    // one row gather of this lane group: slice of row cc of the operand, zeros when !ok
+    auto gather_row = [&](int cc, bool ok, float4 (&dst)[VPL]) __attribute__((always_inline)) {
+      if (NARROW) {
+        // operand < 4 GB, < 2^24 rows: 32-bit byte offsets from the (uniform) base, one full-rate 24-bit multiply-add per gather
+        const unsigned off = __umul24((unsigned)cc, (unsigned)(rowstride_f * 4)) + (unsigned)li * 16u;
 #pragma unroll
-          for (int v = 0; v < VPL; ++v) {
-            const int f4 = li + v * 64;
-            if (VPL == 1 || f4 < d4) acc[v] = fma4(ww, ld4(xr + (size_t)f4 * 4), acc[v]);
+        for (int v = 0; v < VPL; ++v) {
+          const int f4 = li + v * 64;
+          dst[v] = (ok && (VPL == 1 || f4 < d4)) ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(x) + (off + v * 1024u))
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+      }
+      const float *xr = x + (size_t)cc * rowstride;
+      // a CSR with a declared hot set (gss_csr_set_hot: nodes relabelled hub-first; operand rows [0, hot.x) and
+      // [hot.y, hot.z) belong to the hubs): every other row is fetched with the non-temporal policy, so that the
+      // once-read cold rows do not evict the hubs' rows from L2 / the Infinity Cache
+      const bool cold = hot.x >= 0 && !(cc < hot.x || (cc >= hot.y && cc < hot.z));
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const int f4 = li + v * 64;
+        const float *src = xr + (size_t)f4 * 4;
+        float4 got = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && (VPL == 1 || f4 < d4)) {
+          if (cold) {
+            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src));
+            got = make_float4(t[0], t[1], t[2], t[3]);
+          } else {
+            got = ld4(src);
           }
         }
+        dst[v] = got;
+      }
+    };
+    constexpr int kFly = FLY;
+    if (MODE == SPMM_BWD1S || (MODE == SPMM_BWD2S && ep.posbits)) {
+      // row-sparse operand.  BWD1S: only neighbours that are batch rows contribute (about B/N of the entries): look the neighbour up in
+      // the node -> compact-row map (behind the bitmap when there is one).  BWD2S with a bitmap: only neighbours whose row of u may be
+      // non-zero.  The hits of a group are walked in entry order, kFly gathers in flight.
+      int cp = -1;
+      if (ce < e1) {
+        const bool member = !ep.posbits || ((ep.posbits[(unsigned)c >> 5] >> (c & 31)) & 1u);
+        if (member) cp = MODE == SPMM_BWD1S ? ep.pos[c] : c;
+      }
+      const unsigned long long hits = __ballot(cp >= 0);
+      unsigned long long gm = (hits >> ((g << LPR_LOG2) & 63)) & kGroupLow;
+      while (__any(gm != 0ull)) {
+        float4 xv[kFly][VPL];
+        float wv[kFly];
+#pragma unroll
+        for (int u = 0; u < kFly; ++u) {
+          const bool ok = gm != 0ull;
+          const int srcl = ok ? __builtin_ctzll(gm) : 0;
+          gm &= gm - 1ull;
+          const int src = (g << LPR_LOG2) + srcl;
+          const int cc = __shfl(cp, src, 64);
+          const float ww = __shfl(w, src, 64);
+          wv[u] = ok ? ww : 0.f;
+          gather_row(ok ? cc : 0, ok && col_ok, xv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kFly; ++u)
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) acc[v] = fma4(wv[u], xv[u][v], acc[v]);
       }
       continue;
     }
     // kFly row gathers in flight per lane group.  Measured at config 2 (d = 128): 16 -> 44.1 us, 8 -> 39.5 us,
     // 4 -> 36.2 us, 2 -> 37.7 us.  Deeper queues only add L2 thrash; at 4 the kernel needs 48 VGPRs, so two
     // 1024-thread workgroups share a CU (32 waves) instead of one.
-    constexpr int kFly = FLY;
     for (int t = 0; __any(t < cnt); t += kFly) {
       float4 xv[kFly][VPL];
       float wv[kFly];
@@ -320,37 +388,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
         wv[u] = __shfl(w, src, 64);
         const bool ok = (t + u < cnt) && col_ok;
         if (!ok) wv[u] = 0.f;
-        if (NARROW) {
-          // operand < 4 GB, < 2^24 rows: 32-bit byte offsets from the (uniform) base, one full-rate 24-bit multiply-add per gather
-          const unsigned off = __umul24((unsigned)cc, (unsigned)(rowstride_f * 4)) + (unsigned)li * 16u;
-#pragma unroll
-          for (int v = 0; v < VPL; ++v) {
-            const int f4 = li + v * 64;
-            xv[u][v] = (ok && (VPL == 1 || f4 < d4)) ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(x) + (off + v * 1024u))
-                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-          continue;
-        }
-        const float *xr = x + (size_t)cc * rowstride;
-        // a CSR with a declared hot set (gss_csr_set_hot: nodes relabelled hub-first; operand rows [0, hot.x) and
-        // [hot.y, hot.z) belong to the hubs): every other row is fetched with the non-temporal policy, so that the
-        // once-read cold rows do not evict the hubs' rows from L2 / the Infinity Cache
-        const bool cold = hot.x >= 0 && !(cc < hot.x || (cc >= hot.y && cc < hot.z));
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          const int f4 = li + v * 64;
-          const float *src = xr + (size_t)f4 * 4;
-          float4 got = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ok && (VPL == 1 || f4 < d4)) {
-            if (cold) {
-              const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src));
-              got = make_float4(t[0], t[1], t[2], t[3]);
-            } else {
-              got = ld4(src);
-            }
-          }
-          xv[u][v] = got;
-        }
+        gather_row(cc, ok, xv[u]);
       }
 #pragma unroll
       for (int u = 0; u < kFly; ++u)
@@ -376,10 +414,15 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   }
   if (pcount <= GPW) {
     if (row >= 0 && (g & (pcount - 1)) == 0) {
+      const bool tz = row_t_zero<MODE>(ep, row);
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
         const int f4 = li + v * 64;
-        if (f4 < d4) row_epilogue<MODE>(ep, ((size_t)row * rs4 + slice_f4 + f4) * 4, acc[v], compact_off<MODE>(ep, row, rs4, slice_f4 + f4));
+        if (f4 < d4) {
+          const long coff = compact_off<MODE>(ep, row, rs4, slice_f4 + f4);
+          mark_nonzero<MODE>(ep, row, acc[v], coff, gmask);
+          row_epilogue<MODE>(ep, ((size_t)row * rs4 + slice_f4 + f4) * 4, acc[v], coff, tz);
+        }
       }
     }
   }
@@ -401,7 +444,9 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
       if (f4 >= d4) continue;
       float4 t = part[wib * d4 + f4];
       for (int k = 1; k < nw; ++k) t = add4(t, part[(wib + k) * d4 + f4]);
-      row_epilogue<MODE>(ep, ((size_t)row * rs4 + slice_f4 + f4) * 4, t, compact_off<MODE>(ep, row, rs4, slice_f4 + f4));
+      const long coff = compact_off<MODE>(ep, row, rs4, slice_f4 + f4);
+      mark_nonzero<MODE>(ep, row, t, coff, gmask);
+      row_epilogue<MODE>(ep, ((size_t)row * rs4 + slice_f4 + f4) * 4, t, coff, row_t_zero<MODE>(ep, row));
     }
   }
 }
@@ -595,23 +640,25 @@ int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float 
 int spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
               float *u, float *t, void *stream) {
   GSS_REQUIRE(g_am && g_ax && x_in && ax && u && t, "spmm_bwd1: null operand");
-  SpmmEpi ep{g_ax, x_in, ax, u, t, 0.f, nullptr, nullptr, nullptr};
+  SpmmEpi ep{g_ax, x_in, ax, u, t, 0.f, nullptr, nullptr, nullptr, nullptr};
   return launch_spmm<SPMM_BWD1>(at, d, g_am, ep, stream);
 }
 
 int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,
-                     const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream, const uint32_t *posbits) {
+                     const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream, const uint32_t *posbits,
+                     uint32_t *nzbits_out, int skip_zero_rows) {
   GSS_REQUIRE(g_am_b && g_ax_b && pos && pos_row && x_in && ax && u && t, "spmm_bwd1_sparse: null operand");
   GSS_REQUIRE(g_spmm_variant == 2, "spmm_bwd1_sparse needs the balanced SpMM (spmm_variant 2)");
-  SpmmEpi ep{g_ax_b, x_in, ax, u, t, 0.f, pos, pos_row, posbits};
+  GSS_REQUIRE(!skip_zero_rows || nzbits_out, "spmm_bwd1_sparse: skipping the zero rows needs the bitmap that records them");
+  SpmmEpi ep{g_ax_b, x_in, ax, u, t, 0.f, pos, pos_row, posbits, nzbits_out, skip_zero_rows};
   return launch_spmm<SPMM_BWD1S>(at, d, g_am_b, ep, stream);
 }
 
 int spmm_bwd2_sparse_res(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res_b,
-                         const int32_t *pos_row, float *dp, float *gx_out, void *stream) {
+                         const int32_t *pos_row, float *dp, float *gx_out, void *stream, const uint32_t *nzbits) {
   GSS_REQUIRE(u && t && p && res_b && pos_row && dp, "spmm_bwd2_sparse_res: null operand");
   GSS_REQUIRE(g_spmm_variant == 2, "spmm_bwd2_sparse_res needs the balanced SpMM (spmm_variant 2)");
-  SpmmEpi ep{t, p, res_b, dp, gx_out, c, nullptr, pos_row, nullptr};
+  SpmmEpi ep{t, p, res_b, dp, gx_out, c, nullptr, pos_row, nzbits, nullptr, 0};
   return launch_spmm<SPMM_BWD2S>(at, d, u, ep, stream);
 }
 
@@ -620,7 +667,7 @@ bool spmm_sparse_available() { return g_spmm_variant == 2; }
 int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
               float *dp, float *gx_out, void *stream) {
   GSS_REQUIRE(u && t && p && dp, "spmm_bwd2: null operand");
-  SpmmEpi ep{t, p, res, dp, gx_out, c, nullptr, nullptr, nullptr};
+  SpmmEpi ep{t, p, res, dp, gx_out, c, nullptr, nullptr, nullptr, nullptr};
   return launch_spmm<SPMM_BWD2>(at, d, u, ep, stream);
 }
 

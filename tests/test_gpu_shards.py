@@ -207,3 +207,48 @@ def test_hub_first_relabelling_is_invisible_in_the_results(world):
         embs.append((eng.gather_embeddings().cpu().numpy(), eng.loss.item(), shard.nnz_global))
     np.testing.assert_array_equal(embs[0][0], embs[1][0])
     assert embs[0][1] == embs[1][1] and embs[0][2] == embs[1][2] == m2 + n2
+
+
+@pytest.mark.parametrize("world,L", [(1, 2), (1, 3), (3, 2)])
+def test_nonzero_row_bitmaps_of_the_sparse_backward_change_nothing(world, L):
+    """Plans over huge operands (>= sparse_bits_rows rows, 500k by default) keep two bitmaps: batch membership in front of the position map of
+    the top layer's sparse backward hop, and -- written by that hop -- the rows of its result u that can be non-zero, which the hop
+    after it follows exclusively (B << N: nearly all rows of u are zero).  Forced on here at test size (knob) with a small batch, so
+    that most rows ARE skipped: parameters, losses and embeddings after 4 steps equal the plan without the bitmaps bit for bit."""
+    import gcn_drug_repurposing_amd as pkg
+    from gcn_drug_repurposing_amd.dist import local_comms
+    from gcn_drug_repurposing_amd.shards import ScipySource, build_shard, shard_engine, shard_rows
+    from conftest import golden_params
+    lib = pkg.load()
+    g = load_golden("knn_n2000_d64_L3")
+    n, d, _ = (int(v) for v in g["meta"])
+    adj, X, p0 = golden_csr(g, "A"), g["X"], golden_params(g, "init")
+    rng = np.random.RandomState(5)
+    batches = [rng.choice(n, size=s, replace=False).astype(np.int32) for s in (40, 7, 64, 1)]
+    kw = dict(num_layers=L, layer_decay=float(g["decay"]), alpha=float(g["alpha"]), lr=float(g["lr"]), max_batch=64)
+
+    def run(bits_rows):
+        assert lib.gss_debug_set_option(b"sparse_bits_rows", bits_rows) == 0
+        try:
+            comms = local_comms(world)
+
+            def fn(rank):
+                shard = build_shard(ScipySource(adj), comms[rank], need_transpose=True, device="cuda:0", relabel=False)
+                eng = shard_engine(shard, shard_rows(shard, X), p0, comms[rank], **kw)
+                losses = []
+                for idx in batches:
+                    eng.step(torch.from_numpy(idx).cuda(), float(g["beta"]))
+                    losses.append(eng.loss.item())
+                eng.forward()
+                return dict(losses=losses, emb=eng.gather_embeddings().cpu().numpy(), params=[t.cpu().numpy().copy() for t in eng.params])
+
+            return _threaded(world, fn, comms)
+        finally:
+            lib.gss_debug_set_option(b"sparse_bits_rows", 500000)
+
+    plain, bits = run(500000), run(1)
+    for a, b in zip(plain, bits):
+        assert a["losses"] == b["losses"]
+        np.testing.assert_array_equal(a["emb"], b["emb"])
+        for x, y in zip(a["params"], b["params"]):
+            np.testing.assert_array_equal(x, y)
