@@ -79,7 +79,7 @@ struct gss_plan {
 
 // debug knob "sparse_bits_rows": operand rows from which a plan keeps the two bitmaps of the sparsity-aware backward hops (the
 // batch-membership bitmap in front of the position map, the non-zero-row bitmap of u); plans created afterwards
-int g_sparse_bits_rows = 500000;
+int g_sparse_bits_rows = 100000;   // measured with RMAT graphs at B = 2048 (tools/ab_sparse_bits.sh): 60k rows -2.5 %, 120k +2 %, 250k +4.4 %, 450k +6.4 % of a step
 
 using namespace gss;
 
@@ -177,7 +177,7 @@ void carve(gss_plan *p, Carver &c) {
   p->gab = L > 1 ? c.take<float>(2 * bd) : nullptr;            // gax_b = gab, gam_b = gab + b * d: one all-reduce
   p->gax_b = p->gam_b = nullptr;
   p->pos = L > 1 ? c.take<int32_t>(p->rows_t ? p->rows_t : 1) : nullptr;
-  // a 4-byte-per-node map beyond the L2s (>= 500k operand rows = 2 MB): the sparse SpMM tests a bitmap first (zero-initialised slab)
+  // from sparse_bits_rows operand rows on: the sparse SpMM tests a bitmap before the 4-byte-per-node map (zero-initialised slab)
   // (the sizing pass carves from a null base: conditions must not look at the pointers it hands out)
   const bool bitmaps = L > 1 && p->rows_t >= (size_t)g_sparse_bits_rows;
   p->posbits = bitmaps ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;

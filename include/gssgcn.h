@@ -384,7 +384,8 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
  * gss_csr_set_hot declared) or a row count; "gemm_small_nt", "gemm_nt_cap" = narrowest / widest feature tile of the projections in
  * 16-feature units (0 = automatic); "xcd_remap" = 0 / 1 (default): workgroups that read the same rows share an XCD (dense kernels);
  * "wgrad_wgs", "loss_wgs" = workgroups of a full-size weight-gradient launch / the loss sweep (default 256 = one per CU; set
- * before plans are created).  Every setting computes the same results (some in a different summation order); the defaults are the
+ * before plans are created); "sparse_bits_rows" = operand rows from which a plan keeps the bitmaps of the sparsity-aware backward hops
+ * (default 100000).  Every setting computes the same results (some in a different summation order); the defaults are the
  * measured optima recorded in DESIGN.md section 4. */
 int gss_debug_set_option(const char *name, int value);
 /* plain device-to-device copy on `stream` (lets a ctypes host read plan-owned activations) */

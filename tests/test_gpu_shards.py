@@ -211,7 +211,7 @@ def test_hub_first_relabelling_is_invisible_in_the_results(world):
 
 @pytest.mark.parametrize("world,L", [(1, 2), (1, 3), (3, 2)])
 def test_nonzero_row_bitmaps_of_the_sparse_backward_change_nothing(world, L):
-    """Plans over huge operands (>= sparse_bits_rows rows, 500k by default) keep two bitmaps: batch membership in front of the position map of
+    """Plans over huge operands (>= sparse_bits_rows rows, 100k by default) keep two bitmaps: batch membership in front of the position map of
     the top layer's sparse backward hop, and -- written by that hop -- the rows of its result u that can be non-zero, which the hop
     after it follows exclusively (B << N: nearly all rows of u are zero).  Forced on here at test size (knob) with a small batch, so
     that most rows ARE skipped: parameters, losses and embeddings after 4 steps equal the plan without the bitmaps bit for bit."""
@@ -244,9 +244,9 @@ def test_nonzero_row_bitmaps_of_the_sparse_backward_change_nothing(world, L):
 
             return _threaded(world, fn, comms)
         finally:
-            lib.gss_debug_set_option(b"sparse_bits_rows", 500000)
+            lib.gss_debug_set_option(b"sparse_bits_rows", 100000)
 
-    plain, bits = run(500000), run(1)
+    plain, bits = run(100000), run(1)
     for a, b in zip(plain, bits):
         assert a["losses"] == b["losses"]
         np.testing.assert_array_equal(a["emb"], b["emb"])
