@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--workload", default="whole_graph")
     ap.add_argument("--hidden-units", type=int, default=None)
     ap.add_argument("--cache-layer1", action="store_true", help="also report the step time with layer-1 SpMMs cached")
+    ap.add_argument("--lazy-top", action="store_true", help="also time gss_plan_step_lazy (the top layer on the batch rows only: the same loss, "
+                    "gradients and parameters bit for bit) and report it as `lazy_top`; `value` stays the full step")
     ap.add_argument("--pipeline", action="store_true", help="cross-step layer-1 software pipelining on a second HIP stream "
                                                              "(measured: no gain, off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -367,6 +369,25 @@ def main():
             el2 = float(t.item())
         long_run = {"steps": reps * args.steps, "seconds": el2, "ms_per_step": el2 / (reps * args.steps) * 1e3}
 
+    lazy_top = None
+    if args.lazy_top and world == 1 and hasattr(engine, "step_lazy"):
+        # opt-in extra: the same steps through gss_plan_step_lazy (NOT the reported value: the reference's step computes all N rows of
+        # the top layer; this one computes the B rows anything reads).  Same batches, timed the same way.
+        def run_lazy(lo, hi):
+            for s in range(lo, hi):
+                engine.step_lazy(idx_all, beta, count=int(offs[s + 1] - offs[s]), offset=int(offs[s]))
+        run_lazy(0, args.warmup)
+        reps = max(1, int(np.ceil(args.min_time / max(elapsed, 1e-6)))) if args.min_time > 0 else 1
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            run_lazy(args.warmup, args.warmup + args.steps)
+        barrier()
+        lz = (time.perf_counter() - t1) / (reps * args.steps)
+        lazy_top = {"ms_per_step": lz * 1e3, "steps": reps * args.steps, "final_loss": float(engine.loss.item()),
+                    "note": "gss_plan_step_lazy: top layer's A_hat M / projection / ELU / normalise on the batch rows only; loss, gradients "
+                            "and parameters bit-identical to the full step (tests/test_gpu_train.py); not part of `value`"}
+
     spmm_per_step = 2 * L + 2 * (L - 1)
     ms_per_step = elapsed / args.steps * 1e3
     value = spmm_per_step * nnz * args.steps / elapsed
@@ -384,6 +405,8 @@ def main():
     }
     if args.set:
         out["knobs"] = list(args.set)
+    if lazy_top:
+        out["lazy_top"] = lazy_top
     if L > 1:
         # gathers actually executed: the top layer's backward SpMM only follows entries whose neighbour is one of the B batch
         # rows (expected nnz * B / N of them for a random batch); every other SpMM follows all nnz

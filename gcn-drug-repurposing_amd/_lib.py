@@ -109,6 +109,7 @@ SIGNATURES = {
     "gss_plan_backward": (C.c_int, [_P, _P, _I32, _P, _P]),
     "gss_plan_adam": (C.c_int, [_P, _P]),
     "gss_plan_step": (C.c_int, [_P, _P, _I32, _F, _P]),
+    "gss_plan_step_lazy": (C.c_int, [_P, _P, _I32, _F, _P]),
     "gss_plan_activation": (_P, [_P, C.c_int, C.c_int]),
     "gss_plan_device_bytes": (_SZ, [_P]),
     "gss_plan_set_step": (None, [_P, _I32]),

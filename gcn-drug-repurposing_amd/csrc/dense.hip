@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 template <int NT, int EPI>
 __device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&acc)[NT], int nd, int j0, int q) {
   const bool live = nd < g.n;
-  const int ndc = min(nd, g.n - 1);
+  int ndc = min(nd, g.n - 1);
+  if (g.rows) ndc = g.rows[ndc];   // forward over a row list (gss_plan_step_lazy): tile row -> node row, inputs and outputs alike
   float4 bb[NT], pp[NT];
 #pragma unroll
   for (int u = 0; u < NT; ++u) {
@@ -181,11 +182,11 @@ __device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&ac
   if (!live) return;
 #pragma unroll
   for (int u = 0; u < NT; ++u) {
-    const size_t off = (size_t)nd * g.ld_out0 + j0 + 16 * u + 4 * q;
+    const size_t off = (size_t)ndc * g.ld_out0 + j0 + 16 * u + 4 * q;   // ndc == nd for a live row without a row list
     st4(g.out0 + off, pv[u]);
     st4(g.x_next + off, EPI == EPI_FWD_NORM ? scale4(inv, o[u]) : o[u]);
   }
-  if (EPI == EPI_FWD_NORM && q == 0) g.inv_den[nd] = inv;
+  if (EPI == EPI_FWD_NORM && q == 0) g.inv_den[ndc] = inv;
 }
 
 // ---- LDS-staged variant (default) -----------------------------------------------------------------------
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
     const float *wp = g.w[jh][kh];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int node = min(g.n - 1, node_base + 16 * (w + 4 * i) + r);
+      int node = min(g.n - 1, node_base + 16 * (w + 4 * i) + r);
+      if (EPI != EPI_SPLIT && g.rows) node = g.rows[node];
       xsrc[kh][i] = in ? in + (size_t)node * ld + 4 * q : nullptr;
     }
 #pragma unroll
@@ -428,9 +430,10 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
 }
 
 int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
-              const float *b2, const float *p_prev, float decay, float *p, float *x_next, void *stream) {
+              const float *b2, const float *p_prev, float decay, float *p, float *x_next, void *stream, const int32_t *row_list) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(n >= 0 && ax && am && w1 && b1 && w2 && b2 && p && x_next, "dense_fwd: null operand");
+  GSS_REQUIRE(!row_list || g_gemm_variant >= 2, "dense_fwd: a row list needs the LDS-staged GEMM");
   GemmArgs g{};
   g.n = n;
   g.K = 2 * d;
@@ -452,7 +455,7 @@ int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const floa
   g.p_prev = p_prev;
   g.x_next = x_next;
   g.decay = decay;
-  g.rows = nullptr;
+  g.rows = row_list;
   return launch_gemm<EPI_FWD>(g, d, as_stream(stream));
 }
 
@@ -460,7 +463,7 @@ int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const floa
 bool dense_fwd_norm_available(int32_t d) { return g_gemm_variant >= 2 && (d == 128 || d == 64 || d == 32 || d == 16); }
 
 int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
-                   const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream) {
+                   const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream, const int32_t *row_list) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(n >= 0 && ax && am && w1 && b1 && w2 && b2 && p && e && inv_den, "dense_fwd_norm: null operand");
   GSS_REQUIRE(dense_fwd_norm_available(d), "dense_fwd_norm: needs d in {16, 32, 64, 128} and the LDS-staged GEMM");
@@ -484,6 +487,7 @@ int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const
   g.x_next = e;
   g.decay = decay;
   g.inv_den = inv_den;
+  g.rows = row_list;
   return launch_gemm<EPI_FWD_NORM>(g, d, as_stream(stream));
 }
 

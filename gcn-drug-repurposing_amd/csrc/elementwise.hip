@@ -123,6 +123,18 @@ __global__ void batch_bits_kernel(const int32_t *__restrict__ ids, int b, uint32
     bits[(unsigned)id >> 5] = 0u;  // every set bit of the word belongs to a member of this batch
 }
 
+// gss_plan_step_lazy, before the forward pass: node id -> row (node_map, relabelled graphs), the translated ids for the kernels that
+// index by row, and the batch-position map pos[row] = position (the row mask of the top layer, later the key of the sparse backward hop)
+__global__ void batch_prepare_kernel(const int32_t *__restrict__ idx, int b, const int32_t *__restrict__ node_map, int32_t *__restrict__ rows_out,
+                                     int32_t *__restrict__ ids_out, int32_t *__restrict__ pos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b) return;
+  const int id = node_map ? node_map[idx[i]] : idx[i];
+  if (rows_out) rows_out[i] = id;
+  if (ids_out) ids_out[i] = id;
+  pos[id] = i;
+}
+
 __global__ void bits_fill_kernel(uint32_t *__restrict__ bits, long long first, long long last) {
   const long long w = first / 32 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (w > (last - 1) / 32) return;
@@ -305,6 +317,14 @@ int batch_bits(const int32_t *ids, int32_t b, uint32_t *bits, int set, void *str
   if (b == 0) return GSS_OK;
   hipLaunchKernelGGL(batch_bits_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, as_stream(stream), ids, b, bits, set);
   GSS_LAUNCH_CHECK("batch_bits_kernel");
+  return GSS_OK;
+}
+
+int batch_prepare(const int32_t *idx, int32_t b, const int32_t *node_map, int32_t *rows_out, int32_t *ids_out, int32_t *pos, void *stream) {
+  GSS_REQUIRE(idx && pos && b >= 0, "batch_prepare: null operand");
+  if (b == 0) return GSS_OK;
+  hipLaunchKernelGGL(batch_prepare_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, as_stream(stream), idx, b, node_map, rows_out, ids_out, pos);
+  GSS_LAUNCH_CHECK("batch_prepare_kernel");
   return GSS_OK;
 }
 

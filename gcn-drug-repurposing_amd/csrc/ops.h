@@ -35,16 +35,21 @@ struct gss_comm {
 namespace gss {
 // nnz-balanced segment descriptors of a CSR for 2^gpw_log2 lane groups per wave (spmm.hip; cached in the handle)
 int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks);
-int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream);
+int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream,
+             const int32_t *row_pos = nullptr,   // plain product only: compute rows with row_pos[row] >= 0 only
+             const uint32_t *row_bits = nullptr); // Hadamard-fused product only: compute rows whose bit is set only
+int mark_rows_and_neighbours(const gss_csr *a, const int32_t *rows, int32_t b, uint32_t *bits, void *stream);
 int spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
               float *u, float *t, void *stream);
 int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
               float *dp, float *gx_out, void *stream);
 int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
-              const float *b2, const float *p_prev, float decay, float *p, float *x_next, void *stream);
+              const float *b2, const float *p_prev, float decay, float *p, float *x_next, void *stream,
+              const int32_t *row_list = nullptr);  // row_list: the n tile rows are node rows row_list[0..n) of every operand
 bool dense_fwd_norm_available(int32_t d);
 int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
-                   const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream);
+                   const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream,
+                   const int32_t *row_list = nullptr);
 int dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t, const float *w2t, const int32_t *rows,
                     float *g_ax, float *g_am, void *stream);
 size_t wgrad_workspace_bytes(int32_t n, int32_t d);
@@ -79,6 +84,7 @@ int batch_bits(const int32_t *ids, int32_t b, uint32_t *bits, int set, void *str
 bool spmm_sparse_available();
 int spmm_bwd2_sparse_res(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res_b,
                          const int32_t *pos_row, float *dp, float *gx_out, void *stream, const uint32_t *nzbits = nullptr);
+int batch_prepare(const int32_t *idx, int32_t b, const int32_t *node_map, int32_t *rows_out, int32_t *ids_out, int32_t *pos, void *stream);
 // bits [first, last) of a bitmap := 1 (whole and partial words; other bits untouched)
 int bits_fill(uint32_t *bits, int64_t first, int64_t last, void *stream);
 int adam_step(int64_t count, float *param, const float *grad, float *m, float *v, int32_t step, float lr, float beta1,

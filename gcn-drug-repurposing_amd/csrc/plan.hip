@@ -30,6 +30,7 @@ struct gss_plan {
   float *de_b, *dx_b, *dp_b, *gax_b, *gam_b;
   int32_t *pos;  // operand row of A_hat^T's column space -> batch position (-1 outside the batch), for the sparsity-aware backward SpMM
   uint32_t *posbits;  // bitmap of pos >= 0, kept only around the sparse backward SpMM and only for huge operands (else NULL)
+  uint32_t *needbits; // huge operands only (else NULL): gss_plan_step_lazy -- the rows of the top layer's AX / M that anything reads (batch + neighbours)
   uint32_t *nzbits;   // huge operands only (else NULL): bit r set <=> row r of u (the top layer's A_hat^T operand) may be non-zero; written by the
                       // sparse hop, read by the hop after it (which then skips the zero rows); halo rows are always set
   float *w1t, *w2t;
@@ -182,6 +183,7 @@ void carve(gss_plan *p, Carver &c) {
   const bool bitmaps = L > 1 && p->rows_t >= (size_t)g_sparse_bits_rows;
   p->posbits = bitmaps ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;
   p->nzbits = bitmaps ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;
+  p->needbits = (bitmaps && !sharded) ? c.take<uint32_t>(n1 / 32 + 1) : nullptr;
   p->w1t = c.take<float>((size_t)D.d * D.d);
   p->w2t = c.take<float>((size_t)D.d * D.d);
   const size_t cnt[4] = {(size_t)D.d * D.d, (size_t)D.d, (size_t)D.d * D.d, (size_t)D.d};
@@ -418,7 +420,9 @@ int plan_prefetch_layer1(gss_plan *p, void *main_stream) {
   return GSS_OK;
 }
 
-int plan_forward_impl(gss_plan *p, void *stream) {
+// lazy_rows != NULL (gss_plan_step_lazy): the top layer's A_hat M, projection, ELU, residual and normalisation are evaluated on the
+// lazy_b listed rows only (p->pos is their row mask) -- the rows the loss and the backward pass read
+int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = nullptr, int32_t lazy_b = 0) {
   GSS_REQUIRE(p, "plan_forward: null plan");
   const gss_plan_desc &D = p->desc;
   const int L = D.num_layers;
@@ -445,27 +449,40 @@ int plan_forward_impl(gss_plan *p, void *stream) {
       // layer 1's inputs are constants, so are the boundary rows of its M: every shard recomputes its own rows each step
       // (the SpMM is executed), the boundary rows are exchanged once
       float *m = l == 0 ? p->m0op : p->m_tmp;
+      const bool lazy_l = lazy_rows && l == L - 1;
+      if (lazy_l && p->needbits) {
+        // huge graphs: AX and M of the top layer on the batch rows and their neighbours only (what A_hat M on the batch rows, the
+        // batch-row weight gradient and the backward hop's epilogue read)
+        PROF(GSS_PROF_ELEMENTWISE);
+        GSS_HIP(hipMemsetAsync(p->needbits, 0, sizeof(uint32_t) * (((size_t)D.n + 31) / 32), as_stream(stream)));
+        if (int rc = mark_rows_and_neighbours(p->a, lazy_rows, lazy_b, p->needbits, stream)) return rc;
+      }
       {
         PROF(GSS_PROF_SPMM_FWD_HAD);
-        if (int rc = spmm_fwd(p->a, D.d, xl, p->ax[l], xl, m, stream)) return rc;
+        if (int rc = spmm_fwd(p->a, D.d, xl, p->ax[l], xl, m, stream, nullptr, (lazy_l && p->needbits) ? p->needbits : nullptr)) return rc;
       }
       // AM = A M                      (model.py:169)
       if (l > 0 || !p->m0_ready) {
         if (int rc = plan_halo(p, p->halo_a, m, stream)) return rc;
         if (l == 0) p->m0_ready = true;
       }
+      const bool lazy = lazy_l;
       {
         PROF(GSS_PROF_SPMM_FWD);
-        if (int rc = spmm_fwd(p->a, D.d, m, p->am[l], nullptr, nullptr, stream)) return rc;
+        if (int rc = spmm_fwd(p->a, D.d, m, p->am[l], nullptr, nullptr, stream, lazy ? p->pos : nullptr)) return rc;
       }
-      if (l == 0) p->layer1_valid = true;
+      if (l == 0 && !lazy) p->layer1_valid = true;
     }
     PROF(GSS_PROF_DENSE_FWD);
     if (l == L - 1 && dense_fwd_norm_available(D.d)) {
       // last layer: F.normalize fused into the GEMM epilogue (no x_last round trip, no extra launch)
+      if (lazy_rows)
+        return dense_fwd_norm(lazy_b, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr, D.layer_decay,
+                              p->p[l], p->emb, p->inv_den, stream, lazy_rows);
       return dense_fwd_norm(D.n, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr, D.layer_decay,
                             p->p[l], p->emb, p->inv_den, stream);
     }
+    GSS_REQUIRE(!(lazy_rows && l == L - 1), "plan_forward: the batch-row top layer needs the fused normalise epilogue");
     float *xn = (l == L - 1) ? p->x_last : p->xin[l + 1];
     if (int rc = dense_fwd(D.n, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr,
                            D.layer_decay, p->p[l], xn, stream))
@@ -494,8 +511,9 @@ static BatchView plan_batch_view(gss_plan *p, const int32_t *idx) {
 int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float *de_rows, bool top_done, bool wt_ok, void *stream,
                        int *deferred_slices = nullptr);
 
+// prepared (gss_plan_step_lazy): batch_prepare already translated the batch ids and set the batch-position map
 int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta, bool wt_ok, void *stream, BatchView &bv,
-                            int *deferred_slices = nullptr) {
+                            int *deferred_slices = nullptr, bool prepared = false) {
   GSS_REQUIRE(p && idx, "plan_loss_backward: null argument");
   const gss_plan_desc &D = p->desc;
   GSS_REQUIRE(b >= 1 && b <= D.max_batch, "plan_loss_backward: batch %d out of [1, %d]", b, D.max_batch);
@@ -507,7 +525,7 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
   {
     // E_B = emb[idx] (model.py:216-217): every shard contributes the rows it owns, one all-reduce assembles them (C3)
     PROF(GSS_PROF_LOSS);
-    if (plan_batch_mapped(p)) {
+    if (plan_batch_mapped(p) && !prepared) {
       if (int rc = loss_gather_rows_mapped(D.d, p->emb, idx, D.node_map, p->lo, D.n, p->gid2op_t, p->pid, p->rloc, p->keep, b, p->loss_ws, &e_b,
                                            stream))
         return rc;
@@ -520,7 +538,7 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
     // sweep -- identical bits everywhere, no exchange of the loss -- and keeps the gradient rows it owns)
     PROF(GSS_PROF_LOSS);
     if (int rc = loss_fused_gathered(D.d, b, beta, D.alpha, p->loss, bv.rows, bv.ids, bv.keep, p->inv_den, p->p[L - 1],
-                                     L > 1 ? D.layer_decay : 1.f, p->dx_b, p->dp_b, sparse_top ? p->pos : nullptr, p->loss_ws, stream))
+                                     L > 1 ? D.layer_decay : 1.f, p->dx_b, p->dp_b, (sparse_top && !prepared) ? p->pos : nullptr, p->loss_ws, stream))
       return rc;
   }
   return plan_backward_impl(p, bv, b, nullptr, true, wt_ok, stream, deferred_slices);
@@ -733,15 +751,42 @@ int gss_plan_adam(gss_plan *p, void *stream) {
   if (p) p->wt_valid = false;
   return rc;
 }
-int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
+static int plan_step_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream, bool lazy);
+
+int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) { return plan_step_impl(p, idx, b, beta, stream, false); }
+
+// The same step with the top layer evaluated on the batch rows only.  The loss reads the top layer's output on the b batch rows and
+// its backward pass reads AX of that layer (kept whole); A_hat M, the projection, ELU, the residual and the normalisation of the other
+// N - b rows are not read by anything inside a step.  A row that IS computed goes through the same segments, the same summation tree
+// and the same MFMA rows as in the full pass, so loss, gradients and parameters equal gss_plan_step's bit for bit; afterwards
+// io.emb holds this step's embeddings on the batch rows only (call gss_plan_forward for all of them).  Falls back to the full step
+// where the pieces it needs are absent (one layer, a sharded plan, a width without the fused normalise epilogue, spmm_variant 1).
+int gss_plan_step_lazy(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
+  GSS_REQUIRE(p, "plan_step_lazy: null plan");
+  const gss_plan_desc &D = p->desc;
+  const bool can = p->P == 1 && D.num_layers > 1 && spmm_sparse_available() && dense_fwd_norm_available(D.d) && !D.pipeline_layer1 && p->pos;
+  return plan_step_impl(p, idx, b, beta, stream, can);
+}
+
+static int plan_step_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream, bool lazy) {
   GSS_REQUIRE(p, "plan_step: null plan");
   const bool pipe = p->desc.pipeline_layer1 && p->side && !p->prof_on && !p->desc.cache_layer1;
-  if (int rc = plan_forward_impl(p, stream)) return rc;
+  if (lazy) {
+    GSS_REQUIRE(idx && b >= 1 && b <= p->desc.max_batch, "plan_step_lazy: batch %d out of [1, %d]", b, p->desc.max_batch);
+    const bool mapped = p->desc.node_map != nullptr;
+    {
+      PROF(GSS_PROF_ELEMENTWISE);
+      if (int rc = batch_prepare(idx, b, p->desc.node_map, mapped ? p->rloc : nullptr, mapped ? p->pid : nullptr, p->pos, stream)) return rc;
+    }
+    if (int rc = plan_forward_impl(p, stream, mapped ? p->rloc : idx, b)) return rc;
+  } else if (int rc = plan_forward_impl(p, stream)) {
+    return rc;
+  }
   if (pipe)  // the side stream starts when this stream reaches the loss kernel (MFMA-bound, 1 MB working set)
     if (int rc = plan_prefetch_layer1(p, stream)) return rc;
   int slices = 0;
   BatchView bv{};
-  if (int rc = plan_loss_backward_impl(p, idx, b, beta, p->wt_valid, stream, bv, &slices)) return rc;
+  if (int rc = plan_loss_backward_impl(p, idx, b, beta, p->wt_valid, stream, bv, &slices, lazy)) return rc;
   const gss_plan_desc &D = p->desc;
   const bool wt = D.num_layers > 1;
   const bool sparse_top = wt && spmm_sparse_available();

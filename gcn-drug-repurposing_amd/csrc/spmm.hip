@@ -272,8 +272,22 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   const int g = lane >> LPR_LOG2;
   const int li = lane & (LPR - 1);
   const int4 sd = segs[((size_t)sblk * kBalWaves + wib) * GPW + g];  // {row, first edge, edge count, flags | log2 p}
-  const int row = sd.x;
-  const int e0 = sd.y, e1 = sd.y + sd.z;
+  int row = sd.x;
+  const int e0 = sd.y;
+  int e1 = sd.y + sd.z;
+  // SPMM_PLAIN with a row map (ep.pos): only rows with pos[row] >= 0 are computed -- the others' segments gather nothing and store
+  // nothing (their output rows keep whatever they held).  A computed row is summed exactly as in the full launch (same segments,
+  // same tree): gss_plan_step_lazy's top layer needs A_hat M on the batch rows only
+  if (MODE == SPMM_PLAIN && ep.pos && row >= 0 && ep.pos[row] < 0) {
+    row = -1;
+    e1 = e0;
+  }
+  // SPMM_FWD1 with a row bitmap (ep.posbits): the same for AX / M -- gss_plan_step_lazy on huge graphs needs them on the batch rows
+  // and their neighbours only
+  if (MODE == SPMM_FWD1 && ep.posbits && row >= 0 && !((ep.posbits[(unsigned)row >> 5] >> (row & 31)) & 1u)) {
+    row = -1;
+    e1 = e0;
+  }
   const int plog = sd.w & 0xff;
   const bool multiwave = (sd.w & 0x100) != 0;  // workgroup-uniform: some row of this workgroup spans several waves
   const bool col_ok = (VPL > 1) || (li < d4);
@@ -626,14 +640,17 @@ static int launch_spmm(const gss_csr *a, int32_t d, const float *x, const SpmmEp
 }
 
 // internal entry points shared with plan.hip
-int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream) {
+int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream, const int32_t *row_pos,
+             const uint32_t *row_bits) {
   GSS_REQUIRE(y, "spmm: y is null");
+  GSS_REQUIRE(!row_pos || (!m && g_spmm_variant == 2), "spmm: a row map goes with the plain product of the balanced SpMM only");
+  GSS_REQUIRE(!row_bits || (m && g_spmm_variant == 2), "spmm: a row bitmap goes with the Hadamard-fused product of the balanced SpMM only");
   if (m) {
     GSS_REQUIRE(h, "spmm: m given without h");
-    SpmmEpi ep{h, nullptr, nullptr, y, m, 0.f, nullptr, nullptr, nullptr};
+    SpmmEpi ep{h, nullptr, nullptr, y, m, 0.f, nullptr, nullptr, row_bits};
     return launch_spmm<SPMM_FWD1>(a, d, x, ep, stream);
   }
-  SpmmEpi ep{nullptr, nullptr, nullptr, y, nullptr, 0.f, nullptr, nullptr, nullptr};
+  SpmmEpi ep{nullptr, nullptr, nullptr, y, nullptr, 0.f, row_pos, nullptr, nullptr};
   return launch_spmm<SPMM_PLAIN>(a, d, x, ep, stream);
 }
 
@@ -663,6 +680,28 @@ int spmm_bwd2_sparse_res(const gss_csr *at, int32_t d, const float *u, const flo
 }
 
 bool spmm_sparse_available() { return g_spmm_variant == 2; }
+
+// bits[r] := 1 for every listed row r and every column of the listed rows of `a` (one wave per listed row)
+__global__ __launch_bounds__(256) void mark_rows_and_neighbours_kernel(CsrView a, const int32_t *__restrict__ rows, int b, uint32_t *__restrict__ bits) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= b) return;
+  const int r = rows[i];
+  if (lane == 0) atomicOr(&bits[(unsigned)r >> 5], 1u << (r & 31));
+  for (int e = a.rowptr[r] + lane; e < a.rowptr[r + 1]; e += 64) {
+    const int c = a.col[e];
+    atomicOr(&bits[(unsigned)c >> 5], 1u << (c & 31));
+  }
+}
+
+int mark_rows_and_neighbours(const gss_csr *a, const int32_t *rows, int32_t b, uint32_t *bits, void *stream) {
+  GSS_REQUIRE(a && rows && bits && b >= 0, "mark_rows_and_neighbours: null operand");
+  if (b == 0) return GSS_OK;
+  CsrView v{a->rowptr, a->col, a->val, a->n_rows};
+  hipLaunchKernelGGL(mark_rows_and_neighbours_kernel, dim3(ceil_div(b, 4)), dim3(256), 0, as_stream(stream), v, rows, b, bits);
+  GSS_LAUNCH_CHECK("mark_rows_and_neighbours_kernel");
+  return GSS_OK;
+}
 
 int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
               float *dp, float *gx_out, void *stream) {

@@ -93,6 +93,13 @@ class GssEngine:
         _lib.check(self.lib.gss_plan_step(self.handle, idx32.data_ptr() + 4 * offset, b, float(beta), _lib.current_stream()),
                    "gss_plan_step")
 
+    def step_lazy(self, idx32: torch.Tensor, beta: float, count=None, offset=0):
+        """step() with the top layer evaluated on the batch rows only (gss_plan_step_lazy): the same loss, gradients and parameters
+        bit for bit; self.emb is then valid on the batch rows only -- forward() recomputes all of it"""
+        b = int(count if count is not None else idx32.numel())
+        _lib.check(self.lib.gss_plan_step_lazy(self.handle, idx32.data_ptr() + 4 * offset, b, float(beta), _lib.current_stream()),
+                   "gss_plan_step_lazy")
+
     def gather_embeddings(self) -> torch.Tensor:
         """the full [N][d] embeddings in node order (a collective on a sharded plan; the plan's own tensor otherwise)"""
         if self.shard is None:

@@ -243,8 +243,12 @@ def main(argv=None):
                     print(f"selected beta:{beta_score}")
                 engine.loss_backward(idx32, beta_score, count=b, offset=off)   # train.py:175,183
                 engine.adam()                                 # train.py:184
+            elif itr == args.epochs - 1 and batch_id == len(sizes) - 1:
+                engine.step(idx32, beta_score, count=b, offset=off)          # the run's last forward: all rows (they are written out)
             else:
-                engine.step(idx32, beta_score, count=b, offset=off)
+                # every other step reads B rows of its top layer (the loss, train.py:175): gss_plan_step_lazy computes those -- the
+                # same loss, gradients and parameters bit for bit (the reference computes all N rows every step, train.py:158-161)
+                engine.step_lazy(idx32, beta_score, count=b, offset=off)
             off += b
             step_no += 1
         itr += 1

@@ -345,6 +345,13 @@ int gss_plan_backward(gss_plan *p, const int32_t *rows, int32_t b, const float *
 int gss_plan_adam(gss_plan *p, void *stream);
 /* forward + loss + backward + Adam = one iteration of train.py:155-184 */
 int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream);
+/* gss_plan_step with the top layer evaluated on the b batch rows only -- the rows of it that the loss (model.py:216-221) and the
+ * backward pass read; the reference computes all N every step (train.py:158-161) and reads B of them.  Loss, gradients and
+ * parameters equal gss_plan_step's bit for bit (a computed row takes the same path through the same kernels).  Afterwards io.emb
+ * holds the step's embeddings on the batch rows only: call gss_plan_forward when all of them are wanted (the beta percentile of
+ * step 0, the embeddings that are written out).  Plans it does not apply to (one layer, shards, widths without the fused
+ * normalise epilogue) run the full step. */
+int gss_plan_step_lazy(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream);
 /* layer activations for parity tests: which 0 AX, 1 AM, 2 P of layer `layer` (0-based) */
 const float *gss_plan_activation(const gss_plan *p, int layer, int which);
 size_t gss_plan_device_bytes(const gss_plan *p);
