@@ -187,8 +187,8 @@ def main():
     ap.add_argument("--workload", default="whole_graph")
     ap.add_argument("--hidden-units", type=int, default=None)
     ap.add_argument("--cache-layer1", action="store_true", help="also report the step time with layer-1 SpMMs cached")
-    ap.add_argument("--lazy-top", action="store_true", help="also time gss_plan_step_lazy (the top layer on the batch rows only: the same loss, "
-                    "gradients and parameters bit for bit) and report it as `lazy_top`; `value` stays the full step")
+    ap.add_argument("--no-lazy-top", dest="lazy_top", action="store_false", help="do not also time gss_plan_step_lazy (the top layer on the "
+                    "batch rows only: the same loss, gradients and parameters bit for bit; reported as `lazy_top`, never part of `value`)")
     ap.add_argument("--pipeline", action="store_true", help="cross-step layer-1 software pipelining on a second HIP stream "
                                                              "(measured: no gain, off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
