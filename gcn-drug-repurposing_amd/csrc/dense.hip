@@ -461,6 +461,7 @@ int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const floa
 
 // last layer: P as usual, but the residual mix is row-normalised on the fly: e = normalize(p_prev + decay elu(p))
 bool dense_fwd_norm_available(int32_t d) { return g_gemm_variant >= 2 && (d == 128 || d == 64 || d == 32 || d == 16); }
+bool dense_row_list_available() { return g_gemm_variant >= 2; }   // the projection over a row list (gss_plan_step_lazy) is the LDS-staged kernel's
 
 int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
                    const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream, const int32_t *row_list) {

@@ -9,13 +9,14 @@ namespace gss {
 // wave normalises 64/LPR rows; the sum of squares is reduced with xor-shuffles inside the lane group.
 template <int VPL>
 __global__ __launch_bounds__(256) void rownorm_fwd_kernel(int n, int d4, int lpr_log2, const float *__restrict__ x,
-                                                          float *__restrict__ e, float *__restrict__ inv_den) {
+                                                          float *__restrict__ e, float *__restrict__ inv_den, const int32_t *__restrict__ rows) {
   const int lane = threadIdx.x & 63;
   const int lpr = 1 << lpr_log2;
   const int rpw = 64 >> lpr_log2;
   const int li = lane & (lpr - 1);
-  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + (lane >> lpr_log2);
-  const bool ok = row < n;
+  const int ri = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + (lane >> lpr_log2);
+  const bool ok = ri < n;
+  const int row = (ok && rows) ? rows[ri] : ri;   // a row list: the n listed rows of x / e / inv_den (gss_plan_step_lazy)
   float4 v[VPL];
   float ss = 0.f;
 #pragma unroll
@@ -235,7 +236,7 @@ static void row_geometry(int d, int &d4, int &lpr_log2, int &vpl) {
   vpl = d4 <= 64 ? 1 : d4 <= 128 ? 2 : 4;
 }
 
-int rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, void *stream) {
+int rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, void *stream, const int32_t *rows) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(n >= 0 && x && e && inv_den, "rownorm_fwd: null operand");
   if (n == 0) return GSS_OK;
@@ -245,11 +246,11 @@ int rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, 
   dim3 grid(ceil_div(n, rows_per_block)), block(256);
   hipStream_t st = as_stream(stream);
   if (vpl == 1)
-    hipLaunchKernelGGL((rownorm_fwd_kernel<1>), grid, block, 0, st, n, d4, lg, x, e, inv_den);
+    hipLaunchKernelGGL((rownorm_fwd_kernel<1>), grid, block, 0, st, n, d4, lg, x, e, inv_den, rows);
   else if (vpl == 2)
-    hipLaunchKernelGGL((rownorm_fwd_kernel<2>), grid, block, 0, st, n, d4, lg, x, e, inv_den);
+    hipLaunchKernelGGL((rownorm_fwd_kernel<2>), grid, block, 0, st, n, d4, lg, x, e, inv_den, rows);
   else
-    hipLaunchKernelGGL((rownorm_fwd_kernel<4>), grid, block, 0, st, n, d4, lg, x, e, inv_den);
+    hipLaunchKernelGGL((rownorm_fwd_kernel<4>), grid, block, 0, st, n, d4, lg, x, e, inv_den, rows);
   GSS_LAUNCH_CHECK("rownorm_fwd_kernel");
   return GSS_OK;
 }

@@ -47,6 +47,7 @@ int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const floa
               const float *b2, const float *p_prev, float decay, float *p, float *x_next, void *stream,
               const int32_t *row_list = nullptr);  // row_list: the n tile rows are node rows row_list[0..n) of every operand
 bool dense_fwd_norm_available(int32_t d);
+bool dense_row_list_available();
 int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
                    const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream,
                    const int32_t *row_list = nullptr);
@@ -67,7 +68,7 @@ int wgrad_slices_max(int32_t n_max, int32_t d);  // bound over every n in [1, n_
 int wgrad_reduce_adam(int32_t d, void *ws, int total_slices, int nslices, float *const grad[4], float *const param[4],
                       float *const m[4], float *const v[4], int32_t step, float lr, float beta1, float beta2, float eps, float *w1t,
                       float *w2t, int32_t *pos_clear, const int32_t *idx, int32_t b, void *stream);
-int rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, void *stream);
+int rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_den, void *stream, const int32_t *rows = nullptr);
 int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b, const float *e, const float *inv_den,
                     const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set, void *stream);
 // dst[rows[r]] += src[r] unless rows[r] < 0 or keep[r] == 0 (keep nullable); pos_clear != NULL: also pos_clear[pos_ids[r]] = -1

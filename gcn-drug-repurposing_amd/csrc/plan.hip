@@ -482,13 +482,15 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
       return dense_fwd_norm(D.n, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr, D.layer_decay,
                             p->p[l], p->emb, p->inv_den, stream);
     }
-    GSS_REQUIRE(!(lazy_rows && l == L - 1), "plan_forward: the batch-row top layer needs the fused normalise epilogue");
+
     float *xn = (l == L - 1) ? p->x_last : p->xin[l + 1];
-    if (int rc = dense_fwd(D.n, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr,
-                           D.layer_decay, p->p[l], xn, stream))
+    const bool listed = lazy_rows && l == L - 1;
+    if (int rc = dense_fwd(listed ? lazy_b : D.n, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr,
+                           D.layer_decay, p->p[l], xn, stream, listed ? lazy_rows : nullptr))
       return rc;
   }
   PROF(GSS_PROF_ROWNORM);
+  if (lazy_rows) return rownorm_fwd(lazy_b, D.d, p->x_last, p->emb, p->inv_den, stream, lazy_rows);
   return rownorm_fwd(D.n, D.d, p->x_last, p->emb, p->inv_den, stream);
 }
 
@@ -760,11 +762,11 @@ int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *
 // N - b rows are not read by anything inside a step.  A row that IS computed goes through the same segments, the same summation tree
 // and the same MFMA rows as in the full pass, so loss, gradients and parameters equal gss_plan_step's bit for bit; afterwards
 // io.emb holds this step's embeddings on the batch rows only (call gss_plan_forward for all of them).  Falls back to the full step
-// where the pieces it needs are absent (one layer, a sharded plan, a width without the fused normalise epilogue, spmm_variant 1).
+// where the pieces it needs are absent (one layer, a sharded plan, spmm_variant 1, gemm_variant 1).
 int gss_plan_step_lazy(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
   GSS_REQUIRE(p, "plan_step_lazy: null plan");
   const gss_plan_desc &D = p->desc;
-  const bool can = p->P == 1 && D.num_layers > 1 && spmm_sparse_available() && dense_fwd_norm_available(D.d) && !D.pipeline_layer1 && p->pos;
+  const bool can = p->P == 1 && D.num_layers > 1 && spmm_sparse_available() && dense_row_list_available() && !D.pipeline_layer1 && p->pos;
   return plan_step_impl(p, idx, b, beta, stream, can);
 }
 
