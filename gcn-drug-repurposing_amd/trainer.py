@@ -52,7 +52,9 @@ def build_parser():
     p.add_argument('--adj-file', type=str, default=None,
                    help="weighted edgelist ('u v w') or .sif adjacency over the nodes of --emb-file; replaces the kNN graph")
     p.add_argument('--out', type=str, default='graph_embs.txt', help='output file (reference: ./graph_embs.txt)')
-    p.add_argument('--cache-layer1', action='store_true', help="keep layer 1's two SpMM results across steps (inputs are constant)")
+    p.add_argument('--cache-layer1', dest='cache_layer1', action='store_true', default=True,
+                   help="keep layer 1's two SpMM results across steps (their inputs, A_hat and X, never change; bitwise neutral): the default")
+    p.add_argument('--no-cache-layer1', dest='cache_layer1', action='store_false', help="recompute them every step, as the reference does")
     p.add_argument('--batch-file', type=str, default=None, help='.npz with batches/batch_sizes to replay instead of sampling')
     p.add_argument('--log-loss', action='store_true', help='print the last loss of every epoch')
     p.add_argument('--checkpoint', default=None, help='write the training state (weights, Adam moments, step, beta, sampler RNG) '
@@ -136,7 +138,7 @@ def main(argv=None):
     # all but test-sized graphs go through the shard builder even on one GPU: it relabels the nodes hub-first for gather
     # locality (shards.build_shard: -2 % of a step at N = 30k, -30 % at 10M; invisible in the results)
     from .shards import RELABEL_MIN_NODES
-    shard_path = sharded or (n >= RELABEL_MIN_NODES and not args.cache_layer1)
+    shard_path = sharded or n >= RELABEL_MIN_NODES
     graph = None
     if not shard_path:
         graph = GssGraph(adj, device=dev, need_transpose=args.num_layers > 1)   # train.py:100-101
