@@ -35,3 +35,11 @@ for k in range(3):
     eng.step(idx, 0.25)
 pr = eng.profile_read()
 say("profile: " + ", ".join(f"{k} {v[0] / max(v[1], 1) * 1e3:.0f} us x{v[1]}" for k, v in pr.items() if v[1]))
+for k in range(2):
+    eng.step_lazy(idx, 0.25)
+eng.profile(True)
+for k in range(3):
+    eng.step_lazy(idx, 0.25)
+pr = eng.profile_read()
+say("lazy profile: " + ", ".join(f"{k} {v[0] / max(v[1], 1) * 1e3:.0f} us x{v[1]}" for k, v in pr.items() if v[1]))
+
