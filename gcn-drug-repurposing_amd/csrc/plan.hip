@@ -466,12 +466,11 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
         if (int rc = plan_halo(p, p->halo_a, m, stream)) return rc;
         if (l == 0) p->m0_ready = true;
       }
-      const bool lazy = lazy_l;
       {
         PROF(GSS_PROF_SPMM_FWD);
-        if (int rc = spmm_fwd(p->a, D.d, m, p->am[l], nullptr, nullptr, stream, lazy ? p->pos : nullptr)) return rc;
+        if (int rc = spmm_fwd(p->a, D.d, m, p->am[l], nullptr, nullptr, stream, lazy_l ? p->pos : nullptr)) return rc;
       }
-      if (l == 0 && !lazy) p->layer1_valid = true;
+      if (l == 0) p->layer1_valid = true;   // (the lazy top layer is never layer 1: gss_plan_step_lazy needs two layers)
     }
     PROF(GSS_PROF_DENSE_FWD);
     if (l == L - 1 && dense_fwd_norm_available(D.d)) {
