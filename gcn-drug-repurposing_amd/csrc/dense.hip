@@ -243,14 +243,16 @@ __device__ __forceinline__ XcdIds xcd_ids(int L, int n_spread, int n_share, bool
   return r;
 }
 
-template <int NT, int MT, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
+// WAVES = 1 (forward over a short row list, gss_plan_step_lazy's 2048 batch rows): one wave and 16 MT nodes per workgroup, so that the
+// few rows spread over 4 x as many CUs; a row's MFMA chain is the same, its result has the same bits
+template <int NT, int MT, int EPI, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BN = 16 * NT;
-  constexpr int BM = 64 * MT;              // nodes per workgroup (MT 16-node tiles per wave)
+  constexpr int BM = 16 * WAVES * MT;      // nodes per workgroup (MT 16-node tiles per wave)
   constexpr int XT = BM * 16;              // floats per X chunk tile
   constexpr int BUF = XT + BN * 16;        // floats per buffer
-  constexpr int WG = (NT + 3) / 4;         // W fragment blocks staged per wave
+  constexpr int WG = (NT + WAVES - 1) / WAVES;  // W fragment blocks staged per wave
   constexpr int G = MT + WG;               // DMA instructions per wave and chunk (uniform over waves)
   constexpr int NBUF = 4, PF = 3;          // chunks ci+1 .. ci+PF-1 stay in flight while chunk ci is consumed
   float *lds = reinterpret_cast<float *>(smem);
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
   const float *wsrc[2][WG];
   int wblk[WG];
 #pragma unroll
-  for (int i = 0; i < WG; ++i) wblk[i] = (w + 4 * i) % NT;
+  for (int i = 0; i < WG; ++i) wblk[i] = (w + WAVES * i) % NT;
 #pragma unroll
   for (int kh = 0; kh < 2; ++kh) {
     const float *in = kh ? g.in1 : g.in0;
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
     const float *wp = g.w[jh][kh];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      int node = min(g.n - 1, node_base + 16 * (w + 4 * i) + r);
+      int node = min(g.n - 1, node_base + 16 * (w + WAVES * i) + r);
       if (EPI != EPI_SPLIT && g.rows) node = g.rows[node];
       xsrc[kh][i] = in ? in + (size_t)node * ld + 4 * q : nullptr;
     }
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmArgs g) {
     const int off = (ci - (kh ? csplit : 0)) * 16;
     const unsigned buf = lds_base + (unsigned)((ci % NBUF) * BUF) * 4u;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) glds16(xsrc[kh][i] + off, buf + (unsigned)((w + 4 * i) * 1024));
+    for (int i = 0; i < MT; ++i) glds16(xsrc[kh][i] + off, buf + (unsigned)((w + WAVES * i) * 1024));
 #pragma unroll
     for (int i = 0; i < WG; ++i) glds16(wsrc[kh][i] + off, buf + (unsigned)(XT * 4 + wblk[i] * 1024));
   };
@@ -396,6 +398,19 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
     // W-staging redundancy of small tiles costs more than that buys (measured, tools/gemm_bench.py), and so it does once
     // the grid is many waves of workgroups deep (d = 128: N = 1M 791 -> 753 us, N = 4M 3061 -> 2913 us with 128-node tiles)
     const int mt = g_gemm_variant == 3 ? 2 : g_gemm_variant == 4 ? 1 : ((d >= 256 || g.n >= 262144) ? 2 : 1);
+    if (EPI != EPI_SPLIT && g.rows && (int64_t)ceil_div(g.n, 64) * (g.J / (16 * nt)) < 256) {
+      // forward over a short row list: 16-node workgroups of one wave (see the kernel)
+      dim3 grid1(ceil_div(g.n, 16), g.J / (16 * nt));
+      const size_t lds1 = 4 * (size_t)(16 * 16 + 16 * nt * 16) * sizeof(float);
+      switch (nt) {
+        case 8: hipLaunchKernelGGL((gemm_nt_lds_kernel<8, 1, EPI, 1>), grid1, dim3(64), lds1, st, g); break;
+        case 4: hipLaunchKernelGGL((gemm_nt_lds_kernel<4, 1, EPI, 1>), grid1, dim3(64), lds1, st, g); break;
+        case 2: hipLaunchKernelGGL((gemm_nt_lds_kernel<2, 1, EPI, 1>), grid1, dim3(64), lds1, st, g); break;
+        default: hipLaunchKernelGGL((gemm_nt_lds_kernel<1, 1, EPI, 1>), grid1, dim3(64), lds1, st, g); break;
+      }
+      GSS_LAUNCH_CHECK("gemm_nt_lds_kernel (one wave)");
+      return GSS_OK;
+    }
     dim3 grid(ceil_div(g.n, 64 * mt), g.J / (16 * nt));
     const size_t lds = 4 * (size_t)(64 * mt * 16 + 16 * nt * 16) * sizeof(float);
 #define GSS_GEMM_CASE(NTV)                                                                              \
