@@ -124,16 +124,22 @@ __global__ void batch_bits_kernel(const int32_t *__restrict__ ids, int b, uint32
     bits[(unsigned)id >> 5] = 0u;  // every set bit of the word belongs to a member of this batch
 }
 
-// gss_plan_step_lazy, before the forward pass: node id -> row (node_map, relabelled graphs), the translated ids for the kernels that
-// index by row, and the batch-position map pos[row] = position (the row mask of the top layer, later the key of the sparse backward hop)
-__global__ void batch_prepare_kernel(const int32_t *__restrict__ idx, int b, const int32_t *__restrict__ node_map, int32_t *__restrict__ rows_out,
-                                     int32_t *__restrict__ ids_out, int32_t *__restrict__ pos) {
+// gss_plan_step_lazy, before the forward pass: node id -> row (node_map, relabelled graphs) -> local row of this shard (lo, nl) /
+// position-map id (gid2op, or the local row) -- the translation loss.hip's gather_rows_mapped_kernel does in the full step -- and the
+// batch-position map pos[id] = position (on own rows it is the row mask of the top layer, later the key of the sparse backward hop)
+__global__ void batch_prepare_kernel(const int32_t *__restrict__ idx, int b, const int32_t *__restrict__ node_map, int lo, int nl,
+                                     const int32_t *__restrict__ gid2op, int32_t *__restrict__ rloc, int32_t *__restrict__ pid,
+                                     float *__restrict__ keep, int32_t *__restrict__ pos) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b) return;
   const int id = node_map ? node_map[idx[i]] : idx[i];
-  if (rows_out) rows_out[i] = id;
-  if (ids_out) ids_out[i] = id;
-  pos[id] = i;
+  const int rel = id - lo;
+  const bool mine = rel >= 0 && rel < nl;
+  const int op = gid2op ? gid2op[id] : (mine ? rel : -1);
+  if (rloc) rloc[i] = min(max(rel, 0), max(nl - 1, 0));
+  if (pid) pid[i] = op;
+  if (keep) keep[i] = mine ? 1.f : 0.f;
+  if (op >= 0) pos[op] = i;
 }
 
 __global__ void bits_fill_kernel(uint32_t *__restrict__ bits, long long first, long long last) {
@@ -321,10 +327,12 @@ int batch_bits(const int32_t *ids, int32_t b, uint32_t *bits, int set, void *str
   return GSS_OK;
 }
 
-int batch_prepare(const int32_t *idx, int32_t b, const int32_t *node_map, int32_t *rows_out, int32_t *ids_out, int32_t *pos, void *stream) {
-  GSS_REQUIRE(idx && pos && b >= 0, "batch_prepare: null operand");
+int batch_prepare(const int32_t *idx, int32_t b, const int32_t *node_map, int32_t lo, int32_t nl, const int32_t *gid2op, int32_t *rloc,
+                  int32_t *pid, float *keep, int32_t *pos, void *stream) {
+  GSS_REQUIRE(idx && pos && b >= 0 && nl >= 0, "batch_prepare: null operand");
   if (b == 0) return GSS_OK;
-  hipLaunchKernelGGL(batch_prepare_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, as_stream(stream), idx, b, node_map, rows_out, ids_out, pos);
+  hipLaunchKernelGGL(batch_prepare_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, as_stream(stream), idx, b, node_map, lo, nl, gid2op, rloc, pid,
+                     keep, pos);
   GSS_LAUNCH_CHECK("batch_prepare_kernel");
   return GSS_OK;
 }

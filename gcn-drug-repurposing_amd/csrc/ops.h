@@ -85,7 +85,8 @@ int batch_bits(const int32_t *ids, int32_t b, uint32_t *bits, int set, void *str
 bool spmm_sparse_available();
 int spmm_bwd2_sparse_res(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res_b,
                          const int32_t *pos_row, float *dp, float *gx_out, void *stream, const uint32_t *nzbits = nullptr);
-int batch_prepare(const int32_t *idx, int32_t b, const int32_t *node_map, int32_t *rows_out, int32_t *ids_out, int32_t *pos, void *stream);
+int batch_prepare(const int32_t *idx, int32_t b, const int32_t *node_map, int32_t lo, int32_t nl, const int32_t *gid2op, int32_t *rloc,
+                  int32_t *pid, float *keep, int32_t *pos, void *stream);
 // bits [first, last) of a bitmap := 1 (whole and partial words; other bits untouched)
 int bits_fill(uint32_t *bits, int64_t first, int64_t last, void *stream);
 int adam_step(int64_t count, float *param, const float *grad, float *m, float *v, int32_t step, float lr, float beta1,

@@ -761,11 +761,12 @@ int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *
 // N - b rows are not read by anything inside a step.  A row that IS computed goes through the same segments, the same summation tree
 // and the same MFMA rows as in the full pass, so loss, gradients and parameters equal gss_plan_step's bit for bit; afterwards
 // io.emb holds this step's embeddings on the batch rows only (call gss_plan_forward for all of them).  Falls back to the full step
-// where the pieces it needs are absent (one layer, a sharded plan, spmm_variant 1, gemm_variant 1).
+// where the pieces it needs are absent (one layer, spmm_variant 1, gemm_variant 1).  On a sharded plan every shard evaluates the
+// top layer on the batch rows it owns.
 int gss_plan_step_lazy(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
   GSS_REQUIRE(p, "plan_step_lazy: null plan");
   const gss_plan_desc &D = p->desc;
-  const bool can = p->P == 1 && D.num_layers > 1 && spmm_sparse_available() && dense_row_list_available() && !D.pipeline_layer1 && p->pos;
+  const bool can = D.num_layers > 1 && spmm_sparse_available() && dense_row_list_available() && !D.pipeline_layer1 && p->pos;
   return plan_step_impl(p, idx, b, beta, stream, can);
 }
 
@@ -774,12 +775,17 @@ static int plan_step_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta
   const bool pipe = p->desc.pipeline_layer1 && p->side && !p->prof_on && !p->desc.cache_layer1;
   if (lazy) {
     GSS_REQUIRE(idx && b >= 1 && b <= p->desc.max_batch, "plan_step_lazy: batch %d out of [1, %d]", b, p->desc.max_batch);
-    const bool mapped = p->desc.node_map != nullptr;
+    const bool mapped = plan_batch_mapped(p);   // a relabelled graph and / or a shard: translated ids in rloc / pid (/ keep)
     {
       PROF(GSS_PROF_ELEMENTWISE);
-      if (int rc = batch_prepare(idx, b, p->desc.node_map, mapped ? p->rloc : nullptr, mapped ? p->pid : nullptr, p->pos, stream)) return rc;
+      if (int rc = batch_prepare(idx, b, p->desc.node_map, p->lo, p->desc.n, p->gid2op_t, mapped ? p->rloc : nullptr, mapped ? p->pid : nullptr,
+                                 p->keep, p->pos, stream))
+        return rc;
     }
-    if (int rc = plan_forward_impl(p, stream, mapped ? p->rloc : idx, b)) return rc;
+    // a shard lists every batch member: those of other shards are clamped onto one of its rows, whose top-layer values are then
+    // recomputed from whatever that row's A_hat M holds -- nothing reads them (the batch rows the shard owns are in the list as
+    // themselves); an empty shard has no row to clamp onto and no top layer to evaluate
+    if (int rc = plan_forward_impl(p, stream, mapped ? p->rloc : idx, p->desc.n > 0 ? b : 0)) return rc;
   } else if (int rc = plan_forward_impl(p, stream)) {
     return rc;
   }

@@ -349,7 +349,8 @@ int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *
  * backward pass read; the reference computes all N every step (train.py:158-161) and reads B of them.  Loss, gradients and
  * parameters equal gss_plan_step's bit for bit (a computed row takes the same path through the same kernels).  Afterwards io.emb
  * holds the step's embeddings on the batch rows only: call gss_plan_forward when all of them are wanted (the beta percentile of
- * step 0, the embeddings that are written out).  Plans it does not apply to (one layer, shards) run the full step. */
+ * step 0, the embeddings that are written out).  On a sharded plan every shard evaluates the top layer on the batch rows it owns.
+ * One-layer plans run the full step. */
 int gss_plan_step_lazy(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream);
 /* layer activations for parity tests: which 0 AX, 1 AM, 2 P of layer `layer` (0-based) */
 const float *gss_plan_activation(const gss_plan *p, int layer, int which);

@@ -252,3 +252,42 @@ def test_nonzero_row_bitmaps_of_the_sparse_backward_change_nothing(world, L):
         np.testing.assert_array_equal(a["emb"], b["emb"])
         for x, y in zip(a["params"], b["params"]):
             np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("world,relabel", [(2, False), (3, True), (8, False)])
+def test_lazy_step_on_shards_equals_the_full_sharded_step(world, relabel):
+    """gss_plan_step_lazy on a node-range sharded plan: every shard evaluates the top layer on the batch rows it owns (the members of
+    other shards are clamped onto one of its rows, recomputed and read by nobody; an empty shard evaluates nothing).  Losses, parameters
+    and the embeddings of a full forward afterwards equal the full sharded step's bit for bit, over batches of changing size that
+    leave some shards without a member."""
+    from gcn_drug_repurposing_amd.dist import local_comms
+    from gcn_drug_repurposing_amd.shards import ScipySource, build_shard, shard_engine, shard_rows
+    from conftest import golden_params
+    g = load_golden("knn_n200_d16_L2" if world == 8 else "knn_n2000_d64_L3")
+    n, d, L = (int(v) for v in g["meta"])
+    adj, X, p0 = golden_csr(g, "A"), g["X"], golden_params(g, "init")
+    rng = np.random.RandomState(9)
+    batches = [rng.choice(n, size=s, replace=False).astype(np.int32) for s in (min(n, 150), 3, 1, 64, min(n, 200))]
+    kw = dict(num_layers=L, layer_decay=float(g["decay"]), alpha=float(g["alpha"]), lr=float(g["lr"]), max_batch=200)
+
+    def run(lazy):
+        comms = local_comms(world)
+
+        def fn(rank):
+            shard = build_shard(ScipySource(adj), comms[rank], need_transpose=True, device="cuda:0", relabel=relabel)
+            eng = shard_engine(shard, shard_rows(shard, X), p0, comms[rank], **kw)
+            losses = []
+            for idx in batches:
+                (eng.step_lazy if lazy else eng.step)(torch.from_numpy(idx).cuda(), float(g["beta"]))
+                losses.append(eng.loss.item())
+            eng.forward()
+            return dict(losses=losses, emb=eng.gather_embeddings().cpu().numpy(), params=[t.cpu().numpy().copy() for t in eng.params])
+
+        return _threaded(world, fn, comms)
+
+    full, lazy = run(False), run(True)
+    for a, b in zip(full, lazy):
+        assert a["losses"] == b["losses"]
+        np.testing.assert_array_equal(a["emb"], b["emb"])
+        for x, y in zip(a["params"], b["params"]):
+            np.testing.assert_array_equal(x, y)
