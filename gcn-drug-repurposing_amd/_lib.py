@@ -69,6 +69,7 @@ SIGNATURES = {
     "gss_dense_bwd_weight": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "gss_rownorm_fwd": (C.c_int, [_I32, _I32, _P, _P, _P, _P]),
     "gss_loss_workspace_bytes": (_SZ, [_I32, _I32]),
+    "gss_loss_workspace_bytes_max": (_SZ, [_I32, _I32]),
     "gss_loss_fwd_bwd": (C.c_int, [_I32, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "gss_rownorm_elu_bwd": (C.c_int, [_I32, _P, _P, _I32, _P, _P, _P, _F, _P, _P, _P]),
     "gss_scatter_add_rows": (C.c_int, [_I32, _P, _P, _I32, _P, _P]),

@@ -13,6 +13,8 @@
 // partial dE tiles are tree-reduced in LDS and the grid.y partials are summed by loss_finish_kernel.
 //
 // Roofline: MFMA fp32.  flops = 2 B^2 d (S) + 2 B^2 d (G E) = 4 B^2 d, S tiles computed once.
+#include <algorithm>
+
 #include "ops.h"
 
 namespace gss {
@@ -357,6 +359,18 @@ size_t loss_workspace_bytes(int32_t b, int32_t d) {
   return de + (sizeof(double) * (size_t)ni * js + 15) / 16 * 16 + sizeof(float) * (size_t)b * d;
 }
 
+// The workspace is NOT monotone in b: the number of j slabs grows as the i tiles get fewer (B = 2048 -> 128 tiles x 2 slabs, 3 B d floats;
+// B = 2032 -> 127 x 3, 4 B d), so a plan sized for max_batch alone is too small for the shorter last batch of an epoch.  Upper bound over
+// every b in [1, b_max]: within one tile count the largest b needs the most, so one candidate per tile count.
+size_t loss_workspace_bytes_max(int32_t b_max, int32_t d) {
+  size_t worst = 0;
+  for (int ni = 1; ni <= ceil_div(b_max, 16); ++ni) {
+    const int b = std::min(16 * ni, (int)b_max);
+    worst = std::max(worst, loss_workspace_bytes(b, d));
+  }
+  return worst;
+}
+
 struct LossLaunch {
   int ni, js, nz, ng;
   float *de_part;
@@ -488,6 +502,7 @@ int loss_fused_gathered(int32_t d, int32_t b, float beta, float alpha, float *lo
 using namespace gss;
 extern "C" {
 size_t gss_loss_workspace_bytes(int32_t b, int32_t d) { return loss_workspace_bytes(b, d); }
+size_t gss_loss_workspace_bytes_max(int32_t b_max, int32_t d) { return b_max > 0 ? loss_workspace_bytes_max(b_max, d) : 0; }
 int gss_loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha,
                      float *loss_out, float *de_b, void *ws, void *stream) {
   return loss_fwd_bwd(n, d, e, idx, b, beta, alpha, loss_out, de_b, ws, stream);

@@ -110,6 +110,7 @@ int loss_fused_gathered(int32_t d, int32_t b, float beta, float alpha, float *lo
                         void *ws, void *stream);
 int transpose2(int32_t dim, const float *a, const float *b, float *at, float *bt, void *stream);
 size_t loss_workspace_bytes(int32_t b, int32_t d);
+size_t loss_workspace_bytes_max(int32_t b_max, int32_t d);   // enough for every batch of 1..b_max rows (the size is not monotone in b)
 int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha,
                  float *loss_out, float *de_b, void *ws, void *stream);
 }  // namespace gss

@@ -191,7 +191,7 @@ void carve(gss_plan *p, Carver &c) {
     p->adam_m[k] = c.take<float>(cnt[k]);
     p->adam_v[k] = c.take<float>(cnt[k]);
   }
-  p->loss_ws = c.take<char>(loss_workspace_bytes(D.max_batch, D.d));
+  p->loss_ws = c.take<char>(loss_workspace_bytes_max(D.max_batch, D.d));   // not monotone in the batch size: the worst case over 1..max_batch
   const int wg_total = wgrad_slices_max(D.max_batch, D.d) + (L - 1) * wgrad_slices(D.n, D.d);
   p->wgrad_ws = c.take<char>(sizeof(float) * (size_t)wg_total * ((size_t)D.d * 2 * D.d + D.d));
 }

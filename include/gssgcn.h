@@ -118,6 +118,9 @@ int gss_rownorm_fwd(int32_t n, int32_t d, const float *x, float *e, float *inv_d
  * de_b[b] = dLoss/dE_B[b] = sum_j (G_bj + G_jb) E_B[j], G = -alpha/B^2 (relu(S)-beta) 1[S>0].
  * S is never materialised.  idx: int32[B], unique.  ws: gss_loss_workspace_bytes(B, d) bytes. */
 size_t gss_loss_workspace_bytes(int32_t b, int32_t d);
+/* The size is NOT monotone in B (fewer row tiles get more column slabs: B = 2032 needs more than B = 2048): a caller that keeps one
+ * workspace for batches of up to b_max rows -- e.g. the shorter last batch of an epoch -- sizes it with this. */
+size_t gss_loss_workspace_bytes_max(int32_t b_max, int32_t d);
 int gss_loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta,
                      float alpha, float *loss_out, float *de_b, void *ws, void *stream);
 

@@ -65,3 +65,16 @@ def test_product_package_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
     for f in ("train.py",):
         assert "oracle" not in open(os.path.join(ROOT, f)).read()
+
+
+def test_workspace_bounds_cover_every_shorter_batch(lib):
+    """Host arithmetic only.  The loss workspace is not monotone in the batch size (fewer row tiles get more column slabs) and neither is
+    the weight-gradient slice count: a plan sized for max_batch alone would be too small for the shorter last batch
+    of an epoch.  gss_loss_workspace_bytes_max is what plans carve; it covers every batch of 1..b_max rows."""
+    for d in (64, 128, 256):
+        for b_max in (2048, 1034, 333, 17):
+            cap = lib.gss_loss_workspace_bytes_max(b_max, d)
+            sizes = [lib.gss_loss_workspace_bytes(b, d) for b in range(1, b_max + 1)]
+            assert cap == max(sizes)
+    # the case that motivated it: the tail batch of N = 29,960 at B = 2048, and one just below B
+    assert lib.gss_loss_workspace_bytes(2032, 128) > lib.gss_loss_workspace_bytes(2048, 128)
