@@ -30,6 +30,7 @@ struct gss_plan {
   float *de_b, *dx_b, *dp_b, *gax_b, *gam_b;
   int32_t *pos;  // operand row of A_hat^T's column space -> batch position (-1 outside the batch), for the sparsity-aware backward SpMM
   uint32_t *posbits;  // bitmap of pos >= 0, kept only around the sparse backward SpMM and only for huge operands (else NULL)
+  std::vector<size_t> guard_off;   // slab offsets of the guards behind the carved buffers
   uint32_t *needbits; // huge operands only (else NULL): gss_plan_step_lazy -- the rows of the top layer's AX / M that anything reads (batch + neighbours)
   uint32_t *nzbits;   // huge operands only (else NULL): bit r set <=> row r of u (the top layer's A_hat^T operand) may be non-zero; written by the
                       // sparse hop, read by the hop after it (which then skips the zero rows); halo rows are always set
@@ -113,14 +114,23 @@ struct ProfScope {
 };
 #define PROF(cls) ProfScope prof_scope_##__LINE__(p, cls, stream)
 
+// Every carved buffer is followed by a 256-byte guard (kGuardByte everywhere, written once at creation).  No kernel may touch one:
+// gss_plan_check_guards reads them back -- a buffer sized for the wrong worst case shows up there instead of silently running into
+// its neighbour (what the loss workspace did until round 2)
+constexpr size_t kGuardBytes = 256;
+constexpr int kGuardByte = 0xA5;
 struct Carver {
   size_t off = 0;
   char *base = nullptr;
+  std::vector<size_t> *guards = nullptr;   // offsets of the guards, recorded by the carving pass
   template <typename T>
   T *take(size_t count) {
     off = (off + 255) / 256 * 256;
     T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
     off += sizeof(T) * count;
+    off = (off + 255) / 256 * 256;
+    if (guards) guards->push_back(off);
+    off += kGuardBytes;
     return p;
   }
 };
@@ -310,6 +320,7 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
   }
   Carver real;
   real.base = p->slab;
+  real.guards = &p->guard_off;
   carve(p, real);
   if (real.off != sizing.off) {  // the two passes must carve the same sequence (a condition that looked at a pointer would not)
     const size_t a_ = sizing.off, b_ = real.off;
@@ -341,6 +352,14 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
       (void)hipFree(p->slab);
       delete p;
       return fail(GSS_EHIP, "plan_create: hipMemset(pos) -> %s", hipGetErrorString(e));
+    }
+  }
+  for (size_t g : p->guard_off) {
+    e = hipMemset(p->slab + g, kGuardByte, kGuardBytes);
+    if (e != hipSuccess) {
+      (void)hipFree(p->slab);
+      delete p;
+      return fail(GSS_EHIP, "plan_create: hipMemset(guard) -> %s", hipGetErrorString(e));
     }
   }
   if (p->nzbits && p->rows_t > (size_t)desc->n) {
@@ -851,6 +870,20 @@ const float *gss_plan_activation(const gss_plan *p, int layer, int which) {
   return which == 0 ? p->ax[layer] : which == 1 ? p->am[layer] : which == 2 ? p->p[layer] : nullptr;
 }
 size_t gss_plan_device_bytes(const gss_plan *p) { return p ? p->slab_bytes : 0; }
+
+int gss_plan_check_guards(gss_plan *p) {
+  GSS_REQUIRE(p, "plan_check_guards: null plan");
+  GSS_HIP(hipDeviceSynchronize());
+  std::vector<unsigned char> host(kGuardBytes);
+  for (size_t k = 0; k < p->guard_off.size(); ++k) {
+    GSS_HIP(hipMemcpy(host.data(), p->slab + p->guard_off[k], kGuardBytes, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < kGuardBytes; ++i)
+      if (host[i] != (unsigned char)kGuardByte)
+        return fail(GSS_EINVAL, "plan_check_guards: the guard behind carved buffer %zu (slab offset %zu) was overwritten at byte %zu", k,
+                    p->guard_off[k], i);
+  }
+  return GSS_OK;
+}
 void gss_plan_set_step(gss_plan *p, int32_t step) {
   if (!p) return;
   p->step = step;

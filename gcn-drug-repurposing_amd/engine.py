@@ -171,5 +171,9 @@ class GssEngine:
                 torch.cuda.current_stream().synchronize()   # src must outlive the copy
         self.lib.gss_plan_set_step(self.handle, int(sd["step"]))
 
+    def check_guards(self) -> None:
+        """raises if a kernel wrote behind one of the plan's buffers (gss_plan_check_guards; tests call it)"""
+        _lib.check(self.lib.gss_plan_check_guards(self.handle), "gss_plan_check_guards")
+
     def device_bytes(self) -> int:
         return int(self.lib.gss_plan_device_bytes(self.handle))

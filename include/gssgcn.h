@@ -358,6 +358,9 @@ int gss_plan_step_lazy(gss_plan *p, const int32_t *idx, int32_t b, float beta, v
 /* layer activations for parity tests: which 0 AX, 1 AM, 2 P of layer `layer` (0-based) */
 const float *gss_plan_activation(const gss_plan *p, int layer, int which);
 size_t gss_plan_device_bytes(const gss_plan *p);
+/* every buffer the plan carves from its slab is followed by a 256-byte guard no kernel may touch; this synchronises the device and
+ * verifies them all (GSS_EINVAL names the first one that was overwritten).  For tests. */
+int gss_plan_check_guards(gss_plan *p);
 /* set the 1-based Adam step counter (resume; also marks every buffer derived from the weights stale) / read it */
 void gss_plan_set_step(gss_plan *p, int32_t step);
 int32_t gss_plan_get_step(const gss_plan *p);

@@ -240,6 +240,7 @@ def test_nonzero_row_bitmaps_of_the_sparse_backward_change_nothing(world, L):
                     eng.step(torch.from_numpy(idx).cuda(), float(g["beta"]))
                     losses.append(eng.loss.item())
                 eng.forward()
+                eng.check_guards()
                 return dict(losses=losses, emb=eng.gather_embeddings().cpu().numpy(), params=[t.cpu().numpy().copy() for t in eng.params])
 
             return _threaded(world, fn, comms)
@@ -281,6 +282,7 @@ def test_lazy_step_on_shards_equals_the_full_sharded_step(world, relabel):
                 (eng.step_lazy if lazy else eng.step)(torch.from_numpy(idx).cuda(), float(g["beta"]))
                 losses.append(eng.loss.item())
             eng.forward()
+            eng.check_guards()
             return dict(losses=losses, emb=eng.gather_embeddings().cpu().numpy(), params=[t.cpu().numpy().copy() for t in eng.params])
 
         return _threaded(world, fn, comms)
