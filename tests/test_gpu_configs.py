@@ -105,6 +105,7 @@ def test_config3_full_size_step_matches_cpu_port(config3):
     eng, _ = _single_gpu(c)
     w0 = eng.params[0].clone()
     eng.step(torch.from_numpy(c["idx"].astype(np.int32)).cuda(), BETA)
+    eng.check_guards()
     assert eng.loss.item() == loss.item()
     assert 0 < (eng.params[0] - w0).abs().max().item() < 2.5 * LR
 
@@ -153,7 +154,9 @@ def test_config4_sharded_plan_equals_single_gpu_plan(config3, world):
         res = dict(emb=eng.gather_embeddings().cpu().numpy(), loss=eng.loss.item(), grads=[g.cpu().numpy() for g in eng.grads],
                    rows=eng.n, bounds=eng.part.bounds.copy())
         eng.adam()
+        eng.check_guards()
         eng.step(t, BETA)                      # the fused step with its grouped gradient all-reduce
+        eng.check_guards()
         res["loss2"] = eng.loss.item()
         res["w1"] = eng.params[0].cpu().numpy()
         return res
@@ -301,6 +304,7 @@ def test_config2_downstream_auc_with_the_real_drug_indication_pairs():
     cpu = TorchCpuPath(O.to_fp32_csr(a_hat), X, p, L, DECAY, ALPHA, LR)
     for idx in batches:
         eng.step(torch.from_numpy(idx.astype(np.int32)).cuda(), beta)
+        eng.check_guards()
         emb_cpu, loss_cpu = cpu.step(idx.astype(np.int64), beta)
     emb_gpu = eng.emb.cpu().numpy()                                      # the last forward, as train.py:193 writes it
     assert abs(eng.loss.item() - loss_cpu) < 2e-4 * abs(loss_cpu)

@@ -168,6 +168,7 @@ def test_native_sharded_plan_other_depths_and_layer1_cache(world, L, cache):
                 out = []
                 for idx in batches:
                     eng.step(torch.from_numpy(idx.astype(np.int32)).cuda(), 0.3)
+                    eng.check_guards()
                     out.append((eng.loss.item(), eng.gather_embeddings().cpu().numpy()))
                 results[rank] = out
         except Exception as e:  # noqa: BLE001
