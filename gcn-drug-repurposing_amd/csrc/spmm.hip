@@ -389,6 +389,9 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
       }
       continue;
     }
+    // Measured dead end (round 2): broadcasting the entries of a 16-lane group with DPP (v_mov_b32_dpp row_newbcast:k, loop fully
+    // unrolled) instead of ds_bpermute: 32.3 vs 32.9 us in a kernel that carried both paths, 31.4 us for this one alone -- the LDS
+    // crossbar is not what the gather loop waits for.
     // kFly row gathers in flight per lane group.  Measured at config 2 (d = 128): 16 -> 44.1 us, 8 -> 39.5 us,
     // 4 -> 36.2 us, 2 -> 37.7 us.  Deeper queues only add L2 thrash; at 4 the kernel needs 48 VGPRs, so two
     // 1024-thread workgroups share a CU (32 waves) instead of one.
