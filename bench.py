@@ -372,41 +372,44 @@ def main():
 
     lazy_top = None
     if args.lazy_top and world == 1 and hasattr(engine, "step_lazy"):
-        # opt-in extra: the same steps through gss_plan_step_lazy (NOT the reported value: the reference's step computes all N rows of
-        # the top layer; this one computes the B rows anything reads).  Same batches, timed the same way.
-        def run_lazy(lo, hi):
-            for s in range(lo, hi):
-                engine.step_lazy(idx_all, beta, count=int(offs[s + 1] - offs[s]), offset=int(offs[s]))
-        run_lazy(0, args.warmup)
-        reps = max(1, int(np.ceil(args.min_time / max(elapsed, 1e-6)))) if args.min_time > 0 else 1
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            run_lazy(args.warmup, args.warmup + args.steps)
-        barrier()
-        lz = (time.perf_counter() - t1) / (reps * args.steps)
-        trainer_ms = None
-        if not from_source and not sharded and shard is not None:
-            # what train.py runs: lazy steps on a plan that also keeps layer 1's two SpMM results (their inputs, A_hat and X, are
-            # constants; tests: bitwise neutral).  A second plan over the same shard.
-            eng2 = shard_engine(shard, x_rows, params_host, comm, num_layers=L, layer_decay=decay, alpha=alpha, lr=lr, max_batch=B,
-                                cache_layer1=True)
-            def run2(lo, hi):
+        try:
+            # opt-in extra: the same steps through gss_plan_step_lazy (NOT the reported value: the reference's step computes all N rows of
+            # the top layer; this one computes the B rows anything reads).  Same batches, timed the same way.
+            def run_lazy(lo, hi):
                 for s in range(lo, hi):
-                    eng2.step_lazy(idx_all, beta, count=int(offs[s + 1] - offs[s]), offset=int(offs[s]))
-            run2(0, args.warmup)
+                    engine.step_lazy(idx_all, beta, count=int(offs[s + 1] - offs[s]), offset=int(offs[s]))
+            run_lazy(0, args.warmup)
+            reps = max(1, int(np.ceil(args.min_time / max(elapsed, 1e-6)))) if args.min_time > 0 else 1
             barrier()
-            t2 = time.perf_counter()
+            t1 = time.perf_counter()
             for _ in range(reps):
-                run2(args.warmup, args.warmup + args.steps)
+                run_lazy(args.warmup, args.warmup + args.steps)
             barrier()
-            trainer_ms = (time.perf_counter() - t2) / (reps * args.steps) * 1e3
-            del eng2
-        lazy_top = {"ms_per_step": lz * 1e3, "ms_per_step_with_layer1_kept": trainer_ms, "steps": reps * args.steps,
-                    "final_loss": float(engine.loss.item()),
-                    "note": "gss_plan_step_lazy: top layer's A_hat M / projection / ELU / normalise on the batch rows only; loss, gradients "
-                            "and parameters bit-identical to the full step (tests/test_gpu_train.py); not part of `value`.  ms_per_step_with_layer1_kept: the same "
-                            "on a plan that keeps layer 1's SpMM results (constant inputs) -- the step train.py runs"}
+            lz = (time.perf_counter() - t1) / (reps * args.steps)
+            trainer_ms = None
+            if not from_source and not sharded and shard is not None:
+                # what train.py runs: lazy steps on a plan that also keeps layer 1's two SpMM results (their inputs, A_hat and X, are
+                # constants; tests: bitwise neutral).  A second plan over the same shard.
+                eng2 = shard_engine(shard, x_rows, params_host, comm, num_layers=L, layer_decay=decay, alpha=alpha, lr=lr, max_batch=B,
+                                    cache_layer1=True)
+                def run2(lo, hi):
+                    for s in range(lo, hi):
+                        eng2.step_lazy(idx_all, beta, count=int(offs[s + 1] - offs[s]), offset=int(offs[s]))
+                run2(0, args.warmup)
+                barrier()
+                t2 = time.perf_counter()
+                for _ in range(reps):
+                    run2(args.warmup, args.warmup + args.steps)
+                barrier()
+                trainer_ms = (time.perf_counter() - t2) / (reps * args.steps) * 1e3
+                del eng2
+            lazy_top = {"ms_per_step": lz * 1e3, "ms_per_step_with_layer1_kept": trainer_ms, "steps": reps * args.steps,
+                        "final_loss": float(engine.loss.item()),
+                        "note": "gss_plan_step_lazy: top layer's A_hat M / projection / ELU / normalise on the batch rows only; loss, gradients "
+                                "and parameters bit-identical to the full step (tests/test_gpu_train.py); not part of `value`.  ms_per_step_with_layer1_kept: the same "
+                                "on a plan that keeps layer 1's SpMM results (constant inputs) -- the step train.py runs"}
+        except Exception as e:  # noqa: BLE001  (an extra must never cost the run its headline line)
+            lazy_top = {"error": repr(e)}
 
     spmm_per_step = 2 * L + 2 * (L - 1)
     ms_per_step = elapsed / args.steps * 1e3
