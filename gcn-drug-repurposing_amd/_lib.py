@@ -9,7 +9,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgssgcn.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -73,12 +73,14 @@ SIGNATURES = {
     "gss_loss_fwd_bwd": (C.c_int, [_I32, _I32, _P, _P, _I32, _F, _F, _P, _P, _P, _P]),
     "gss_rownorm_elu_bwd": (C.c_int, [_I32, _P, _P, _I32, _P, _P, _P, _F, _P, _P, _P]),
     "gss_scatter_add_rows": (C.c_int, [_I32, _P, _P, _I32, _P, _P]),
-    "gss_shard_batch_maps": (C.c_int, [_P, _I32, _I32, _I32, _P, _I32, _I32, _P, _P, _P, _P, _P, _P]),
     "gss_comm_unique_id": (C.c_int, [_P]),
     "gss_comm_create_rccl": (C.c_int, [C.POINTER(_P), _I32, _I32, _P]),
     "gss_comm_create_local": (C.c_int, [C.POINTER(_P), _I32]),
     "gss_comm_destroy": (None, [_P]),
     "gss_comm_abort": (None, [_P]),
+    "gss_comm_check": (C.c_int, [_P]),
+    "gss_comm_count": (C.c_int, [_P, C.POINTER(_I32)]),
+    "gss_comm_sync": (C.c_int, [_P, _P, _D]),
     "gss_comm_world": (_I32, [_P]),
     "gss_comm_rank": (_I32, [_P]),
     "gss_allgather_rows": (C.c_int, [_P, _I32, _I32, _P, _P, _P]),

@@ -14,10 +14,12 @@
 //     sharded plan can be run and checked at world 2..8 on a box with a single GPU; it is not a fast path.
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "ops.h"
@@ -31,30 +33,84 @@ namespace gss {
   } while (0)
 
 // ---- RCCL ------------------------------------------------------------------------------------------------
+// Error handling: RCCL reports a failed peer / transport asynchronously.  Every enqueue below ends with a poll of
+// ncclCommGetAsyncError; a failure aborts the communicator (ncclCommAbort: kernels already enqueued on the stream stop waiting for
+// the dead peer) and is returned to the caller, who exits non-zero -- a process that has touched the GPU never re-execs.  A
+// collective that hangs without an error (a rank that stopped calling: mismatched order, a crashed peer whose socket stays open)
+// is caught at the caller's synchronisation points by gss_comm_sync, which waits for the stream with a deadline and aborts.
 struct RcclComm final : gss_comm {
   ncclComm_t comm = nullptr;
+  std::atomic<bool> aborted{false};
   ~RcclComm() override {
     if (comm) (void)ncclCommDestroy(comm);
   }
-  int all_gather(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) override {
-    // in place when send == recv + rank * bytes_per_rank (RCCL detects it)
-    GSS_NCCL(ncclAllGather(send, recv, bytes_per_rank, ncclInt8, comm, st));
+  void abort() override {
+    if (aborted.exchange(true)) return;
+    if (comm) (void)ncclCommAbort(comm);   // frees the communicator
+    comm = nullptr;
+  }
+  int alive() const {
+    if (aborted.load() || !comm) return fail(GSS_ECOMM, "RCCL communicator of rank %d was aborted after an earlier failure", rank);
     return GSS_OK;
   }
+  int check_async() override {
+    if (int rc = alive()) return rc;
+    ncclResult_t st = ncclSuccess;
+    const ncclResult_t r = ncclCommGetAsyncError(comm, &st);
+    if (r == ncclSuccess && (st == ncclSuccess || st == ncclInProgress)) return GSS_OK;
+    const ncclResult_t bad = r != ncclSuccess ? r : st;
+    abort();
+    return fail(GSS_ECOMM, "RCCL asynchronous error on rank %d of %d: %s (communicator aborted)", rank, world, ncclGetErrorString(bad));
+  }
+  int count(int32_t *out) override {
+    if (int rc = alive()) return rc;
+    int c = 0;
+    GSS_NCCL(ncclCommCount(comm, &c));
+    *out = c;
+    return GSS_OK;
+  }
+  int sync(hipStream_t st, double timeout_s) override {
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    for (;;) {
+      const hipError_t q = hipStreamQuery(st);
+      if (q == hipSuccess) return check_async();
+      if (q != hipErrorNotReady) return fail(GSS_EHIP, "comm_sync: hipStreamQuery -> %s", hipGetErrorString(q));
+      if ((++spins & 63) == 0) {
+        if (int rc = check_async()) return rc;
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (timeout_s > 0 && el > timeout_s) {
+          abort();
+          return fail(GSS_ETIMEOUT, "comm_sync: rank %d of %d waited %.0f s for its stream (a peer stopped taking part in a collective?); "
+                      "communicator aborted", rank, world, el);
+        }
+      }
+      if (spins < 2000) std::this_thread::yield();
+      else std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 20 : 500));
+    }
+  }
+  int all_gather(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) override {
+    if (int rc = alive()) return rc;
+    // in place when send == recv + rank * bytes_per_rank (RCCL detects it)
+    GSS_NCCL(ncclAllGather(send, recv, bytes_per_rank, ncclInt8, comm, st));
+    return check_async();
+  }
   int all_reduce_sum(float *const *bufs, const size_t *counts, int nbuf, hipStream_t st) override {
+    if (int rc = alive()) return rc;
     // several tensors = one fused RCCL operation (one launch)
     if (nbuf > 1) GSS_NCCL(ncclGroupStart());
     for (int k = 0; k < nbuf; ++k) {
       const ncclResult_t r = ncclAllReduce(bufs[k], bufs[k], counts[k], ncclFloat, ncclSum, comm, st);
       if (r != ncclSuccess) {
         if (nbuf > 1) (void)ncclGroupEnd();
-        return fail(GSS_EHIP, "ncclAllReduce -> %s", ncclGetErrorString(r));
+        return fail(GSS_ECOMM, "ncclAllReduce -> %s", ncclGetErrorString(r));
       }
     }
     if (nbuf > 1) GSS_NCCL(ncclGroupEnd());
-    return GSS_OK;
+    return check_async();
   }
   int exchange_rows(const float *send, const int64_t *send_off, float *recv, const int64_t *recv_off, int d, hipStream_t st) override {
+    if (int rc = alive()) return rc;
     // halo exchange: one fused group of point-to-point transfers, each over the xGMI link of its pair; pairs with an empty
     // list are skipped
     GSS_NCCL(ncclGroupStart());
@@ -66,8 +122,8 @@ struct RcclComm final : gss_comm {
       if (nr > 0 && r == ncclSuccess) r = ncclRecv(recv + (size_t)recv_off[q] * d, (size_t)nr * d, ncclFloat, q, comm, st);
     }
     const ncclResult_t e = ncclGroupEnd();
-    if (r != ncclSuccess || e != ncclSuccess) return fail(GSS_EHIP, "halo exchange (ncclSend/ncclRecv group) -> %s", ncclGetErrorString(r != ncclSuccess ? r : e));
-    return GSS_OK;
+    if (r != ncclSuccess || e != ncclSuccess) return fail(GSS_ECOMM, "halo exchange (ncclSend/ncclRecv group) -> %s", ncclGetErrorString(r != ncclSuccess ? r : e));
+    return check_async();
   }
 };
 
@@ -119,6 +175,18 @@ __global__ __launch_bounds__(256) void local_sum_kernel(size_t count, int world,
 struct LocalComm final : gss_comm {
   std::shared_ptr<LocalShared> sh;
   void abort() override { sh->abort(); }
+  int check_async() override {
+    std::lock_guard<std::mutex> lk(sh->mu);
+    return sh->broken ? fail(GSS_ECOMM, "local comm: a peer rank failed or timed out") : GSS_OK;
+  }
+  int count(int32_t *out) override {
+    *out = world;
+    return GSS_OK;
+  }
+  int sync(hipStream_t st, double) override {   // every collective of this backend already waited behind a timed barrier
+    GSS_HIP(hipStreamSynchronize(st));
+    return check_async();
+  }
   float *tmp = nullptr;
   size_t tmp_floats = 0;
   ~LocalComm() override {
@@ -225,6 +293,18 @@ int gss_comm_create_local(gss_comm **out, int32_t world) {
 void gss_comm_destroy(gss_comm *c) { delete c; }
 void gss_comm_abort(gss_comm *c) {
   if (c) c->abort();
+}
+int gss_comm_check(gss_comm *c) {
+  GSS_REQUIRE(c, "comm_check: null communicator");
+  return c->check_async();
+}
+int gss_comm_count(gss_comm *c, int32_t *count_out) {
+  GSS_REQUIRE(c && count_out, "comm_count: null argument");
+  return c->count(count_out);
+}
+int gss_comm_sync(gss_comm *c, void *stream, double timeout_s) {
+  GSS_REQUIRE(c, "comm_sync: null communicator");
+  return c->sync(as_stream(stream), timeout_s);
 }
 int32_t gss_comm_world(const gss_comm *c) { return c ? c->world : 0; }
 int32_t gss_comm_rank(const gss_comm *c) { return c ? c->rank : -1; }

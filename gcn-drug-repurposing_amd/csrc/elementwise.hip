@@ -93,25 +93,6 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(int b, int d4, co
   st4(p, add4(ld4(p), ld4(src + i * 4)));
 }
 
-// ---- sharded trainer: index maps of one batch on one shard (dist.py ShardedEngine.loss_backward) ----
-__global__ void shard_batch_maps_kernel(const int32_t *__restrict__ idx, int b, int lo, int nl, const int64_t *__restrict__ bounds, int world,
-                                        int maxr, int32_t *__restrict__ rows_all, int32_t *__restrict__ rows_own, float *__restrict__ keep,
-                                        int32_t *__restrict__ pos_col, int32_t *__restrict__ pos_row) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= b) return;
-  const int id = idx[i];
-  const int rel = id - lo;
-  const bool mine = rel >= 0 && rel < nl;
-  rows_all[i] = min(max(rel, 0), max(nl - 1, 0));
-  rows_own[i] = mine ? rel : -1;
-  keep[i] = mine ? 1.f : 0.f;
-  int o = 0;
-  while (o + 1 < world && (int64_t)id >= bounds[o + 1]) ++o;
-  pos_col[(size_t)o * maxr + (id - (int)bounds[o])] = i;
-  if (mine) pos_row[rel] = i;
-}
-
-
 // bitmap companion of the batch-position map (spmm.hip SPMM_BWD1S): set the members' bits / zero their words
 __global__ void batch_bits_kernel(const int32_t *__restrict__ ids, int b, uint32_t *__restrict__ bits, int set) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -292,20 +273,6 @@ int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, const flo
   return GSS_OK;
 }
 
-int shard_batch_maps(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
-                     int32_t *rows_all, int32_t *rows_own, float *keep, int32_t *pos_col, int32_t *pos_row, void *stream) {
-  GSS_REQUIRE(b >= 0 && nl >= 0 && world >= 1 && maxr >= 1 && idx && bounds && rows_all && rows_own && keep && pos_col && pos_row,
-              "shard_batch_maps: bad argument");
-  hipStream_t st = as_stream(stream);
-  GSS_HIP(hipMemsetAsync(pos_col, 0xff, (size_t)world * maxr * sizeof(int32_t), st));  // -1
-  GSS_HIP(hipMemsetAsync(pos_row, 0xff, (size_t)(nl > 0 ? nl : 1) * sizeof(int32_t), st));
-  if (b == 0) return GSS_OK;
-  hipLaunchKernelGGL(shard_batch_maps_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, st, idx, b, lo, nl, bounds, world, maxr, rows_all, rows_own,
-                     keep, pos_col, pos_row);
-  GSS_LAUNCH_CHECK("shard_batch_maps_kernel");
-  return GSS_OK;
-}
-
 int adam_step(int64_t count, float *param, const float *grad, float *m, float *v, int32_t step, float lr, float beta1,
               float beta2, float eps, float *wt, int32_t dim, void *stream) {
   GSS_REQUIRE(count >= 0 && param && grad && m && v && step >= 1, "adam_step: bad argument (step is 1-based)");
@@ -402,10 +369,6 @@ int gss_rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_
 }
 int gss_scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, void *stream) {
   return scatter_add_rows(d, src, rows, nullptr, b, dst, nullptr, nullptr, stream);
-}
-int gss_shard_batch_maps(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
-                         int32_t *rows_all, int32_t *rows_own, float *keep, int32_t *pos_col, int32_t *pos_row, void *stream) {
-  return shard_batch_maps(idx, b, lo, nl, bounds, world, maxr, rows_all, rows_own, keep, pos_col, pos_row, stream);
 }
 int gss_adam_step(int64_t count, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int32_t step, float lr,
                   float beta1, float beta2, float eps, float *wt, int32_t dim, void *stream) {

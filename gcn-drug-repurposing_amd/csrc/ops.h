@@ -22,7 +22,12 @@ struct gss_csr {
 struct gss_comm {
   int world = 1, rank = 0;
   virtual ~gss_comm() {}
-  virtual void abort() {}  // local backend: release every rank blocked in a collective (they return an error)
+  // make every rank that is (or will be) blocked in a collective of this group return an error: the local backend releases its
+  // host barrier, RCCL calls ncclCommAbort (the communicator is unusable afterwards)
+  virtual void abort() = 0;
+  virtual int check_async() = 0;                        // GSS_ECOMM once the backend has seen a failure (RCCL: ncclCommGetAsyncError)
+  virtual int count(int32_t *out) = 0;                  // ranks the backend itself reports (RCCL: ncclCommCount)
+  virtual int sync(hipStream_t st, double timeout_s) = 0;  // wait for `st` while watching for errors; past the deadline: abort + GSS_ETIMEOUT
   // rank r's `bytes_per_rank` land at recv + r * bytes_per_rank; in place when send == recv + rank * bytes_per_rank
   virtual int all_gather(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) = 0;
   // in place, nbuf tensors as one fused operation; identical bits on every rank
@@ -75,8 +80,6 @@ int rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_t b,
 int scatter_add_rows(int32_t d, const float *src, const int32_t *rows, const float *keep, int32_t b, float *dst, int32_t *pos_clear,
                      const int32_t *pos_ids, void *stream);
 int pack_rows(int32_t d, const float *src, const int32_t *rows, int64_t n, float *out, void *stream);
-int shard_batch_maps(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
-                     int32_t *rows_all, int32_t *rows_own, float *keep, int32_t *pos_col, int32_t *pos_row, void *stream);
 int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,
                      const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream,
                      const uint32_t *posbits = nullptr, uint32_t *nzbits_out = nullptr, int skip_zero_rows = 0);

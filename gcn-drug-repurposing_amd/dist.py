@@ -2,23 +2,20 @@
 
 The reference is single-process, single-device (train.py:68,118-122); this is the multi-GPU design the north
 star asks for.  One process per GPU; rank p owns a contiguous, nnz-balanced range of rows of A_hat and A_hat^T
-(all columns) and the matching rows of every activation and gradient.  Per SpMM hop the dense operand is
-all-gathered over xGMI (RCCL); the weights are replicated, their gradients all-reduced; the loss needs the B
-batch rows of the embeddings, summed into a [B][d] buffer with one all-reduce.
+and the matching rows of every activation and gradient.  Before an SpMM hop the BOUNDARY rows of the dense operand
+(the rows of other shards this shard's entries reference) are fetched from their owners over xGMI by one grouped
+ncclSend / ncclRecv (gss_exchange_rows); the weights are replicated, their gradients all-reduced; the loss needs the B
+batch rows of the embeddings, summed into a [B][d] buffer with one all-reduce.  The step itself is C++
+(csrc/plan.hip, gss_plan_create_sharded): this module only prepares what the plan borrows -- partition, halo
+layout (Halo), descriptors (ShardLayout) -- and owns the communicator handle (Comm).
 
-Exchange layout: all-gathers land in a *padded* [P][max_rows][d] buffer (all_gather_into_tensor needs equal
-shard sizes), so the column ids of the local CSRs are remapped once to padded ids
-    col' = owner(col) * max_rows + (col - lo[owner(col)])
-and the SpMM kernels gather straight out of the receive buffer -- no compaction pass.
-
-`ShardedEngine` is written against two small interfaces so that its exchange logic can be tested without
-8 GPUs: a communicator (TorchComm = torch.distributed; ThreadComm = P threads in one process) and an op backend
-(HipOps = libgssgcn.so; the tests plug a numpy backend to run world_size-2 gloo on CPU).
+Everything here that talks to peers goes through the five methods of `Comm` (allgather_bytes, exchange_rows,
+all_reduce_sum_, sync, abort), so the same layout code runs over RCCL, over the in-process backend, and -- in
+tests/test_dist_cpu.py, with a gloo communicator and numpy kernels -- as separate processes on a box without a GPU.
 """
 from __future__ import annotations
 
 import ctypes as C
-import threading
 
 import numpy as np
 import scipy.sparse as sp
@@ -48,98 +45,20 @@ class Partition:
         self.parts = len(bounds) - 1
         self.n = int(bounds[-1])
         self.max_rows = int(np.diff(self.bounds).max())
-        # every shard is padded to a multiple of 4 rows only through max_rows; ids below are padded ids
 
     def owner(self, ids):
         return np.searchsorted(self.bounds, ids, side="right") - 1
 
-    def padded_id(self, ids):
-        ids = np.asarray(ids, dtype=np.int64)
-        o = self.owner(ids)
-        return o * self.max_rows + (ids - self.bounds[o])
-
     def rows(self, rank):
         return int(self.bounds[rank]), int(self.bounds[rank + 1])
-
-
-def shard_csr(a_hat, part: Partition, rank):
-    """rows [lo, hi) of a scipy CSR with padded column ids -> (indptr, indices, data)"""
-    lo, hi = part.rows(rank)
-    sub = sp.csr_matrix(a_hat[lo:hi])
-    sub.sort_indices()
-    return sub.indptr.astype(np.int32), part.padded_id(sub.indices).astype(np.int32), sub.data.astype(np.float32)
-
-
-# ---------------------------------------------------------------------------------------------------------
-# communicators
-# ---------------------------------------------------------------------------------------------------------
-class TorchComm:
-    """torch.distributed (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in CPU tests)"""
-
-    def __init__(self):
-        import torch.distributed as dist
-        self.dist = dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-
-    def all_gather_rows(self, src, dst_padded):
-        """src [max_rows, d] (rows beyond the shard are don't-care) -> dst [world * max_rows, d]"""
-        self.dist.all_gather_into_tensor(dst_padded, src)
-
-    def all_reduce_sum_(self, t):
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-
-    def barrier(self):
-        self.dist.barrier()
-
-
-class ThreadComm:
-    """P threads of one process as P ranks (tests: both 'ranks' may share one GPU)."""
-
-    class Shared:
-        def __init__(self, world):
-            self.world = world
-            self.barrier = threading.Barrier(world)
-            self.slots = [None] * world
-
-    def __init__(self, shared, rank):
-        self.shared, self.rank, self.world = shared, rank, shared.world
-
-    def _exchange(self, t):
-        if t.is_cuda:
-            torch.cuda.current_stream().synchronize()
-        self.shared.slots[self.rank] = t
-        self.shared.barrier.wait()
-        got = list(self.shared.slots)
-        return got
-
-    def all_gather_rows(self, src, dst_padded):
-        got = self._exchange(src)
-        m = src.shape[0]
-        for r, t in enumerate(got):
-            dst_padded[r * m:(r + 1) * m].copy_(t)
-        if dst_padded.is_cuda:
-            torch.cuda.current_stream().synchronize()
-        self.shared.barrier.wait()
-
-    def all_reduce_sum_(self, t):
-        got = self._exchange(t.clone())
-        acc = got[0].clone()
-        for o in got[1:]:
-            acc += o          # rank order: identical result on every rank
-        t.copy_(acc)
-        if t.is_cuda:
-            torch.cuda.current_stream().synchronize()
-        self.shared.barrier.wait()
-
-    def barrier(self):
-        self.shared.barrier.wait()
 
 
 # ---------------------------------------------------------------------------------------------------------
 # native communicators (include/gssgcn.h gss_comm_*) and the sharded plan
 # ---------------------------------------------------------------------------------------------------------
 class Comm:
-    """owner of one gss_comm handle"""
+    """owner of one gss_comm handle (RCCL, or the in-process backend); device tensors in, device tensors out, everything on
+    torch's current stream"""
 
     def __init__(self, handle, world, rank):
         self.handle, self.world, self.rank = handle, int(world), int(rank)
@@ -152,12 +71,44 @@ class Comm:
             self.handle = None
 
     def abort(self):
-        """in-process ranks: release the peers blocked in a collective (call from a rank that failed)"""
+        """release the peers blocked in a collective (call from a rank that failed): the in-process backend opens its host
+        barrier, RCCL calls ncclCommAbort -- the communicator is unusable afterwards"""
         if self.handle:
             _lib.load().gss_comm_abort(self.handle)
 
+    def check(self):
+        """raises GssError once the backend has seen a failure (ncclCommGetAsyncError)"""
+        _lib.check(_lib.load().gss_comm_check(self.handle), "gss_comm_check")
+
+    def count(self) -> int:
+        """the number of ranks the backend itself reports (ncclCommCount)"""
+        out = C.c_int32()
+        _lib.check(_lib.load().gss_comm_count(self.handle, C.byref(out)), "gss_comm_count")
+        return int(out.value)
+
+    def sync(self, timeout_s: float = 300.0):
+        """wait for torch's current stream; a stream that does not drain within timeout_s (a peer that stopped taking part) aborts
+        the communicator and raises instead of hanging"""
+        _lib.check(_lib.load().gss_comm_sync(self.handle, _lib.current_stream(), float(timeout_s)), "gss_comm_sync")
+
+    def allgather_bytes(self, src: torch.Tensor) -> torch.Tensor:
+        """every rank's `src` (same shape and dtype everywhere), concatenated in rank order -> [world * src.numel()]"""
+        src = src.contiguous()
+        dst = torch.empty(self.world * src.numel(), dtype=src.dtype, device=src.device)
+        _lib.check(_lib.load().gss_allgather_bytes(self.handle, src.data_ptr(), dst.data_ptr(), src.numel() * src.element_size(),
+                                                   _lib.current_stream()), "gss_allgather_bytes")
+        return dst
+
+    def exchange_rows(self, d, send: torch.Tensor, send_off, recv: torch.Tensor, recv_off):
+        """C1, boundary form (gss_exchange_rows): rows [send_off[q], send_off[q+1]) of `send` go to rank q, the rows rank q sends
+        land at rows [recv_off[q], recv_off[q+1]) of `recv`; rows are d 4-byte words; offsets are host int64 arrays"""
+        send_off = np.ascontiguousarray(send_off, dtype=np.int64)
+        recv_off = np.ascontiguousarray(recv_off, dtype=np.int64)
+        _lib.check(_lib.load().gss_exchange_rows(self.handle, int(d), send.data_ptr(), send_off.ctypes.data, recv.data_ptr(),
+                                                 recv_off.ctypes.data, _lib.current_stream()), "gss_exchange_rows")
+
     def all_gather_rows(self, src, dst_padded):
-        """C1: src [max_rows, d] -> dst_padded [world * max_rows, d] on torch's current stream"""
+        """C1, equal-count form: src [max_rows, d] -> dst_padded [world * max_rows, d]"""
         _lib.check(_lib.load().gss_allgather_rows(self.handle, src.shape[1], src.shape[0], src.data_ptr(), dst_padded.data_ptr(),
                                                   _lib.current_stream()), "gss_allgather_rows")
 
@@ -202,7 +153,7 @@ class _ShardGraph:
 
 
 def partition_for(a_hat, world):
-    """nnz-balanced node ranges over forward + backward entries (the same rule as ShardedEngine)"""
+    """nnz-balanced node ranges over forward + backward entries"""
     work = a_hat.indptr + sp.csr_matrix(a_hat.T).indptr
     return Partition(nnz_balanced_ranges(work, world))
 
@@ -233,26 +184,22 @@ class Halo:
 
     def exchange(self, comm: "Comm", device):
         """tell every owner which of its rows this shard reads (a collective over `comm`: counts by all-gather, the id lists
-        by gss_exchange_rows with one int32 per row)"""
+        by the boundary exchange itself with one int32 per row)"""
         P, rank = self.part.parts, self.rank
-        lib = _lib.load()
-        st = _lib.current_stream
         if P == 1:
             self.send_rows = torch.zeros(1, dtype=torch.int32, device=device)
             return self
         mine = torch.from_numpy(np.diff(self.recv_off).astype(np.int64)).to(device)            # [P]: rows I want from q
-        allc = torch.empty(P, P, dtype=torch.int64, device=device)
-        _lib.check(lib.gss_allgather_bytes(comm.handle, mine.data_ptr(), allc.data_ptr(), 8 * P, st()), "gss_allgather_bytes")
-        torch.cuda.current_stream().synchronize()
-        counts = allc.cpu().numpy()                                                            # counts[r][q]: r wants from q
+        allc = comm.allgather_bytes(mine)
+        comm.sync()
+        counts = allc.cpu().numpy().reshape(P, P)                                              # counts[r][q]: r wants from q
         self.send_off[1:] = np.cumsum(counts[:, rank])
         want = torch.from_numpy(self.remote.astype(np.int32)).to(device) if self.n_halo else torch.zeros(1, dtype=torch.int32, device=device)
         n_send = int(self.send_off[-1])
         got = torch.empty(max(n_send, 1), dtype=torch.int32, device=device)
         # my request list is grouped by owner = my recv layout; what I receive is grouped by requester = my send layout
-        _lib.check(lib.gss_exchange_rows(comm.handle, 1, want.data_ptr(), self.recv_off.ctypes.data, got.data_ptr(),
-                                         self.send_off.ctypes.data, st()), "gss_exchange_rows")
-        torch.cuda.current_stream().synchronize()
+        comm.exchange_rows(1, want, self.recv_off, got, self.send_off)
+        comm.sync()
         self.send_rows = (got - self.lo).contiguous()
         if n_send:
             r = self.send_rows[:n_send]
@@ -327,285 +274,3 @@ def sharded_plan_engine(adj, x_host, params_host, comm, num_layers=2, layer_deca
                     max_batch=max_batch or a_hat.shape[0], cache_layer1=cache_layer1, betas=betas, eps=eps, shard=layout, comm=comm)
     eng.global_nnz, eng.part, eng.layout = int(a_hat.nnz), part, layout
     return eng
-
-
-# ---------------------------------------------------------------------------------------------------------
-# op backend over the C ABI
-# ---------------------------------------------------------------------------------------------------------
-class HipOps:
-    """thin per-op wrappers over include/gssgcn.h; every tensor is a contiguous CUDA fp32/int32 tensor"""
-
-    def __init__(self, device):
-        self.lib = _lib.load()
-        self.device = torch.device(device)
-        self._ws = {}
-
-    def st(self):
-        return _lib.current_stream()
-
-    def empty(self, *shape, dtype=torch.float32):
-        return torch.empty(*shape, dtype=dtype, device=self.device)
-
-    def zeros(self, *shape, dtype=torch.float32):
-        return torch.zeros(*shape, dtype=dtype, device=self.device)
-
-    def tensor(self, a, dtype=None):
-        t = torch.from_numpy(np.ascontiguousarray(a))
-        return (t.to(dtype) if dtype is not None else t).to(self.device)
-
-    def csr(self, indptr, indices, data, n_rows, n_cols):
-        from .graph import DeviceCSR
-        return DeviceCSR(indptr, indices, data, n_rows, n_cols, self.device)
-
-    def spmm(self, csr, x_full, h=None):
-        d = x_full.shape[1]
-        y = self.empty(csr.n_rows, d)
-        m = self.empty(csr.n_rows, d) if h is not None else None
-        _lib.check(self.lib.gss_spmm(csr.handle, d, x_full.data_ptr(), y.data_ptr(), _lib.ptr(h), _lib.ptr(m), self.st()), "gss_spmm")
-        return y, m
-
-    def dense_fwd(self, ax, am, w, p_prev, decay):
-        n, d = ax.shape
-        p, xn = self.empty(n, d), self.empty(n, d)
-        _lib.check(self.lib.gss_dense_fwd(n, d, ax.data_ptr(), am.data_ptr(), w[0].data_ptr(), w[1].data_ptr(), w[2].data_ptr(),
-                                          w[3].data_ptr(), _lib.ptr(p_prev), float(decay), p.data_ptr(), xn.data_ptr(), self.st()),
-                   "gss_dense_fwd")
-        return p, xn
-
-    def rownorm_fwd(self, x):
-        n, d = x.shape
-        e, inv = self.empty(n, d), self.empty(n)
-        _lib.check(self.lib.gss_rownorm_fwd(n, d, x.data_ptr(), e.data_ptr(), inv.data_ptr(), self.st()), "gss_rownorm_fwd")
-        return e, inv
-
-    def loss_fwd_bwd(self, e_b, beta, alpha):
-        b, d = e_b.shape
-        idx = torch.arange(b, dtype=torch.int32, device=self.device)
-        loss, de = self.empty(1), self.empty(b, d)
-        ws = torch.empty(self.lib.gss_loss_workspace_bytes(b, d), dtype=torch.uint8, device=self.device)
-        _lib.check(self.lib.gss_loss_fwd_bwd(b, d, e_b.data_ptr(), idx.data_ptr(), b, float(beta), float(alpha), loss.data_ptr(),
-                                             de.data_ptr(), ws.data_ptr(), self.st()), "gss_loss_fwd_bwd")
-        return loss, de
-
-    def rownorm_elu_bwd(self, de_rows, rows, e, inv_den, p, c):
-        b, d = de_rows.shape
-        dx, dp = self.empty(b, d), self.empty(b, d)
-        if b:
-            _lib.check(self.lib.gss_rownorm_elu_bwd(d, de_rows.data_ptr(), rows.data_ptr(), b, e.data_ptr(), inv_den.data_ptr(),
-                                                    p.data_ptr(), float(c), dx.data_ptr(), dp.data_ptr(), self.st()), "gss_rownorm_elu_bwd")
-        return dx, dp
-
-    def wgrad(self, dp, ax, am, rows, grads, accumulate):
-        n, d = dp.shape
-        if n == 0:
-            if not accumulate:
-                for g in grads:
-                    g.zero_()
-            return
-        need = self.lib.gss_wgrad_workspace_bytes(n, d)
-        if self._ws.get("wgrad") is None or self._ws["wgrad"].numel() < need:
-            self._ws["wgrad"] = torch.empty(need, dtype=torch.uint8, device=self.device)   # grow-only
-        _lib.check(self.lib.gss_dense_bwd_weight(n, d, dp.data_ptr(), ax.data_ptr(), am.data_ptr(), _lib.ptr(rows), grads[0].data_ptr(),
-                                                 grads[2].data_ptr(), grads[1].data_ptr(), 1 if accumulate else 0,
-                                                 self._ws["wgrad"].data_ptr(), self.st()), "gss_dense_bwd_weight")
-        grads[3].copy_(grads[1])
-
-    def dgrad(self, dp, w1t, w2t):
-        n, d = dp.shape
-        gax, gam = self.empty(n, d), self.empty(n, d)
-        if n:
-            _lib.check(self.lib.gss_dense_bwd_input(n, d, dp.data_ptr(), w1t.data_ptr(), w2t.data_ptr(), None, gax.data_ptr(),
-                                                    gam.data_ptr(), self.st()), "gss_dense_bwd_input")
-        return gax, gam
-
-    def spmm_bwd1(self, at, gam_full, gax_local, x_in, ax):
-        d = x_in.shape[1]
-        u, t = self.empty(at.n_rows, d), self.empty(at.n_rows, d)
-        _lib.check(self.lib.gss_spmm_bwd1(at.handle, d, gam_full.data_ptr(), gax_local.data_ptr(), x_in.data_ptr(), ax.data_ptr(),
-                                          u.data_ptr(), t.data_ptr(), self.st()), "gss_spmm_bwd1")
-        return u, t
-
-    def spmm_bwd1_sparse(self, at, gam_b, gax_b, pos_col, pos_row, x_in, ax):
-        d = x_in.shape[1]
-        u, t = self.empty(at.n_rows, d), self.empty(at.n_rows, d)
-        _lib.check(self.lib.gss_spmm_bwd1_sparse(at.handle, d, gam_b.data_ptr(), gax_b.data_ptr(), pos_col.data_ptr(), pos_row.data_ptr(),
-                                                 x_in.data_ptr(), ax.data_ptr(), u.data_ptr(), t.data_ptr(), self.st()),
-                   "gss_spmm_bwd1_sparse")
-        return u, t
-
-    def spmm_bwd2(self, at, u_full, t, p, c, res, want_gx):
-        d = t.shape[1]
-        dp = self.empty(at.n_rows, d)
-        gx = self.empty(at.n_rows, d) if want_gx else None
-        _lib.check(self.lib.gss_spmm_bwd2(at.handle, d, u_full.data_ptr(), t.data_ptr(), p.data_ptr(), float(c), _lib.ptr(res),
-                                          dp.data_ptr(), _lib.ptr(gx), self.st()), "gss_spmm_bwd2")
-        return dp, gx
-
-    def scatter_add_rows(self, src, rows, dst):
-        b, d = src.shape
-        if b:
-            _lib.check(self.lib.gss_scatter_add_rows(d, src.data_ptr(), rows.data_ptr(), b, dst.data_ptr(), self.st()), "gss_scatter_add_rows")
-
-    def batch_maps(self, idx32, lo, nl, bounds_dev, world, maxr):
-        """index maps of one batch on this shard (gss_shard_batch_maps) -> rows_all, rows_own, keep [b,1], pos_col, pos_row"""
-        b = idx32.numel()
-        rows_all, rows_own = self.empty(b, dtype=torch.int32), self.empty(b, dtype=torch.int32)
-        keep = self.empty(b, 1)
-        pos_col, pos_row = self.empty(world * maxr, dtype=torch.int32), self.empty(max(nl, 1), dtype=torch.int32)
-        _lib.check(self.lib.gss_shard_batch_maps(idx32.data_ptr(), b, int(lo), int(nl), bounds_dev.data_ptr(), int(world), int(maxr),
-                                                 rows_all.data_ptr(), rows_own.data_ptr(), keep.data_ptr(), pos_col.data_ptr(),
-                                                 pos_row.data_ptr(), self.st()), "gss_shard_batch_maps")
-        return rows_all, rows_own, keep, pos_col, pos_row
-
-    def adam(self, params, grads, m, v, step, lr, betas, eps):
-        for k in range(4):
-            _lib.check(self.lib.gss_adam_step(params[k].numel(), params[k].data_ptr(), grads[k].data_ptr(), m[k].data_ptr(),
-                                              v[k].data_ptr(), step, float(lr), float(betas[0]), float(betas[1]), float(eps), None, 0,
-                                              self.st()), "gss_adam_step")
-
-
-# ---------------------------------------------------------------------------------------------------------
-# the sharded training step
-# ---------------------------------------------------------------------------------------------------------
-class ShardedEngine:
-    """One rank of the node-range-sharded trainer.  Same step semantics as GssEngine.step (train.py:158-184)."""
-
-    def __init__(self, adj, x_host, params_host, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4, max_batch=None,
-                 betas=(0.9, 0.999), eps=1e-8, comm=None, ops=None, device=None, a_hat=None):
-        self.comm = comm or TorchComm()
-        rank, world = self.comm.rank, self.comm.world
-        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.ops = ops or HipOps(dev)
-        n, d = x_host.shape
-        self.n, self.d, self.L = n, d, int(num_layers)
-        self.decay, self.alpha, self.lr, self.betas, self.eps = float(layer_decay), float(alpha), float(lr), betas, float(eps)
-        # A_hat: every rank normalises the (small) host matrix the same way; values as in preprocess_graph
-        if a_hat is None:
-            a_hat = self._normalize_host(adj)
-        a_hat = sp.csr_matrix(a_hat)
-        a_hat.sort_indices()
-        self.global_nnz = int(a_hat.nnz)
-        work = a_hat.indptr + sp.csr_matrix(a_hat.T).indptr      # forward + backward entries per row prefix
-        self.part = Partition(nnz_balanced_ranges(work, world))
-        self.lo, self.hi = self.part.rows(rank)
-        self.nl, self.maxr = self.hi - self.lo, self.part.max_rows
-        ops = self.ops
-        ip, ix, dv = shard_csr(a_hat, self.part, rank)
-        self.a = ops.csr(ip, ix, dv, self.nl, world * self.maxr)
-        self.at = None
-        if self.L > 1:
-            ip, ix, dv = shard_csr(sp.csr_matrix(a_hat.T), self.part, rank)
-            self.at = ops.csr(ip, ix, dv, self.nl, world * self.maxr)
-        self.x0 = ops.tensor(x_host[self.lo:self.hi].astype(np.float32))
-        self.params = [ops.tensor(params_host[k].astype(np.float32)) for k in ("W1", "b1", "W2", "b2")]
-        # the four gradients are views of one flat buffer: one all-reduce, no packing
-        self._grad_flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=self.params[0].device)
-        self.grads, o = [], 0
-        for p in self.params:
-            self.grads.append(self._grad_flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
-        self.m = [torch.zeros_like(p) for p in self.params]
-        self.v = [torch.zeros_like(p) for p in self.params]
-        self.step_no = 0
-        self.loss = ops.zeros(1)
-        self.emb = None
-        self._send = ops.zeros(self.maxr, d)                 # padded send buffer
-        self._full = [ops.empty(world * self.maxr, d) for _ in range(2)]
-        self._bounds_dev = ops.tensor(self.part.bounds, dtype=torch.int64)
-        self._x0_full = None
-
-    @staticmethod
-    def _normalize_host(adj):
-        # helpers/helper.py:82-89 in fp64, then the fp32 cast of :95 happens in shard_csr
-        adj = sp.csr_matrix(adj, dtype=np.float64)
-        a_ = adj + sp.eye(adj.shape[0], dtype=np.float64, format="csr")
-        rowsum = np.asarray(a_.sum(1)).reshape(-1)
-        dinv = sp.diags(np.power(rowsum, -0.5))
-        return sp.csr_matrix(a_.dot(dinv).transpose().dot(dinv).transpose())
-
-    # -- collectives ------------------------------------------------------------------------------------
-    def _gather(self, local, which=0):
-        """all-gather the local rows [nl, d] into the padded [world*maxr, d] receive buffer"""
-        self._send[:self.nl].copy_(local)
-        self.comm.all_gather_rows(self._send, self._full[which])
-        return self._full[which]
-
-    def _padded_ids(self, ids64):
-        o = torch.searchsorted(self._bounds_dev, ids64, right=True) - 1
-        return o * self.maxr + (ids64 - self._bounds_dev[o])
-
-    # -- one iteration ------------------------------------------------------------------------------------
-    def forward(self):
-        ops, L = self.ops, self.L
-        self.act = []
-        x, p_prev = self.x0, None
-        for l in range(L):
-            if l == 0:
-                if self._x0_full is None:                              # the input features never change: distribute them once
-                    self._x0_full = self._gather(x, 0).clone()
-                xf = self._x0_full
-            else:
-                xf = self._gather(x, 0)
-            ax, m = ops.spmm(self.a, xf, h=x)                          # model.py:163,168
-            mf = self._gather(m, 1)
-            am, _ = ops.spmm(self.a, mf)                               # model.py:169
-            p, xn = ops.dense_fwd(ax, am, self.params, p_prev, self.decay)   # model.py:165,170-173,201-203
-            self.act.append({"x": x, "ax": ax, "am": am, "p": p})
-            x, p_prev = xn, p
-        self.emb, self.inv_den = ops.rownorm_fwd(x)                    # model.py:205
-        return self.emb
-
-    def loss_backward(self, idx32, beta, count=None, offset=0):
-        """Fixed-shape on purpose: every rank handles all b batch rows, with the rows it does not own masked to zero
-        (a clamped row index, zero gradient), so nothing here depends on a device value and the host never waits for
-        the GPU inside a step."""
-        ops, L, d = self.ops, self.L, self.d
-        b = int(count if count is not None else idx32.numel())
-        rows_all, rows_own, keep, pos_col, pos_row = ops.batch_maps(idx32[offset:offset + b], self.lo, self.nl, self._bounds_dev,
-                                                                    self.comm.world, self.maxr)
-        # E_B on every rank: each rank contributes its rows, one all-reduce (model.py:216-217)
-        e_b = self.emb.index_select(0, rows_all.long()) * keep
-        self.comm.all_reduce_sum_(e_b)
-        loss, de_b = ops.loss_fwd_bwd(e_b, beta, self.alpha)           # model.py:218-221 (+ autograd); same on every rank
-        self.loss = loss
-        top = self.act[L - 1]
-        c_top = self.decay if L > 1 else 1.0
-        dx_b, dp_b = ops.rownorm_elu_bwd(de_b * keep, rows_all, self.emb, self.inv_den, top["p"], c_top)   # zero rows where not owned
-        ops.wgrad(dp_b, top["ax"], top["am"], rows_all, self.grads, accumulate=False)
-        if L > 1:
-            w1t, w2t = self.params[0].t().contiguous(), self.params[2].t().contiguous()
-            gax_b, gam_b = ops.dgrad(dp_b, w1t, w2t)                    # [b][d] in batch order, zero where not owned
-            both = torch.cat([gax_b, gam_b])
-            self.comm.all_reduce_sum_(both)                            # batch-row gradients of every rank
-            gax_b, gam_b = both[:b], both[b:]
-            u, t = ops.spmm_bwd1_sparse(self.at, gam_b, gax_b, pos_col, pos_row, top["x"], top["ax"])
-            gx_prev = None       # g_x(lp + 2) as a dense local tensor, once lp + 2 <= L - 1
-            for lp in range(L - 2, -1, -1):
-                lay = self.act[lp]
-                c = 1.0 if lp == 0 else self.decay
-                uf = self._gather(u, 0)
-                dp, gx = ops.spmm_bwd2(self.at, uf, t, lay["p"], c, gx_prev if lp + 2 <= L - 1 else None, want_gx=lp >= 1)
-                if lp + 2 == L:
-                    ops.scatter_add_rows(dx_b, rows_own, dp)
-                ops.wgrad(dp, lay["ax"], lay["am"], None, self.grads, accumulate=True)
-                if lp >= 1:
-                    gax, gam = ops.dgrad(dp, w1t, w2t)
-                    gf = self._gather(gam, 1)
-                    u, t = ops.spmm_bwd1(self.at, gf, gax, lay["x"], lay["ax"])
-                gx_prev = gx
-        self.comm.all_reduce_sum_(self._grad_flat)                     # C2: 2 (d^2 + d) floats
-
-    def adam(self):
-        self.step_no += 1
-        self.ops.adam(self.params, self.grads, self.m, self.v, self.step_no, self.lr, self.betas, self.eps)
-
-    def step(self, idx32, beta, count=None, offset=0):
-        self.forward()
-        self.loss_backward(idx32, beta, count, offset)
-        self.adam()
-
-    def gather_embeddings(self):
-        """full [N][d] embeddings on every rank (row order == node order)"""
-        full = self._gather(self.emb, 0)
-        out = [full[r * self.maxr: r * self.maxr + (self.part.rows(r)[1] - self.part.rows(r)[0])] for r in range(self.comm.world)]
-        return torch.cat(out)

@@ -31,10 +31,8 @@ def allgather_host(comm: Comm, arr: np.ndarray, device) -> np.ndarray:
     if comm.world == 1:
         return arr[None].copy()
     src = torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(device)
-    dst = torch.empty(comm.world * src.numel(), dtype=torch.uint8, device=device)
-    _lib.check(_lib.load().gss_allgather_bytes(comm.handle, src.data_ptr(), dst.data_ptr(), src.numel(), _lib.current_stream()),
-               "gss_allgather_bytes")
-    torch.cuda.current_stream().synchronize()
+    dst = comm.allgather_bytes(src)
+    comm.sync()
     return dst.cpu().numpy().view(arr.dtype).reshape((comm.world,) + arr.shape)
 
 
@@ -47,10 +45,36 @@ def allgather_ranges(comm: Comm, local: torch.Tensor, bounds, device) -> torch.T
     maxr = int(max(1, sizes.max()))
     pad = torch.zeros(maxr, dtype=local.dtype, device=device)
     pad[:local.numel()] = local
-    out = torch.empty(P * maxr, dtype=local.dtype, device=device)
-    _lib.check(_lib.load().gss_allgather_bytes(comm.handle, pad.data_ptr(), out.data_ptr(), maxr * local.element_size(), _lib.current_stream()),
-               "gss_allgather_bytes")
+    out = comm.allgather_bytes(pad)
     return torch.cat([out[r * maxr: r * maxr + int(sizes[r])] for r in range(P)])
+
+
+class NativeShardOps:
+    """the device side of build_shard: libgssgcn.so kernels and CSR handles.  (tests/cpu_ops.py has the numpy stand-in with
+    which tests/test_dist_cpu.py drives build_shard in gloo processes on a box without a GPU.)"""
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    def rowsum_dinv(self, nl, rowptr, val, dev):
+        dinv = torch.empty(max(nl, 1), dtype=torch.float64, device=dev)
+        rowsum = torch.empty(max(nl, 1), dtype=torch.float64, device=dev)
+        _lib.check(self.lib.gss_rowsum_dinv(nl, rowptr.data_ptr(), _lib.ptr(val), dinv.data_ptr(), rowsum.data_ptr(), _lib.current_stream()),
+                   "gss_rowsum_dinv")
+        return dinv, rowsum
+
+    def scale_adj(self, nl, lo, rowptr, col, val, dinv, transposed, dev):
+        val32 = torch.empty(max(col.numel(), 1), dtype=torch.float32, device=dev)
+        _lib.check(self.lib.gss_scale_adj_shard(nl, lo, rowptr.data_ptr(), _lib.ptr(col), _lib.ptr(val), dinv.data_ptr(), transposed,
+                                                val32.data_ptr(), _lib.current_stream()), "gss_scale_adj_shard")
+        return val32
+
+    def csr(self, rowptr_host, col_local, val32, n_rows, n_cols, dev):
+        from .graph import DeviceCSR
+        return DeviceCSR(rowptr_host, col_local, val32, n_rows, n_cols, dev)
+
+    def set_hot(self, csr, own_hot, halo_begin, halo_end):
+        _lib.check(self.lib.gss_csr_set_hot(csr.handle, own_hot, halo_begin, halo_end), "gss_csr_set_hot")
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -301,15 +325,14 @@ ROW_WEIGHT = 12      # what a row costs besides its stored entries (dense projec
                      # 0.064 ns per entry visit, 3 visits per entry)
 
 
-def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="auto", row_weight=ROW_WEIGHT) -> Shard:
+def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="auto", row_weight=ROW_WEIGHT, ops=None) -> Shard:
     """relabel: True / False / "auto" (hub-first node order when the graph has >= RELABEL_MIN_NODES nodes; the non-temporal
     treatment of the cold rows additionally needs an operand far beyond the caches, gss_csr_set_hot).  Relabelling is invisible in
     the results: a row's entries keep their original
     order, so every sum is taken in the same order, batches name original ids (gss_plan_desc.node_map) and
-    GssEngine.gather_embeddings returns original order."""
-    from .graph import DeviceCSR
+    GssEngine.gather_embeddings returns original order.  ops: the device side (NativeShardOps unless a test plugs its own)."""
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-    lib = _lib.load()
+    ops = ops or NativeShardOps()
     P, rank = comm.world, comm.rank
     work = np.asarray(source.work(comm, dev), dtype=np.int64)
     n = len(work)
@@ -322,28 +345,23 @@ def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="a
     part = Partition(nnz_balanced_ranges(np.concatenate([[0], np.cumsum(work + max(0, int(row_weight) - 1))]), P))
     lo, hi = part.rows(rank)
     nl = hi - lo
-    st = _lib.current_stream
 
     rowptr, col, val = source.rows(lo, hi, dev, relabel=rl)
-    dinv_local = torch.empty(max(nl, 1), dtype=torch.float64, device=dev)
-    rowsum = torch.empty(max(nl, 1), dtype=torch.float64, device=dev)
-    _lib.check(lib.gss_rowsum_dinv(nl, rowptr.data_ptr(), _lib.ptr(val), dinv_local.data_ptr(), rowsum.data_ptr(), st()), "gss_rowsum_dinv")
+    dinv_local, rowsum = ops.rowsum_dinv(nl, rowptr, val, dev)
     dinv = allgather_ranges(comm, dinv_local[:nl], part.bounds, dev).contiguous()            # D^-1/2 of every node
 
     def finish(rowptr, col, val, transposed):
-        val32 = torch.empty(max(col.numel(), 1), dtype=torch.float32, device=dev)
-        _lib.check(lib.gss_scale_adj_shard(nl, lo, rowptr.data_ptr(), _lib.ptr(col), _lib.ptr(val), dinv.data_ptr(), transposed,
-                                           val32.data_ptr(), st()), "gss_scale_adj_shard")
+        val32 = ops.scale_adj(nl, lo, rowptr, col, val, dinv, transposed, dev)
         uniq = torch.unique(col).cpu().numpy() if col.numel() else np.zeros(0, np.int64)
         halo = Halo(None, part, rank, uniq=uniq).exchange(comm, dev)
         g2o = torch.from_numpy(halo.gid2op).to(dev)
         col_local = g2o[col.long()].contiguous() if col.numel() else col
-        csr = DeviceCSR(rowptr.cpu().numpy(), col_local, val32[:col.numel()], nl, nl + halo.n_halo, dev)
+        csr = ops.csr(rowptr.cpu().numpy(), col_local, val32[:col.numel()], nl, nl + halo.n_halo, dev)
         if rl is not None:
             # the hubs are nodes [0, HOT_ROWS): this shard's own rows among them, and the head of its halo (ascending ids)
             own_hot = int(min(max(HOT_ROWS - lo, 0), nl))
             halo_hot = int(np.searchsorted(halo.remote, HOT_ROWS))
-            _lib.check(lib.gss_csr_set_hot(csr.handle, own_hot, nl, nl + halo_hot), "gss_csr_set_hot")
+            ops.set_hot(csr, own_hot, nl, nl + halo_hot)
         return csr, halo
 
     a, halo_a = finish(rowptr, col, val, 0)

@@ -24,6 +24,10 @@ from .graph import GssGraph, edgelist_adj, knn_descriptor_adj_device
 from .model import ResidualGraphConvolutionalNetwork
 
 
+COLLECTIVE_TIMEOUT_S = 300.0   # sharded runs: a stream that does not drain for this long means a peer stopped taking part in a collective;
+                               # gss_comm_sync then aborts the RCCL communicator and the rank exits non-zero instead of hanging
+
+
 def build_parser():
     p = argparse.ArgumentParser(description="GSS-GCN embedding trainer on MI355X (train.py of gcn-drug-repurposing)")
     p.add_argument('--kq', type=int, default=5, help='Top k number for the query graph (unused, as in the reference).')
@@ -118,7 +122,8 @@ def main(argv=None):
                 with socket.socket() as s_:
                     s_.bind(("127.0.0.1", 0))
                     os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            import datetime
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=2 * COLLECTIVE_TIMEOUT_S))
 
     if args.seed:                       # seed 0 / None leaves the RNGs unseeded, like train.py:74-76
         torch.manual_seed(args.seed)
@@ -173,10 +178,19 @@ def main(argv=None):
             print('Created G with [k={}] [shape=[{}, {}]] [nnz(A_hat)={}] in {:.2f}s; {} node-range shards'.format(
                 args.k, n, n, engine.global_nnz, time.time() - t0, world))
 
-        def full_embeddings():
-            return engine.gather_embeddings()
+        def watch():
+            # every host-side wait of a sharded run goes through the communicator's watchdog first (RCCL error poll + deadline)
+            if sharded:
+                comm.sync(COLLECTIVE_TIMEOUT_S)
 
-        percentile = engine.percentile
+        def full_embeddings():
+            out = engine.gather_embeddings()
+            watch()
+            return out
+
+        def percentile(q):
+            watch()
+            return engine.percentile(q)
     else:
         feats = torch.from_numpy(X32).to(dev)                    # method/dataset.py:13
         params = [torch.from_numpy(host_params[k]).to(dev) for k in ("W1", "b1", "W2", "b2")]
@@ -184,6 +198,9 @@ def main(argv=None):
                            lr=args.lr, max_batch=min(bsz, n), cache_layer1=args.cache_layer1)
         full_embeddings = engine.gather_embeddings
         percentile = engine.percentile
+
+        def watch():
+            pass
     loader = DataLoader(_IndexDataset(n), batch_size=bsz, shuffle=True, num_workers=0, drop_last=False)
 
     replay = None
@@ -253,6 +270,7 @@ def main(argv=None):
                 engine.step_lazy(idx32, beta_score, count=b, offset=off)
             off += b
             step_no += 1
+        watch()
         itr += 1
         if args.checkpoint and rank == 0:          # weights and optimizer state are replicated: rank 0's copy is the job's
             sd = engine.state_dict()

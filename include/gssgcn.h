@@ -24,13 +24,15 @@
 extern "C" {
 #endif
 
-#define GSS_ABI_VERSION 2
+#define GSS_ABI_VERSION 3
 
 #define GSS_OK 0
 #define GSS_EINVAL (-22)   /* bad argument (shape, null pointer, unsupported d) */
 #define GSS_ENOMEM (-12)   /* hipMalloc failed */
 #define GSS_EHIP (-5)      /* a HIP call or kernel launch failed */
 #define GSS_ENOTCONV (-34)  /* gss_ppr_run: max_iter reached */
+#define GSS_ECOMM (-104)    /* a collective failed or the communicator was aborted (RCCL error, dead peer) */
+#define GSS_ETIMEOUT (-110) /* gss_comm_sync: the stream did not drain before the deadline; the communicator was aborted */
 
 typedef struct gss_csr gss_csr;   /* a CSR operand plus its launch schedule (row bins) */
 typedef struct gss_plan gss_plan; /* activations + workspace of one training replica/shard */
@@ -132,15 +134,6 @@ int gss_rownorm_elu_bwd(int32_t d, const float *de_b, const int32_t *idx, int32_
 /* dst[rows[r]] += src[r] for r < b (rows unique; a negative row is skipped -- a batch row another shard owns) */
 int gss_scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32_t b, float *dst, void *stream);
 
-/* Node-range sharded trainer: the index maps one shard needs for one batch.  idx: [b] global node ids;
- * this shard owns [lo, lo + nl); bounds: device int64 [world + 1] shard boundaries; operands gathered from all shards
- * are laid out padded, shard o at rows [o * maxr, o * maxr + rows of o).
- *   rows_all[i] = local row of idx[i], clamped into the shard (any owned row where the shard has no say)
- *   rows_own[i] = local row, or -1 if another shard owns idx[i];  keep[i] = 1.0 / 0.0 likewise
- *   pos_col[padded id] = i for batch members, -1 elsewhere ([world * maxr]);  pos_row[local row] = i or -1 ([nl]) */
-int gss_shard_batch_maps(const int32_t *idx, int32_t b, int32_t lo, int32_t nl, const int64_t *bounds, int32_t world, int32_t maxr,
-                         int32_t *rows_all, int32_t *rows_own, float *keep, int32_t *pos_col, int32_t *pos_row, void *stream);
-
 /* ---- C1-C3  collectives of the node-range sharded trainer (the reference is single-device,
  * train.py:68,118-122, so there is nothing to match -- these are the exchange points 1-D sharding of its step needs).
  * One process per GPU: rank 0 calls gss_comm_unique_id, the host distributes the GSS_COMM_ID_BYTES bytes (torch.distributed
@@ -153,9 +146,19 @@ int gss_comm_unique_id(void *id_out);
 int gss_comm_create_rccl(gss_comm **out, int32_t world, int32_t rank, const void *id);
 int gss_comm_create_local(gss_comm **out /* [world] */, int32_t world);
 void gss_comm_destroy(gss_comm *c);
-/* in-process backend: make every rank that is (or will be) blocked in a collective of this group return an error -- call it
- * from a rank that failed, so that its peers do not wait for the 120 s barrier timeout.  No-op for an RCCL communicator. */
+/* Make every rank that is (or will be) blocked in a collective of this group return an error -- call it from a rank that failed.
+ * In-process backend: releases the host barrier (the peers do not wait for its 120 s timeout).  RCCL: ncclCommAbort -- kernels
+ * already enqueued stop waiting for the peer, the communicator is unusable afterwards (every later call returns GSS_ECOMM). */
 void gss_comm_abort(gss_comm *c);
+/* Failure detection (the reference is single-process and has none).  Every collective entry point polls
+ * ncclCommGetAsyncError after enqueueing and, on an error, aborts the communicator and returns GSS_ECOMM; gss_comm_check is the same
+ * poll on its own.  gss_comm_sync waits until `stream` has drained (hipStreamQuery + the same poll, no busy device wait) and, if
+ * that takes longer than timeout_s (> 0) -- a peer that stopped calling, mismatched collectives --, aborts the communicator and
+ * returns GSS_ETIMEOUT instead of hanging; callers then exit non-zero.  gss_comm_count: the number of ranks the backend itself
+ * reports (ncclCommCount) -- bench.py prints it as `rccl_ranks`. */
+int gss_comm_check(gss_comm *c);
+int gss_comm_count(gss_comm *c, int32_t *count_out);
+int gss_comm_sync(gss_comm *c, void *stream, double timeout_s);
 int32_t gss_comm_world(const gss_comm *c);
 int32_t gss_comm_rank(const gss_comm *c);
 /* C1: src [max_rows][d] (this rank's rows first, the rest don't-care) -> dst_padded [world * max_rows][d], rank r's rows at

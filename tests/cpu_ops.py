@@ -1,6 +1,10 @@
-"""numpy op backend with the interface of gcn_drug_repurposing_amd.dist.HipOps -- TEST INFRASTRUCTURE.
-Lets the sharded step (partitioning, padded all-gathers, batch-row exchange, gradient all-reduce) run under
-gloo on CPU, where there is no GPU for the HIP kernels."""
+"""numpy stand-ins for the device side of the sharded trainer -- TEST INFRASTRUCTURE.
+Lets the PRODUCT's shard preparation (gcn_drug_repurposing_amd/shards.py build_shard, dist.Halo / ShardLayout) and a restatement of
+the C++ plan's sharded step (tests/shard_step_mirror.py) run as separate gloo processes on CPU, where there is no GPU for the HIP
+kernels:
+  NumpyOps       the arithmetic of the per-op kernels (fp64 inside, fp32 between ops)
+  NumpyShardOps  what shards.NativeShardOps does with libgssgcn.so (row sums, D^-1/2 scaling with the kernels' rounding sequence, CSR)
+  GlooComm       the five methods of dist.Comm over torch.distributed (gloo)"""
 import numpy as np
 import scipy.sparse as sp
 import torch
@@ -98,24 +102,6 @@ class NumpyOps:
         dp = c * gx * _elu_grad(_np(p)) + (_np(res) if res is not None else 0.0)
         return _t(dp), (_t(gx) if want_gx else None)
 
-    def scatter_add_rows(self, src, rows, dst):
-        if src.shape[0]:
-            keep = rows >= 0
-            dst.index_add_(0, rows[keep].long(), src[keep])
-
-    def batch_maps(self, idx32, lo, nl, bounds_dev, world, maxr):
-        idx = idx32.numpy().astype(np.int64)
-        bounds = bounds_dev.numpy()
-        rel = idx - lo
-        mine = (rel >= 0) & (rel < nl)
-        o = np.searchsorted(bounds, idx, side="right") - 1
-        pos_col = np.full(world * maxr, -1, np.int32)
-        pos_col[o * maxr + (idx - bounds[o])] = np.arange(len(idx), dtype=np.int32)
-        pos_row = np.full(max(nl, 1), -1, np.int32)
-        pos_row[rel[mine]] = np.arange(len(idx), dtype=np.int32)[mine]
-        return (torch.from_numpy(np.clip(rel, 0, max(nl - 1, 0)).astype(np.int32)), torch.from_numpy(np.where(mine, rel, -1).astype(np.int32)),
-                torch.from_numpy(mine.astype(np.float32)[:, None]), torch.from_numpy(pos_col), torch.from_numpy(pos_row))
-
     def adam(self, params, grads, m, v, step, lr, betas, eps):
         b1, b2 = betas
         bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
@@ -123,6 +109,89 @@ class NumpyOps:
             m[k].lerp_(grads[k], 1 - b1)
             v[k].mul_(b2).addcmul_(grads[k], grads[k], value=1 - b2)
             params[k].addcdiv_(m[k], (v[k].sqrt() / bc2 ** 0.5).add_(eps), value=-lr / bc1)
+
+
+class NumpyShardOps:
+    """shards.NativeShardOps on the host: the same results as csrc/spmm.hip rowsum_kernel / scale_shard_kernel (same rounding
+    sequence: fp64 products in the kernels' order, one cast to fp32)"""
+
+    def rowsum_dinv(self, nl, rowptr, val, dev):
+        rp, v = rowptr.numpy().astype(np.int64), val.numpy()
+        rowsum = np.array([v[rp[i]:rp[i + 1]].sum() for i in range(nl)] + ([0.0] if nl == 0 else []), dtype=np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dinv = np.power(rowsum, -0.5)
+        return torch.from_numpy(dinv), torch.from_numpy(rowsum)
+
+    def scale_adj(self, nl, lo, rowptr, col, val, dinv, transposed, dev):
+        rp, c, v, di = rowptr.numpy().astype(np.int64), col.numpy().astype(np.int64), val.numpy(), dinv.numpy()
+        row = np.repeat(np.arange(nl, dtype=np.int64), np.diff(rp[:nl + 1])) + lo
+        out = ((v * di[row]) * di[c]) if transposed else ((v * di[c]) * di[row])
+        out = out.astype(np.float32)
+        return torch.from_numpy(out if out.size else np.zeros(1, np.float32))
+
+    def csr(self, rowptr_host, col_local, val32, n_rows, n_cols, dev):
+        c = _Csr(rowptr_host, col_local.numpy(), val32.numpy(), n_rows, n_cols)
+        c.nnz = int(len(val32))
+        c.hot = None
+        return c
+
+    def set_hot(self, csr, own_hot, halo_begin, halo_end):
+        csr.hot = (own_hot, halo_begin, halo_end)       # speed only on the device; recorded so that a test can look at it
+
+
+class GlooComm:
+    """dist.Comm's methods over torch.distributed (gloo): CPU tensors, blocking"""
+
+    handle = None
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.rows_received = 0          # rows of all exchange_rows calls (what a step moves over the links)
+        self.exchanges = 0
+
+    def abort(self):
+        pass
+
+    def check(self):
+        pass
+
+    def count(self):
+        return self.world
+
+    def sync(self, timeout_s=None):
+        pass
+
+    def allgather_bytes(self, src):
+        src = src.contiguous()
+        parts = [torch.empty_like(src) for _ in range(self.world)]
+        self.dist.all_gather(parts, src)
+        return torch.cat([p.reshape(-1) for p in parts])
+
+    def exchange_rows(self, d, send, send_off, recv, recv_off):
+        send_off, recv_off = np.asarray(send_off, np.int64), np.asarray(recv_off, np.int64)
+        reqs, landed = [], []
+        for q in range(self.world):
+            if q == self.rank:
+                continue
+            ns, nr = int(send_off[q + 1] - send_off[q]), int(recv_off[q + 1] - recv_off[q])
+            if ns > 0:
+                reqs.append(self.dist.isend(send.reshape(-1)[send_off[q] * d:send_off[q + 1] * d].contiguous(), q))
+            if nr > 0:
+                buf = torch.empty(nr * d, dtype=recv.dtype)
+                reqs.append(self.dist.irecv(buf, q))
+                landed.append((int(recv_off[q]), nr, buf))
+        for r in reqs:
+            r.wait()
+        flat = recv.reshape(-1)
+        for off, nr, buf in landed:
+            flat[off * d:(off + nr) * d] = buf
+            self.rows_received += nr
+        self.exchanges += 1
+
+    def all_reduce_sum_(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
 
 
 def emulate_ppr(prob, alpha, tol, max_iter):

@@ -1,5 +1,6 @@
-"""-m gpu: the sharded step with the HIP op backend.  P virtual ranks run as threads of one process on the one
-GPU of the test box (ThreadComm); the result must match the single-GPU plan."""
+"""-m gpu: the NATIVE sharded plan (gss_plan_create_sharded).  P ranks run as threads of one process on the one GPU of the
+test box (gss_comm_create_local); the result must match the fixtures and the single-GPU plan.  The RCCL backend runs with the one
+rank a single GPU allows; with two or more visible GPUs test_two_rccl_ranks_* starts real ranks as child processes."""
 import threading
 
 import numpy as np
@@ -8,52 +9,14 @@ import pytest
 from conftest import golden_batches, golden_csr, golden_params, load_golden
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
 torch = pytest.importorskip("torch")
-
-
-def _run_sharded(case, world):
-    from gcn_drug_repurposing_amd.dist import HipOps, ShardedEngine, ThreadComm
-    g = load_golden(case)
-    n, d, L = (int(v) for v in g["meta"])
-    shared = ThreadComm.Shared(world)
-    shared.barrier = threading.Barrier(world, timeout=120)
-    results, errors = [None] * world, []
-
-    def worker(rank):
-        try:
-            torch.cuda.set_device(0)
-            with torch.cuda.stream(torch.cuda.Stream()):
-                eng = ShardedEngine(golden_csr(g, "A"), g["X"], golden_params(g, "init"), num_layers=L, layer_decay=float(g["decay"]),
-                                    alpha=float(g["alpha"]), lr=float(g["lr"]), comm=ThreadComm(shared, rank), ops=HipOps("cuda:0"),
-                                    device=torch.device("cuda:0"))
-                losses = []
-                for idx in golden_batches(g):
-                    eng.step(torch.from_numpy(idx.astype(np.int32)).cuda(), float(g["beta"]))
-                    losses.append(float(eng.loss.item()))
-                emb = eng.gather_embeddings().cpu().numpy()
-                results[rank] = (losses, emb, [p.cpu().numpy() for p in eng.params])
-        except Exception as e:  # noqa: BLE001
-            errors.append((rank, repr(e)))
-            shared.barrier.abort()
-
-    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
-    [t.start() for t in ts]
-    [t.join(300) for t in ts]
-    assert not errors, errors
-    return g, results
-
-
-@pytest.mark.parametrize("world,case", [(2, "edge_n600_d128_L2"), (3, "knn_n2000_d64_L3"), (4, "knn_n200_d16_L2")])
-def test_sharded_hip_matches_reference(world, case):
-    g, res = _run_sharded(case, world)
-    for r in range(1, world):
-        assert res[r][0] == res[0][0]
-        np.testing.assert_array_equal(res[r][1], res[0][1])
-    losses, emb, params = res[0]
-    np.testing.assert_allclose(losses, g["losses"], rtol=2e-4, atol=1e-8)
-    assert np.abs(emb - g["emb_last"]).max() / np.abs(g["emb_last"]).max() < 2e-3
-    for k, p in zip(("W1", "b1", "W2", "b2"), params):
-        assert np.abs(p - g["final_" + k]).max() < 2.5 * float(g["lr"]), k
 
 
 def _run_native(adj, X, params, L, batches, beta, world, decay=0.3, alpha=1.0, lr=3e-4, max_batch=None, fused_step=True, a_hat=None):
@@ -283,11 +246,103 @@ def test_rccl_backend_single_rank_collectives():
     _lib.check(_lib.load().gss_exchange_rows(comm.handle, 16, src.data_ptr(), off.ctypes.data, dst.data_ptr(), off.ctypes.data, _lib.current_stream()))
     torch.cuda.synchronize()
     assert torch.equal(dst, src) and torch.equal(t, torch.full((9,), 3.0, device="cuda"))
+    assert comm.count() == 1                      # ncclCommCount
+    comm.check()                                  # ncclCommGetAsyncError: healthy
+    comm.sync(30.0)
+
+
+def test_rccl_watchdog_aborts_instead_of_hanging():
+    """gss_comm_sync: a stream that does not drain before the deadline (here: a one-second device spin; in a job: a peer that stopped
+    taking part in a collective) aborts the communicator (ncclCommAbort) and returns GSS_ETIMEOUT; every later call on that
+    communicator fails with GSS_ECOMM instead of enqueueing"""
+    from gcn_drug_repurposing_amd import GssError
+    from gcn_drug_repurposing_amd.dist import rccl_comm
+    comm = rccl_comm(1, 0)
+    t = torch.ones(8, device="cuda")
+    comm.all_reduce_sum_(t)
+    comm.sync(30.0)
+    torch.cuda._sleep(int(2.0e9))                 # ~1 s of spinning on the current stream
+    with pytest.raises(GssError, match="-110"):
+        comm.sync(0.05)
+    with pytest.raises(GssError, match="-104"):
+        comm.all_reduce_sum_(t)
+    with pytest.raises(GssError, match="-104"):
+        comm.check()
+    torch.cuda.synchronize()
+    del comm                                      # destroying an aborted communicator is fine
+
+
+def test_local_backend_abort_is_reported_by_check():
+    from gcn_drug_repurposing_amd import GssError
+    from gcn_drug_repurposing_amd.dist import local_comms
+    comms = local_comms(2)
+    assert comms[0].count() == 2
+    comms[0].check()
+    comms[1].abort()
+    with pytest.raises(GssError, match="-104"):
+        comms[0].check()
+
+
+def _visible_gpus():
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_visible_gpus() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_rccl_ranks_trainer_matches_single_gpu(tmp_path):
+    """The multi-process RCCL path proper: `train.py --ngpus 2` under torch.distributed.run (the torch NCCL process group and the
+    plan's own communicator sharing the two GPUs; grouped ncclSend/ncclRecv halo exchange; grouped all-reduce of the four gradients)
+    against the single-GPU trainer on the reference-generated fixture.  Started as a CHILD process before this process touches
+    a second GPU."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    g = load_golden("train_py_n200_d16")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    emb_path = tmp_path / "in.embs.txt"
+    emb_path.write_bytes(bytes(g["in_embs_txt"]))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    common = ["--emb-file", str(emb_path), "--num-layers", "2", "--hidden-units", "16", "--k", "5", "--epochs", "3", "--lr", "0.0003",
+              "--beta-percentile", "98", "--batch-size", "64", "--seed", "7"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "train.py")] + common + ["--ngpus", "2", "--out", str(tmp_path / "two.txt")],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    one = subprocess.run([sys.executable, os.path.join(root, "train.py")] + common + ["--out", str(tmp_path / "one.txt")],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    a, b = np.loadtxt(str(tmp_path / "two.txt")), np.loadtxt(str(tmp_path / "one.txt"))
+    # the weight gradients are summed over the ranks in RCCL's order (not the single GPU's slice order): rounding-level differences
+    assert np.abs(a - b).max() < 1e-5
+    ref = np.loadtxt(bytes(g["graph_embs_txt"]).decode().splitlines())
+    assert np.abs(a - ref).max() < 5e-3
+
+
+@pytest.mark.skipif(_visible_gpus() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_rccl_ranks_bench_line_is_complete():
+    """`bench.py --gpus 2` starts its own two ranks; the line must carry what a scaling run is graded on"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--spinup-time", "0.05",
+                        "--min-time", "0"], capture_output=True, text=True, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+    for key in ("roofline", "xgmi", "per_rank", "comm_share", "kernel_ms_per_step", "value_executed"):
+        assert key in line, key
+    assert len(line["per_rank"]["ms_per_step"]) == 2 and line["roofline"]["bound"] == "hbm"
+    assert np.isfinite(line["config"]["final_loss"])
 
 
 def test_bench_sharded_path_over_rccl_single_rank(tmp_path):
-    """bench.py's multi-GPU branch (torch.distributed 'nccl' == RCCL, TorchComm, ShardedEngine) with one rank, launched
-    the way the driver launches it; must agree with the single-GPU plan's loss after the same steps."""
+    """bench.py's multi-GPU branch (the native sharded plan over an RCCL communicator) with one rank, launched the way the driver
+    launches it; must agree with the single-GPU plan's loss after the same steps and carry the keys a scaling run is graded on."""
     import json
     import os
     import subprocess
@@ -295,12 +350,16 @@ def test_bench_sharded_path_over_rccl_single_rank(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GSS_FORCE_SHARDED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     sharded = json.loads(line)
     assert "node-range shards" in sharded["config"]["parallelism"]
+    assert sharded["rccl_ranks"] == 1 and len(sharded["per_rank"]["ms_per_step"]) == 1
+    for key in ("roofline", "xgmi", "comm_share", "kernel_ms_per_step", "value_executed", "event_overhead_us_per_launch"):
+        assert key in sharded, key
+    assert sharded["roofline"]["bound"] == "hbm" and 0 < sharded["roofline"]["frac"] < 1
     ref = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=600)
     assert ref.returncode == 0, ref.stderr[-2000:]
@@ -318,7 +377,7 @@ def test_trainer_cli_sharded_mode_writes_the_same_embeddings(tmp_path):
     emb_path = tmp_path / "in.embs.txt"
     emb_path.write_bytes(bytes(g["in_embs_txt"]))
     outs = []
-    for mode, env_extra in (("single", {}), ("sharded", {"GSS_FORCE_SHARDED": "1", "MASTER_PORT": "29541"})):
+    for mode, env_extra in (("single", {}), ("sharded", {"GSS_FORCE_SHARDED": "1"})):
         out = tmp_path / f"{mode}.txt"
         cmd = [sys.executable, os.path.join(root, "train.py"), "--emb-file", str(emb_path), "--num-layers", "2", "--hidden-units", "16",
                "--k", "5", "--epochs", "3", "--lr", "0.0003", "--beta-percentile", "98", "--batch-size", "64", "--seed", "7", "--out", str(out)]
