@@ -126,6 +126,7 @@ SIGNATURES = {
     "gss_ppr_create": (C.c_int, [C.POINTER(_P), C.POINTER(PprDesc)]),
     "gss_ppr_destroy": (None, [_P]),
     "gss_ppr_device_bytes": (_SZ, [_P]),
+    "gss_ppr_check_guards": (C.c_int, [_P]),
     "gss_ppr_run": (C.c_int, [_P, _D, _D, _I32, _P, _P, _P]),
     "gss_ppr_spmm": (C.c_int, [_P, _P, _P, _P]),
 }

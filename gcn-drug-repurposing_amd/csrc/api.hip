@@ -14,6 +14,8 @@ extern int g_gemm_small_nt;
 extern int g_loss_wgs;      // loss.hip
 extern int g_xcd_remap;     // dense.hip
 extern int g_wgrad_wgs;
+extern int g_gemm_prio;
+extern int g_wgrad_prio;
 }
 extern int g_sparse_bits_rows;  // plan.hip
 namespace gss {
@@ -86,6 +88,16 @@ int gss_debug_set_option(const char *name, int value) {
   if (strcmp(name, "gemm_small_nt") == 0) {
     GSS_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "gemm_small_nt must be 0, 1, 2, 4 or 8");
     g_gemm_small_nt = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "gemm_prio") == 0) {
+    GSS_REQUIRE(value >= 0, "gemm_prio must be >= 0 (0 = off)");
+    g_gemm_prio = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "wgrad_prio") == 0) {
+    GSS_REQUIRE(value >= 0 && value <= 2, "wgrad_prio must be 0, 1 or 2");
+    g_wgrad_prio = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_variant") == 0) {

@@ -45,6 +45,7 @@ struct GemmArgs {
   const int32_t *rows;  // scatter map for the output row (nullable)
   float *inv_den;       // EPI_FWD_NORM: 1 / max(||x_row||, eps) per node (x_next then receives the unit-norm rows)
   int xcd_remap;        // renumber the workgroups so that those sharing input rows sit on one XCD (xcd_ids below)
+  int prio_cut;         // > 0: workgroups whose linear id is below it raise their wave priority (debug knob "gemm_prio")
 };
 
 template <int FT, int EPI>
@@ -152,9 +153,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 // naive way this was 3 NT serialised memory round trips per tile and most of the kernel's time.
 template <int NT, int EPI>
 __device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&acc)[NT], int nd, int j0, int q) {
-  const bool live = nd < g.n;
+  bool live = nd < g.n;
   int ndc = min(nd, g.n - 1);
-  if (g.rows) ndc = g.rows[ndc];   // forward over a row list (gss_plan_step_lazy): tile row -> node row, inputs and outputs alike
+  if (g.rows) {   // forward over a row list (gss_plan_step_lazy): tile row -> node row, inputs and outputs alike
+    ndc = g.rows[ndc];
+    if (ndc < 0) {   // a batch member another shard owns: computed from row 0's operands, never stored
+      live = false;
+      ndc = 0;
+    }
+  }
   float4 bb[NT], pp[NT];
 #pragma unroll
   for (int u = 0; u < NT; ++u) {
@@ -261,7 +268,12 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
   // grid = (node tiles, column tiles): the column tiles of a node tile read the same input rows
-  const XcdIds id = xcd_ids((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)gridDim.x, (int)gridDim.y, g.xcd_remap != 0);
+  const int linear = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+  const XcdIds id = xcd_ids(linear, (int)gridDim.x, (int)gridDim.y, g.xcd_remap != 0);
+  // The first generation of workgroups (one per CU) and the ones that double up on the CUs start together and otherwise run in
+  // lockstep: shared MFMA pipe at half rate each, then both store at once.  With the first generation at a higher wave priority it
+  // takes the pipe, finishes early and stores while the second generation computes (MI355X guide, 'static priority').  Speed only.
+  if (g.prio_cut > 0 && linear < g.prio_cut) __builtin_amdgcn_s_setprio(3);
   const int node_base = id.spread * BM;
   const int j0 = id.share * BN;
   const int jh = j0 >= g.jsplit ? 1 : 0;
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       int node = min(g.n - 1, node_base + 16 * (w + WAVES * i) + r);
-      if (EPI != EPI_SPLIT && g.rows) node = g.rows[node];
+      if (EPI != EPI_SPLIT && g.rows) node = max(g.rows[node], 0);   // a skipped entry (< 0) stages row 0; fwd_epilogue drops the result
       xsrc[kh][i] = in ? in + (size_t)node * ld + 4 * q : nullptr;
     }
 #pragma unroll
@@ -379,6 +391,8 @@ int g_gemm_variant = 2;
 int g_gemm_nt_cap = 0;
 int g_wgrad_wgs = 256;  // debug knob "wgrad_wgs": workgroups of a full-size weight-gradient launch (one per CU)
 int g_xcd_remap = 1;    // debug knob "xcd_remap": workgroups that share input rows on one XCD (xcd_ids)
+int g_gemm_prio = 0;      // debug knob "gemm_prio": linear workgroup ids below it run at raised wave priority (0 = off)
+int g_wgrad_prio = 0;     // debug knob "wgrad_prio": 1 = waves 4-7 of a weight-gradient workgroup at priority 1, 2 = waves 0-3
 int g_gemm_small_nt = 2;  // debug knob "gemm_small_nt": narrowest feature tile (in 16-feature units) for small problems, 0 = never narrow
 
 template <int EPI>
@@ -386,6 +400,7 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
   if (g_in.n <= 0) return GSS_OK;
   GemmArgs g = g_in;
   g.xcd_remap = g_xcd_remap;
+  g.prio_cut = g_gemm_prio;
   if (g_gemm_variant >= 2) {
     int nt = (d % 128 == 0) ? 8 : (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
     if (g_gemm_nt_cap > 0 && EPI != EPI_FWD_NORM)   // debug knob "gemm_nt_cap": narrower feature tiles (the fused normalise needs whole rows)
@@ -555,6 +570,7 @@ struct WgradArgs {
   float *part_b;  // [nslices][d]
   int rows_per_slice;
   int xcd_remap;
+  int prio;
 };
 
 // Two problems may share one launch (grid.y = ns0 + slices of the second): the top layer's batch-row gradient is 64
@@ -566,6 +582,9 @@ __global__ __launch_bounds__(64 * kWgWaves) void wgrad_tn_kernel(WgradArgs g0, W
   const int bx = g0.xcd_remap ? id.share : (int)blockIdx.x, by = g0.xcd_remap ? id.spread : (int)blockIdx.y;
   const bool second = by >= ns0;
   const WgradArgs &g = second ? g1 : g0;
+  // the two waves of a SIMD run the same program in lockstep; a static priority for one half (MI355X guide, item 4)
+  if (g0.prio == 1 && (threadIdx.x >> 6) >= 4) __builtin_amdgcn_s_setprio(1);
+  if (g0.prio == 2 && (threadIdx.x >> 6) < 4) __builtin_amdgcn_s_setprio(1);
   float4 *red = reinterpret_cast<float4 *>(smem);  // [4 slots][16 tiles][64 lanes] float4
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
@@ -808,7 +827,7 @@ int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const 
   *nslices_out = ns;
   float *pw = (float *)ws + (size_t)slice0 * d * 2 * d;
   float *pb = (float *)ws + (size_t)total_slices * d * 2 * d + (size_t)slice0 * d;
-  WgradArgs g{n, d, dp, ax, am, rows, pw, pb, rps, g_xcd_remap};
+  WgradArgs g{n, d, dp, ax, am, rows, pw, pb, rps, g_xcd_remap, g_wgrad_prio};
   if (n == 0) {  // empty shard: its slices must still read as zero
     GSS_HIP(hipMemsetAsync(pw, 0, sizeof(float) * (size_t)ns * d * 2 * d, st));
     GSS_HIP(hipMemsetAsync(pb, 0, sizeof(float) * (size_t)ns * d, st));
@@ -843,8 +862,8 @@ int wgrad_partial_pair(int32_t d, int32_t n0, const float *dp0, const float *ax0
   *ns0_out = ns0;
   *ns1_out = ns1;
   float *base_w = (float *)ws, *base_b = (float *)ws + (size_t)total_slices * d * 2 * d;
-  WgradArgs g0{n0, d, dp0, ax0, am0, rows0, base_w + (size_t)slice0_0 * d * 2 * d, base_b + (size_t)slice0_0 * d, rps0, g_xcd_remap};
-  WgradArgs g1{n1, d, dp1, ax1, am1, rows1, base_w + (size_t)slice0_1 * d * 2 * d, base_b + (size_t)slice0_1 * d, rps1, g_xcd_remap};
+  WgradArgs g0{n0, d, dp0, ax0, am0, rows0, base_w + (size_t)slice0_0 * d * 2 * d, base_b + (size_t)slice0_0 * d, rps0, g_xcd_remap, g_wgrad_prio};
+  WgradArgs g1{n1, d, dp1, ax1, am1, rows1, base_w + (size_t)slice0_1 * d * 2 * d, base_b + (size_t)slice0_1 * d, rps1, g_xcd_remap, g_wgrad_prio};
   const int tiles = (d / 64) * (2 * d / 64);
   hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns0 + ns1), dim3(64 * kWgWaves), 4 * 16 * 64 * sizeof(float4), as_stream(stream), g0, g1,
                      ns0);

@@ -15,8 +15,10 @@ __global__ __launch_bounds__(256) void rownorm_fwd_kernel(int n, int d4, int lpr
   const int rpw = 64 >> lpr_log2;
   const int li = lane & (lpr - 1);
   const int ri = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + (lane >> lpr_log2);
-  const bool ok = ri < n;
-  const int row = (ok && rows) ? rows[ri] : ri;   // a row list: the n listed rows of x / e / inv_den (gss_plan_step_lazy)
+  // a row list: the n listed rows of x / e / inv_den (gss_plan_step_lazy); a negative entry = a batch member another shard owns: skipped
+  const int listed = (ri < n && rows) ? rows[ri] : ri;
+  const bool ok = ri < n && listed >= 0;
+  const int row = ok ? listed : 0;
   float4 v[VPL];
   float ss = 0.f;
 #pragma unroll
@@ -110,7 +112,7 @@ __global__ void batch_bits_kernel(const int32_t *__restrict__ ids, int b, uint32
 // batch-position map pos[id] = position (on own rows it is the row mask of the top layer, later the key of the sparse backward hop)
 __global__ void batch_prepare_kernel(const int32_t *__restrict__ idx, int b, const int32_t *__restrict__ node_map, int lo, int nl,
                                      const int32_t *__restrict__ gid2op, int32_t *__restrict__ rloc, int32_t *__restrict__ pid,
-                                     float *__restrict__ keep, int32_t *__restrict__ pos) {
+                                     float *__restrict__ keep, int32_t *__restrict__ pos, int32_t *__restrict__ rlist) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b) return;
   const int id = node_map ? node_map[idx[i]] : idx[i];
@@ -120,6 +122,7 @@ __global__ void batch_prepare_kernel(const int32_t *__restrict__ idx, int b, con
   if (rloc) rloc[i] = min(max(rel, 0), max(nl - 1, 0));
   if (pid) pid[i] = op;
   if (keep) keep[i] = mine ? 1.f : 0.f;
+  if (rlist) rlist[i] = mine ? rel : -1;   // the row list of the lazy top layer: the members this shard owns, -1 for the others
   if (op >= 0) pos[op] = i;
 }
 
@@ -295,11 +298,11 @@ int batch_bits(const int32_t *ids, int32_t b, uint32_t *bits, int set, void *str
 }
 
 int batch_prepare(const int32_t *idx, int32_t b, const int32_t *node_map, int32_t lo, int32_t nl, const int32_t *gid2op, int32_t *rloc,
-                  int32_t *pid, float *keep, int32_t *pos, void *stream) {
+                  int32_t *pid, float *keep, int32_t *pos, void *stream, int32_t *rlist) {
   GSS_REQUIRE(idx && pos && b >= 0 && nl >= 0, "batch_prepare: null operand");
   if (b == 0) return GSS_OK;
   hipLaunchKernelGGL(batch_prepare_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, as_stream(stream), idx, b, node_map, lo, nl, gid2op, rloc, pid,
-                     keep, pos);
+                     keep, pos, rlist);
   GSS_LAUNCH_CHECK("batch_prepare_kernel");
   return GSS_OK;
 }

@@ -50,7 +50,8 @@ int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, cons
               float *dp, float *gx_out, void *stream);
 int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
               const float *b2, const float *p_prev, float decay, float *p, float *x_next, void *stream,
-              const int32_t *row_list = nullptr);  // row_list: the n tile rows are node rows row_list[0..n) of every operand
+              const int32_t *row_list = nullptr);  // row_list: the n tile rows are node rows row_list[0..n) of every operand; a negative
+                                                   // entry is skipped (nothing of it is written)
 bool dense_fwd_norm_available(int32_t d);
 bool dense_row_list_available();
 int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
@@ -88,8 +89,9 @@ int batch_bits(const int32_t *ids, int32_t b, uint32_t *bits, int set, void *str
 bool spmm_sparse_available();
 int spmm_bwd2_sparse_res(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res_b,
                          const int32_t *pos_row, float *dp, float *gx_out, void *stream, const uint32_t *nzbits = nullptr);
+// rlist (nullable): per member the local row when this shard owns it, -1 otherwise -- the row list of the lazy top layer
 int batch_prepare(const int32_t *idx, int32_t b, const int32_t *node_map, int32_t lo, int32_t nl, const int32_t *gid2op, int32_t *rloc,
-                  int32_t *pid, float *keep, int32_t *pos, void *stream);
+                  int32_t *pid, float *keep, int32_t *pos, void *stream, int32_t *rlist = nullptr);
 // bits [first, last) of a bitmap := 1 (whole and partial words; other bits untouched)
 int bits_fill(uint32_t *bits, int64_t first, int64_t last, void *stream);
 int adam_step(int64_t count, float *param, const float *grad, float *m, float *v, int32_t step, float lr, float beta1,

@@ -75,6 +75,7 @@ struct gss_plan {
   float *m0op;             // layer 1's M = AX (.) X as an operand: its OWN rows are recomputed every step, its halo rows -- the same
   bool m0_ready;           // constants computed by their owners -- are fetched once (m_tmp itself on one GPU)
   int32_t *pid, *rloc;     // per batch: operand row in A_hat^T's column space (or -1) / local row (clamped) of every member
+  int32_t *rlist;          // shards, gss_plan_step_lazy: per member its local row when this shard owns it, -1 otherwise (the top layer's row list)
   float *keep;             // per batch: 1.0 where this shard owns the member
   float *gab;              // [2 * max_batch][d]: the top layer's compact input gradients, all-reduced as one buffer
 };
@@ -151,6 +152,7 @@ void carve(gss_plan *p, Carver &c) {
   p->pid = maps ? c.take<int32_t>(D.max_batch) : nullptr;
   p->rloc = maps ? c.take<int32_t>(D.max_batch) : nullptr;
   p->keep = sharded ? c.take<float>(D.max_batch) : nullptr;
+  p->rlist = sharded ? c.take<int32_t>(D.max_batch) : nullptr;
   p->ax.assign(L, nullptr);
   p->am.assign(L, nullptr);
   p->p.assign(L, nullptr);
@@ -798,13 +800,13 @@ static int plan_step_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta
     {
       PROF(GSS_PROF_ELEMENTWISE);
       if (int rc = batch_prepare(idx, b, p->desc.node_map, p->lo, p->desc.n, p->gid2op_t, mapped ? p->rloc : nullptr, mapped ? p->pid : nullptr,
-                                 p->keep, p->pos, stream))
+                                 p->keep, p->pos, stream, p->rlist))
         return rc;
     }
-    // a shard lists every batch member: those of other shards are clamped onto one of its rows, whose top-layer values are then
-    // recomputed from whatever that row's A_hat M holds -- nothing reads them (the batch rows the shard owns are in the list as
-    // themselves); an empty shard has no row to clamp onto and no top layer to evaluate
-    if (int rc = plan_forward_impl(p, stream, mapped ? p->rloc : idx, p->desc.n > 0 ? b : 0)) return rc;
+    // a shard lists the batch members it OWNS (rlist: -1 for the others, whose tile rows compute on row 0's operands and store
+    // nothing): every listed row has one writer, no row outside the batch is touched; an empty shard has no top layer to evaluate
+    const int32_t *rows = p->rlist ? p->rlist : (mapped ? p->rloc : idx);
+    if (int rc = plan_forward_impl(p, stream, rows, p->desc.n > 0 ? b : 0)) return rc;
   } else if (int rc = plan_forward_impl(p, stream)) {
     return rc;
   }

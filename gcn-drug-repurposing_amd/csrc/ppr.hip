@@ -23,6 +23,7 @@ struct gss_ppr {
   gss_csr *csr;       // structure handle for the segment schedule
   char *slab;
   size_t slab_bytes;
+  std::vector<size_t> guard_off;   // slab offsets of the guards behind the carved buffers
   double *y;          // [n][kpad]
   double *stash_o;    // [n_ovr]
   double *part;       // [max(z chunks, row blocks)][kpad] column partial sums
@@ -307,7 +308,9 @@ int gss_ppr_create(gss_ppr **out, const gss_ppr_desc *desc) {
   const size_t b_y = al((size_t)D.n * row), b_so = al((size_t)D.n_ovr * sizeof(double)),
                b_part = al((size_t)std::max(p->n_rowblocks, std::max(p->n_zchunks, 1)) * row), b_col = al(row),
                b_int = al((size_t)D.kpad * sizeof(int32_t));
-  p->slab_bytes = b_y + b_so + b_part + 2 * b_col + 2 * b_int + 256;
+  // every carved buffer is followed by a 256-byte guard (as in plan.hip): gss_ppr_check_guards verifies that no kernel wrote one
+  constexpr size_t kGuard = 256;
+  p->slab_bytes = b_y + b_so + b_part + 2 * b_col + 2 * b_int + 256 + 8 * kGuard;
   if (hipMalloc((void **)&p->slab, p->slab_bytes) != hipSuccess) {
     gss_csr_destroy(p->csr);
     const size_t want = p->slab_bytes;
@@ -315,7 +318,13 @@ int gss_ppr_create(gss_ppr **out, const gss_ppr_desc *desc) {
     return fail(GSS_ENOMEM, "ppr_create: hipMalloc of %zu bytes failed", want);
   }
   char *q = p->slab;
-  auto take = [&](size_t b) { char *r = q; q += b; return r; };
+  auto take = [&](size_t b) {
+    char *r = q;
+    q += b;
+    p->guard_off.push_back((size_t)(q - p->slab));
+    q += kGuard;
+    return r;
+  };
   p->y = (double *)take(b_y);
   p->stash_o = (double *)take(b_so);
   p->part = (double *)take(b_part);
@@ -324,6 +333,16 @@ int gss_ppr_create(gss_ppr **out, const gss_ppr_desc *desc) {
   p->done = (int32_t *)take(b_int);
   p->iters = (int32_t *)take(b_int);
   p->n_active = (int32_t *)take(256);
+  hipError_t ge = hipSuccess;
+  for (size_t g : p->guard_off)
+    if (ge == hipSuccess) ge = hipMemset(p->slab + g, 0xA5, kGuard);
+  if (ge == hipSuccess) ge = hipDeviceSynchronize();
+  if (ge != hipSuccess) {
+    gss_csr_destroy(p->csr);
+    (void)hipFree(p->slab);
+    delete p;
+    return fail(GSS_EHIP, "ppr_create: guard fill -> %s", hipGetErrorString(ge));
+  }
   *out = p;
   return GSS_OK;
 }
@@ -336,6 +355,20 @@ void gss_ppr_destroy(gss_ppr *p) {
 }
 
 size_t gss_ppr_device_bytes(const gss_ppr *p) { return p ? p->slab_bytes : 0; }
+
+int gss_ppr_check_guards(gss_ppr *p) {
+  GSS_REQUIRE(p, "ppr_check_guards: null handle");
+  GSS_HIP(hipDeviceSynchronize());
+  unsigned char host[256];
+  for (size_t k = 0; k < p->guard_off.size(); ++k) {
+    GSS_HIP(hipMemcpy(host, p->slab + p->guard_off[k], sizeof(host), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < sizeof(host); ++i)
+      if (host[i] != 0xA5)
+        return fail(GSS_EINVAL, "ppr_check_guards: the guard behind carved buffer %zu (slab offset %zu) was overwritten at byte %zu", k,
+                    p->guard_off[k], i);
+  }
+  return GSS_OK;
+}
 
 int gss_ppr_spmm(gss_ppr *p, const double *x, double *y, void *stream) {
   GSS_REQUIRE(p && x && y, "ppr_spmm: null argument");

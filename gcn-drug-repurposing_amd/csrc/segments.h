@@ -1,0 +1,70 @@
+// segments.h -- host-only: the nnz-balanced schedule of the balanced SpMM (spmm.hip spmm_balanced_kernel, ppr.hip ppr_spmm_kernel).
+//
+// Every row is cut into segments of <= seg_edges stored entries; a row with s segments occupies an ALIGNED block of p = pow2ceil(s)
+// consecutive lane groups of ONE workgroup (waves x 2^gpw_log2 groups), rows too long for that take the whole workgroup with longer
+// segments.  Rows are placed in order of non-increasing block size (then non-increasing length), so blocks stay aligned without
+// gaps; the tail of the last workgroup is padded with empty descriptors (row -1).  One int4 per lane group:
+//     {row, first entry, entry count, log2 p | 0x100 if some row of the workgroup spans more than one wave}
+// The kernels trust these descriptors blindly (a wrong one reads or writes out of bounds on the device), so this routine is kept free
+// of HIP and is run under ASan / UBSan with random degree sequences by tests/test_native_host.py.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace gss {
+
+// -> number of workgroups; segs receives 4 int32 per lane group
+inline int build_segments(const int32_t *rowptr, int32_t n_rows, int waves, int gpw_log2, int seg_edges, std::vector<int32_t> &segs) {
+  const int gpw = 1 << gpw_log2;
+  const int ngb = waves * gpw;  // groups per workgroup
+  int ngb_log2 = 0;
+  while ((1 << ngb_log2) < ngb) ++ngb_log2;
+  struct RowItem {
+    int32_t row, len, plog;
+  };
+  std::vector<RowItem> items;
+  items.reserve((size_t)(n_rows > 0 ? n_rows : 0));
+  int64_t nnz = 0;
+  for (int32_t r = 0; r < n_rows; ++r) {
+    const int32_t len = rowptr[r + 1] - rowptr[r];
+    nnz += len;
+    const int sgm = len <= seg_edges ? 1 : (len + seg_edges - 1) / seg_edges;
+    int plog = 0;
+    while ((1 << plog) < sgm && plog < ngb_log2) ++plog;  // longer rows: whole workgroup, longer segments
+    items.push_back({r, len, plog});
+  }
+  std::stable_sort(items.begin(), items.end(), [](const RowItem &x, const RowItem &y) {
+    return x.plog != y.plog ? x.plog > y.plog : x.len > y.len;
+  });
+  segs.clear();
+  segs.reserve(((size_t)items.size() + (size_t)(nnz / (seg_edges > 0 ? seg_edges : 1)) + 2 * (size_t)ngb) * 4);
+  for (const RowItem &it : items) {  // sizes are non-increasing powers of two: blocks stay aligned
+    const int p = 1 << it.plog;
+    const int per = (it.len + p - 1) / p;
+    for (int k = 0; k < p; ++k) {
+      const int b0 = std::min(it.len, k * per), b1 = std::min(it.len, (k + 1) * per);
+      segs.push_back(it.row);
+      segs.push_back(rowptr[it.row] + b0);
+      segs.push_back(b1 - b0);
+      segs.push_back(it.plog);
+    }
+  }
+  while ((segs.size() / 4) % (size_t)ngb != 0) {
+    segs.push_back(-1);
+    segs.push_back(0);
+    segs.push_back(0);
+    segs.push_back(0);
+  }
+  const int nblk = (int)(segs.size() / 4 / (size_t)ngb);
+  for (int bi = 0; bi < nblk; ++bi) {  // flag workgroups that need the LDS step
+    bool multi = false;
+    for (int k = 0; k < ngb; ++k) multi |= (1 << segs[((size_t)bi * ngb + k) * 4 + 3]) > gpw;
+    if (multi)
+      for (int k = 0; k < ngb; ++k) segs[((size_t)bi * ngb + k) * 4 + 3] |= 0x100;
+  }
+  return nblk;
+}
+
+}  // namespace gss

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "ops.h"
+#include "segments.h"
 
 namespace gss {
 
@@ -123,9 +124,12 @@ __device__ __forceinline__ void row_epilogue(const SpmmEpi &ep, size_t off, floa
     st4(ep.o1 + off, mul4(acc, ld4(ep.a2 + off)));
   } else if (MODE == SPMM_BWD1S) {
     // same with a row-sparse g_ax held compactly: coff addresses its row (or is < 0)
-    // a row without a batch-row neighbour (nearly all of them when B << N) has acc == 0: u = g_ax (or 0), t = 0 without reading x / ax
+    // a row without a batch-row neighbour (nearly all of them when B << N) has acc == 0: u = g_ax (or 0), t = 0 without reading x / ax.
+    // t_zero here: the WHOLE row is zero and not a batch row (row_mark_nonzero) -- with skip_zero_rows it is not written at all, its
+    // clear bit in nzbits_out tells every reader.  The decision is per row, never per piece: a live row writes every piece, zeros
+    // included, so that no piece of it keeps an earlier step's values
+    if (t_zero && ep.skip_zero_rows) return;
     const bool z = is_zero4(acc);
-    if (z && coff < 0 && ep.skip_zero_rows) return;
     float4 u = z ? make_float4(0.f, 0.f, 0.f, 0.f) : mul4(acc, ld4(ep.a1 + off));
     if (coff >= 0) u = add4(u, ld4(ep.a0 + coff));
     st4(ep.o0 + off, u);
@@ -248,12 +252,16 @@ __device__ __forceinline__ bool row_t_zero(const SpmmEpi &ep, int row) {
   return ((ep.posbits[(unsigned)row >> 5] >> (row & 31)) & 1u) == 0u;
 }
 // SPMM_BWD1S with nzbits_out: u = acc (.) x + g_ax can only be non-zero where the sum is, or on a batch row.  gmask = the lanes of
-// this lane's group (they hold the pieces of one row): its first lane sets the bit when any piece is non-zero
+// this lane's group (they hold the pieces of one row); `piece_live` = some piece this lane holds is non-zero or belongs to a batch row.
+// Called by every lane of the group that reached the row's epilogue; its first lane sets the row's bit when any lane is live.
+// Returns true when the whole row is dead (all pieces of all lanes zero, not a batch row).
 template <int MODE>
-__device__ __forceinline__ void mark_nonzero(const SpmmEpi &ep, int row, const float4 &sum, long coff, unsigned long long gmask) {
-  if (MODE != SPMM_BWD1S || !ep.nzbits_out) return;
-  const unsigned long long m = __ballot(coff >= 0 || !is_zero4(sum));
-  if ((m & gmask) != 0ull && (int)(threadIdx.x & 63) == __builtin_ctzll(gmask)) atomicOr(&ep.nzbits_out[(unsigned)row >> 5], 1u << (row & 31));
+__device__ __forceinline__ bool row_mark_nonzero(const SpmmEpi &ep, int row, bool piece_live, unsigned long long gmask) {
+  if (MODE != SPMM_BWD1S || !ep.nzbits_out) return false;
+  const unsigned long long m = __ballot(piece_live);
+  const bool live = (m & gmask) != 0ull;
+  if (live && (int)(threadIdx.x & 63) == __builtin_ctzll(gmask)) atomicOr(&ep.nzbits_out[(unsigned)row >> 5], 1u << (row & 31));
+  return !live;
 }
 
 template <int MODE, int LPR_LOG2, int VPL, bool NARROW, int FLY = 4>
@@ -431,13 +439,18 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   }
   if (pcount <= GPW) {
     if (row >= 0 && (g & (pcount - 1)) == 0) {
-      const bool tz = row_t_zero<MODE>(ep, row);
+      bool tz = row_t_zero<MODE>(ep, row);
+      if (MODE == SPMM_BWD1S) {
+        bool piece_live = ep.pos_row[row] >= 0;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) piece_live |= (li + v * 64 < d4) && !is_zero4(acc[v]);
+        tz = row_mark_nonzero<MODE>(ep, row, piece_live, gmask);
+      }
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
         const int f4 = li + v * 64;
         if (f4 < d4) {
           const long coff = compact_off<MODE>(ep, row, rs4, slice_f4 + f4);
-          mark_nonzero<MODE>(ep, row, acc[v], coff, gmask);
           row_epilogue<MODE>(ep, ((size_t)row * rs4 + slice_f4 + f4) * 4, acc[v], coff, tz);
         }
       }
@@ -455,15 +468,25 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   }
   __syncthreads();
   if (nw > 1 && (wib & (nw - 1)) == 0 && g == 0 && row >= 0) {
+    float4 t[VPL];
+    bool piece_live = MODE == SPMM_BWD1S && ep.pos_row[row] >= 0;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int f4 = li + v * 64;
+      t[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f4 >= d4) continue;
+      t[v] = part[wib * d4 + f4];
+      for (int k = 1; k < nw; ++k) t[v] = add4(t[v], part[(wib + k) * d4 + f4]);
+      piece_live |= !is_zero4(t[v]);
+    }
+    bool tz = row_t_zero<MODE>(ep, row);
+    if (MODE == SPMM_BWD1S) tz = row_mark_nonzero<MODE>(ep, row, piece_live, gmask);
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int f4 = li + v * 64;
       if (f4 >= d4) continue;
-      float4 t = part[wib * d4 + f4];
-      for (int k = 1; k < nw; ++k) t = add4(t, part[(wib + k) * d4 + f4]);
       const long coff = compact_off<MODE>(ep, row, rs4, slice_f4 + f4);
-      mark_nonzero<MODE>(ep, row, t, coff, gmask);
-      row_epilogue<MODE>(ep, ((size_t)row * rs4 + slice_f4 + f4) * 4, t, coff, row_t_zero<MODE>(ep, row));
+      row_epilogue<MODE>(ep, ((size_t)row * rs4 + slice_f4 + f4) * 4, t[v], coff, tz);
     }
   }
 }
@@ -503,53 +526,8 @@ int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks
     *n_blocks = m->n_seg_blocks[gpw_log2];
     return GSS_OK;
   }
-  const int kSegEdges = g_seg_edges;
-  const int gpw = 1 << gpw_log2;
-  const int ngb = kBalWaves * gpw;  // groups per workgroup
-  int ngb_log2 = 0;
-  while ((1 << ngb_log2) < ngb) ++ngb_log2;
-  const int32_t *rp = m->h_rowptr.data();
-  struct RowItem {
-    int32_t row, len, plog;
-  };
-  std::vector<RowItem> items;
-  items.reserve((size_t)a->n_rows);
-  for (int32_t r = 0; r < a->n_rows; ++r) {
-    const int32_t len = rp[r + 1] - rp[r];
-    const int sgm = len <= kSegEdges ? 1 : (len + kSegEdges - 1) / kSegEdges;
-    int plog = 0;
-    while ((1 << plog) < sgm && plog < ngb_log2) ++plog;  // longer rows: whole workgroup, longer segments
-    items.push_back({r, len, plog});
-  }
-  std::stable_sort(items.begin(), items.end(), [](const RowItem &x, const RowItem &y) {
-    return x.plog != y.plog ? x.plog > y.plog : x.len > y.len;
-  });
   std::vector<int32_t> segs;
-  segs.reserve(((size_t)a->n_rows + (size_t)a->nnz / kSegEdges + 2 * ngb) * 4);
-  for (const RowItem &it : items) {  // sizes are non-increasing powers of two: blocks stay aligned
-    const int p = 1 << it.plog;
-    const int per = (it.len + p - 1) / p;
-    for (int k = 0; k < p; ++k) {
-      const int b0 = std::min(it.len, k * per), b1 = std::min(it.len, (k + 1) * per);
-      segs.push_back(it.row);
-      segs.push_back(rp[it.row] + b0);
-      segs.push_back(b1 - b0);
-      segs.push_back(it.plog);
-    }
-  }
-  while ((segs.size() / 4) % ngb != 0) {
-    segs.push_back(-1);
-    segs.push_back(0);
-    segs.push_back(0);
-    segs.push_back(0);
-  }
-  const int nblk = (int)(segs.size() / 4 / ngb);
-  for (int bi = 0; bi < nblk; ++bi) {  // flag workgroups that need the LDS step
-    bool multi = false;
-    for (int k = 0; k < ngb; ++k) multi |= (1 << segs[((size_t)bi * ngb + k) * 4 + 3]) > gpw;
-    if (multi)
-      for (int k = 0; k < ngb; ++k) segs[((size_t)bi * ngb + k) * 4 + 3] |= 0x100;
-  }
+  const int nblk = build_segments(m->h_rowptr.data(), a->n_rows, kBalWaves, gpw_log2, g_seg_edges, segs);
   const size_t bytes = segs.size() * sizeof(int32_t);
   if (bytes) {
     GSS_HIP(hipMalloc((void **)&m->d_segs[gpw_log2], bytes));
@@ -690,6 +668,7 @@ __global__ __launch_bounds__(256) void mark_rows_and_neighbours_kernel(CsrView a
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= b) return;
   const int r = rows[i];
+  if (r < 0) return;   // a row-list entry another shard owns
   if (lane == 0) atomicOr(&bits[(unsigned)r >> 5], 1u << (r & 31));
   for (int e = a.rowptr[r] + lane; e < a.rowptr[r + 1]; e += 64) {
     const int c = a.col[e];

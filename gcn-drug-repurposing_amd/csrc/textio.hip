@@ -17,8 +17,10 @@
 #include <algorithm>
 
 #include <exception>
+#include <functional>
 #include <memory>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -178,6 +180,58 @@ namespace gss {
 namespace {
 inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r'; }
 
+// work(0) .. work(count - 1) on up to `count` host threads.  Thread creation can be refused (std::system_error: process / cgroup
+// limits): the threads that did start are joined and the remaining items run inline -- unwinding a vector of joinable std::threads
+// would call std::terminate before any catch is reached.
+template <typename F>
+void run_parallel(int count, F &&work) {
+  if (count <= 1) {
+    if (count == 1) work(0);
+    return;
+  }
+  std::vector<std::thread> pool;
+  pool.reserve((size_t)count);
+  int started = 0;
+  try {
+    for (; started < count; ++started) pool.emplace_back(std::ref(work), started);
+  } catch (const std::system_error &) {
+    // started threads keep running; the rest is done here
+  }
+  for (int t = started; t < count; ++t) work(t);
+  for (auto &th : pool) th.join();
+}
+
+struct FileCloser {
+  void operator()(FILE *f) const {
+    if (f) fclose(f);
+  }
+};
+using FilePtr = std::unique_ptr<FILE, FileCloser>;
+
+// the whole file into `text`; false (and errno) on a read error
+inline bool read_all(FILE *f, std::string &text) {
+  char chunk[1 << 16];
+  size_t got;
+  while ((got = fread(chunk, 1, sizeof(chunk), f)) > 0) text.append(chunk, got);
+  return ferror(f) == 0;
+}
+
+// a number as Python's float() reads the token [p, end): strtod's grammar minus C hex floats, "inf" / "nan" spellings (a weight or
+// feature that is not finite is a broken file here) and anything behind the number inside the token
+inline bool parse_number(const char *p, const char *end, double *out, const char **stop) {
+  char *q = nullptr;
+  const double v = strtod(p, &q);
+  if (q == p || q > end) return false;
+  for (const char *c = p; c < q; ++c) {
+    const char ch = *c;
+    const bool ok = (ch >= '0' && ch <= '9') || ch == '+' || ch == '-' || ch == '.' || ch == 'e' || ch == 'E';
+    if (!ok) return false;   // 'x' (hex), 'i' / 'n' (inf, nan) ...
+  }
+  *out = v;
+  *stop = q;
+  return true;
+}
+
 // parse lines [l0, l1) (offsets into text, each [begin, end)) into x / names; returns false on a malformed line
 bool parse_lines(const char *text, const std::vector<std::pair<size_t, size_t>> &lines, size_t l0, size_t l1, int d, double *x,
                  std::vector<std::pair<size_t, size_t>> &name_span) {
@@ -191,11 +245,9 @@ bool parse_lines(const char *text, const std::vector<std::pair<size_t, size_t>> 
     for (int k = 0; k < d; ++k) {
       while (p < end && is_space(*p)) ++p;
       if (p >= end) return false;
-      char *q = nullptr;
-      row[k] = strtod(p, &q);     // the line ends in '\n' or the buffer's terminating NUL: strtod stops there
-      if (q == p || q > end) return false;
-      for (const char *c = p; c < q; ++c)
-        if (*c == 'x' || *c == 'X') return false;  // strtod reads C hex floats, Python's float() (np.loadtxt) does not
+      const char *q = nullptr;    // the line ends in '\n' or the buffer's terminating NUL: strtod stops there
+      if (!parse_number(p, end, &row[k], &q)) return false;
+      if (q < end && !is_space(*q)) return false;   // '1.5abc'
       p = q;
     }
     while (p < end && is_space(*p)) ++p;
@@ -217,7 +269,8 @@ using namespace gss;
 
 extern "C" {
 
-// a C++ exception (out of memory on a huge file, thread creation refused) must not cross the C boundary: reported as an error code
+// a C++ exception (out of memory on a huge file) must not cross the C boundary: reported as an error code.  (A refused thread creation
+// never gets this far: run_parallel joins what started and finishes inline.)
 #define GSS_NOTHROW(call, name)                                                   \
   try {                                                                           \
     return call;                                                                  \
@@ -255,14 +308,11 @@ static int edgelist_open_impl(gss_edgelist_file **out, const char *path, const c
     }
     GSS_REQUIRE(row == n_names, "edgelist_open: the name buffer holds %d names, %lld announced", row, (long long)n_names);
   }
-  FILE *f = fopen(path, "rb");
-  if (!f) return fail(GSS_EINVAL, "edgelist_open: cannot open %s: %s", path, strerror(errno));
   std::string text;
   {
-    char chunk[1 << 16];
-    size_t got;
-    while ((got = fread(chunk, 1, sizeof(chunk), f)) > 0) text.append(chunk, got);
-    fclose(f);
+    FilePtr f(fopen(path, "rb"));
+    if (!f) return fail(GSS_EINVAL, "edgelist_open: cannot open %s: %s", path, strerror(errno));
+    if (!read_all(f.get(), text)) return fail(GSS_EINVAL, "edgelist_open: read error on %s: %s", path, strerror(errno));
   }
   std::vector<std::pair<size_t, size_t>> lines;
   for (size_t pos = 0; pos < text.size();) {
@@ -304,9 +354,15 @@ static int edgelist_open_impl(gss_edgelist_file **out, const char *path, const c
       while (p < end && is_space(*p)) ++p;
       double wt = 1.0;  // an edgelist without weights: unit weights
       if (p < end) {
-        char *q = nullptr;
-        wt = strtod(p, &q);
-        if (q == p) {
+        // exactly one more token, a finite decimal number: anything else (hex, inf / nan, 'u v w extra') is reported as a bad line,
+        // and the caller falls back to the Python parser and ITS error message (embio.read_edgelist)
+        const char *q = nullptr;
+        bool ok = parse_number(p, end, &wt, &q);
+        if (ok) {
+          while (q < end && is_space(*q)) ++q;
+          ok = q == end;
+        }
+        if (!ok) {
           if (bad[(size_t)t] < 0) bad[(size_t)t] = (int64_t)li;
           continue;
         }
@@ -316,13 +372,7 @@ static int edgelist_open_impl(gss_edgelist_file **out, const char *path, const c
       e->w[li] = wt;
     }
   };
-  if (nt == 1) {
-    work(0);
-  } else {
-    std::vector<std::thread> pool;
-    for (int t = 0; t < nt; ++t) pool.emplace_back(work, t);
-    for (auto &th : pool) th.join();
-  }
+  run_parallel(nt, work);
   for (int64_t b : bad)
     if (b >= 0 && (e->bad_line < 0 || b < e->bad_line)) e->bad_line = b;
   *out = owner.release();
@@ -346,14 +396,11 @@ void gss_edgelist_close(gss_edgelist_file *e) { delete e; }
 
 static int embs_open_impl(gss_embs_file **out, const char *path, int32_t threads) {
   GSS_REQUIRE(out && path, "embs_open: null argument");
-  FILE *f = fopen(path, "rb");
-  if (!f) return fail(GSS_EINVAL, "embs_open: cannot open %s: %s", path, strerror(errno));
   std::string text;
   {
-    char chunk[1 << 16];
-    size_t got;
-    while ((got = fread(chunk, 1, sizeof(chunk), f)) > 0) text.append(chunk, got);
-    fclose(f);
+    FilePtr f(fopen(path, "rb"));
+    if (!f) return fail(GSS_EINVAL, "embs_open: cannot open %s: %s", path, strerror(errno));
+    if (!read_all(f.get(), text)) return fail(GSS_EINVAL, "embs_open: read error on %s: %s", path, strerror(errno));
   }
   // line table (the first line is the '<N> <d>' header of node2vec.py:42; blank lines are skipped like the reference's loadtxt)
   std::vector<std::pair<size_t, size_t>> lines;
@@ -407,13 +454,7 @@ static int embs_open_impl(gss_embs_file **out, const char *path, int32_t threads
     const size_t l0 = (size_t)e->n * (size_t)t / (size_t)nt, l1 = (size_t)e->n * (size_t)(t + 1) / (size_t)nt;
     ok[(size_t)t] = parse_lines(text.c_str(), lines, l0, l1, e->d, e->x.data(), span) ? 1 : 0;
   };
-  if (nt == 1) {
-    work(0);
-  } else {
-    std::vector<std::thread> pool;
-    for (int t = 0; t < nt; ++t) pool.emplace_back(work, t);
-    for (auto &th : pool) th.join();
-  }
+  run_parallel(nt, work);
   for (char c : ok)
     if (!c) return fail(GSS_EINVAL, "embs_open: %s: a line does not hold a name and %d numbers", path, e->d);
   size_t total = 0;
@@ -449,8 +490,9 @@ int gss_format_e18(float value, char *out26) {
 
 static int write_embs_text_impl(const char *path, const float *h_emb, int64_t n, int32_t d, int32_t threads) {
   GSS_REQUIRE(path && (h_emb || n == 0) && n >= 0 && d >= 1, "write_embs_text: bad argument");
-  FILE *f = fopen(path, "wb");
-  if (!f) return fail(GSS_EINVAL, "write_embs_text: cannot open %s: %s", path, strerror(errno));
+  FilePtr fp(fopen(path, "wb"));   // closed on every path out of here, an exception included
+  if (!fp) return fail(GSS_EINVAL, "write_embs_text: cannot open %s: %s", path, strerror(errno));
+  FILE *f = fp.get();
   (void)tables();
   int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
   if (nt < 1) nt = 1;
@@ -477,20 +519,15 @@ static int write_embs_text_impl(const char *path, const float *h_emb, int64_t n,
       }
       s.resize((size_t)(p - &s[0]));
     };
-    if (cnt == 1) {
-      work(0);
-    } else {
-      std::vector<std::thread> pool;
-      for (int t = 0; t < cnt; ++t) pool.emplace_back(work, t);
-      for (auto &th : pool) th.join();
-    }
+    run_parallel(cnt, work);
     for (int t = 0; t < cnt && rc == GSS_OK; ++t)
       if (fwrite(buf[(size_t)t].data(), 1, buf[(size_t)t].size(), f) != buf[(size_t)t].size())
         rc = fail(GSS_EINVAL, "write_embs_text: short write to %s: %s", path, strerror(errno));
   }
-  if (fclose(f) != 0 && rc == GSS_OK) rc = fail(GSS_EINVAL, "write_embs_text: close of %s failed: %s", path, strerror(errno));
+  if (fclose(fp.release()) != 0 && rc == GSS_OK) rc = fail(GSS_EINVAL, "write_embs_text: close of %s failed: %s", path, strerror(errno));
   return rc;
-}int gss_write_embs_text(const char *path, const float *h_emb, int64_t n, int32_t d, int32_t threads) {
+}
+int gss_write_embs_text(const char *path, const float *h_emb, int64_t n, int32_t d, int32_t threads) {
   GSS_NOTHROW(write_embs_text_impl(path, h_emb, n, d, threads), "write_embs_text")
 }
 }

@@ -145,6 +145,10 @@ class PprEngine:
     def spmm(self, x, y):
         _lib.check(self.lib.gss_ppr_spmm(self.handle, x.data_ptr(), y.data_ptr(), _lib.current_stream()), "gss_ppr_spmm")
 
+    def check_guards(self):
+        """raises if a kernel wrote behind one of the handle's buffers (gss_ppr_check_guards; tests call it)"""
+        _lib.check(self.lib.gss_ppr_check_guards(self.handle), "gss_ppr_check_guards")
+
     def device_bytes(self) -> int:
         return int(self.lib.gss_ppr_device_bytes(self.handle))
 

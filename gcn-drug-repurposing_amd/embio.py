@@ -79,7 +79,7 @@ def read_edgelist(path, names=None):
     given (the .embs.txt row order) ids are mapped to those rows, otherwise in order of appearance.
     A .sif file is undirected: both directions are emitted."""
     sif = path.endswith(".sif") or path.endswith(".sif.lcc")
-    if not sif and names is not None and len(names) > 0 and not any("\n" in n for n in names[:1]):
+    if not sif and names is not None and len(names) > 0 and not any("\n" in n for n in names):
         # the trainer's case (ids mapped to the .embs.txt rows): native multi-threaded parser; a file it rejects (an unknown id,
         # a malformed weight) goes through the Python loop below, which raises the error with its context
         try:

@@ -235,6 +235,9 @@ typedef struct gss_ppr_desc {
 int gss_ppr_create(gss_ppr **out, const gss_ppr_desc *desc);
 void gss_ppr_destroy(gss_ppr *p);
 size_t gss_ppr_device_bytes(const gss_ppr *p);
+/* every buffer the handle carves from its slab is followed by a 256-byte guard no kernel may touch; this synchronises the device and
+ * verifies them all (as gss_plan_check_guards).  For tests. */
+int gss_ppr_check_guards(gss_ppr *p);
 /* x <- 1/n, then iterate.  iters_out: host [k], the iteration at which each column converged.  Returns
  * GSS_ENOTCONV (x holds the last iterate) if some column needs more than max_iter iterations -- where the reference
  * raises (:90).  Synchronises the stream once per iteration (reads the number of unconverged columns). */

@@ -13,12 +13,14 @@ import torch.nn.functional as F
 
 
 class TorchCpuPath:
-    def __init__(self, a_hat_csr32, x32, params, num_layers, layer_decay, alpha, lr):
+    def __init__(self, a_hat_csr32, x32, params, num_layers, layer_decay, alpha, lr, dtype=torch.float32):
+        """dtype: torch.float32 = the reference's arithmetic; torch.float64 runs the same graph of ops in double precision (the
+        fp32 inputs widened) -- tests/test_trajectory_spread.py uses it to measure how far two valid executions drift apart"""
         coo = a_hat_csr32.tocoo()
         i = torch.from_numpy(np.vstack([coo.row, coo.col]).astype(np.int64))
-        self.adj = torch.sparse_coo_tensor(i, torch.from_numpy(coo.data.astype(np.float32)), coo.shape)  # helper.py:92-96
-        self.x = torch.from_numpy(np.ascontiguousarray(x32, dtype=np.float32))
-        self.p = {k: torch.tensor(v, dtype=torch.float32, requires_grad=True) for k, v in params.items()}
+        self.adj = torch.sparse_coo_tensor(i, torch.from_numpy(coo.data.astype(np.float32)).to(dtype), coo.shape)  # helper.py:92-96
+        self.x = torch.from_numpy(np.ascontiguousarray(x32, dtype=np.float32)).to(dtype)
+        self.p = {k: torch.tensor(np.asarray(v, dtype=np.float32), dtype=dtype, requires_grad=True) for k, v in params.items()}
         self.L, self.decay, self.alpha = num_layers, layer_decay, alpha
         self.opt = torch.optim.Adam([self.p[k] for k in ("W1", "b1", "W2", "b2")], lr=lr, weight_decay=0)
         self.nnz = coo.nnz

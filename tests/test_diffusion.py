@@ -174,3 +174,37 @@ def test_gpu_class_end_to_end_on_the_msi_tables(gold, tmp_path):
     got = np.stack([dp.drug_or_indication2diffusion_profile[s] for s in names])
     assert np.abs(got - gold["profiles"]).max() < 1e-13
     assert os.path.exists(tmp_path / "dp" / "node2idx.pkl")
+
+
+@pytest.mark.gpu
+def test_gpu_ppr_workspace_guards_over_a_size_sweep():
+    """VERDICT round 2, weak spot 9: the plan's buffers had guards, gss_ppr_*'s slab had none.  Random small problems over the sizes
+    that decide its carve -- nodes around the 64-row block size, start nodes around the 64-column padding, with and without empty rows
+    and surviving in-edges -- each checked against the oracle, each followed by gss_ppr_check_guards."""
+    from gcn_drug_repurposing_amd.diffusion import PprEngine, PprProblem
+    from oracle import diffusion_oracle as O
+    rng = np.random.RandomState(17)
+    hp = (0.85, 500, 1e-9)
+    for n, n_start in ((5, 1), (63, 3), (64, 64), (65, 65), (129, 2), (200, 70), (333, 129)):
+        n_start = min(n_start, n // 2)
+        dens = min(1.0, 6.0 / n)
+        a = sp.random(n, n, density=dens, random_state=rng, format="csr")
+        a = sp.csr_matrix(a + a.T)
+        a.setdiag(0)
+        a.eliminate_zeros()
+        m0 = sp.csr_matrix(a)
+        m0.data = rng.rand(m0.nnz) + 0.1
+        starts = np.arange(n_start)
+        # start nodes touch only non-start nodes ('proteins'), as drugs / indications do in the MSI: drop edges among start nodes
+        m0 = sp.lil_matrix(m0)
+        m0[:n_start, :n_start] = 0
+        m0 = sp.csr_matrix(m0)
+        m0.eliminate_zeros()
+        prot = {int(s): [int(c) for c in m0.indices[m0.indptr[s]:m0.indptr[s + 1]]] for s in starts}
+        eng = PprEngine(PprProblem(m0, starts, prot))
+        x, it = eng.run(*[hp[0], hp[2], hp[1]])
+        eng.check_guards()
+        got = x[:, :n_start].t().contiguous().cpu().numpy()
+        for c in (0, n_start - 1):
+            ref, ref_it = O.diffusion_profile(m0, int(starts[c]), prot, *hp)
+            assert np.abs(got[c] - ref).max() < 1e-13 and it[c] == ref_it, (n, n_start, c)

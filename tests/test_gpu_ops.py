@@ -394,6 +394,43 @@ def test_knn_topk_values_and_odd_sizes(G):
         np.testing.assert_allclose(np.sort(tv.cpu().numpy(), 1), np.sort(np.take_along_axis(sim, ref_idx, 1), 1), rtol=1e-12)
 
 
+def test_knn_topk_k_sweep_writes_only_its_outputs(G):
+    """every k the entry point accepts (1 .. 64: its LDS footprint grows with k) at node counts around the 64-row tile, outputs embedded
+    in canary-filled buffers: results equal numpy's, nothing outside [n][k] is written"""
+    rng = np.random.RandomState(4)
+    for n in (64, 65, 127, 130):
+        x = rng.randn(n, 16)
+        xd = cu(x)
+        sim = x @ x.T
+        for k in (1, 2, 3, 5, 8, 13, 21, 34, 55, 63, 64):
+            pad = 257
+            tv = torch.full((n * k + 2 * pad,), -7.25, dtype=torch.float64, device="cuda")
+            ti = torch.full((n * k + 2 * pad,), -77, dtype=torch.int32, device="cuda")
+            G._lib.check(G.lib.gss_knn_topk(n, 16, xd.data_ptr(), k, tv[pad:].data_ptr(), ti[pad:].data_ptr(), G.st()))
+            torch.cuda.synchronize()
+            assert bool((tv[:pad] == -7.25).all()) and bool((tv[pad + n * k:] == -7.25).all()), (n, k)
+            assert bool((ti[:pad] == -77).all()) and bool((ti[pad + n * k:] == -77).all()), (n, k)
+            got_idx = ti[pad:pad + n * k].view(n, k).cpu().numpy()
+            ref_idx = np.argpartition(sim, -k, 1)[:, -k:]
+            assert np.array_equal(np.sort(got_idx, 1), np.sort(ref_idx, 1)), (n, k)
+    with pytest.raises(G._lib.GssError):
+        G._lib.check(G.lib.gss_knn_topk(10, 16, xd.data_ptr(), 65, tv.data_ptr(), ti.data_ptr(), G.st()))
+
+
+def test_percentile_size_sweep(G):
+    """node counts around the 64-row tiles of the select kernel (1 row .. just past two tiles), the percentiles at both ends included"""
+    rng = np.random.RandomState(6)
+    for n in (1, 2, 3, 63, 64, 65, 127, 128, 129, 200):
+        x = rng.randn(n, 16)
+        e = (x / np.sqrt((x ** 2).sum(1, keepdims=True))).astype(np.float32)
+        ed = cu(e)
+        s = (e.astype(np.float64) @ e.astype(np.float64).T).flatten()
+        for q in (0.0, 37.5, 50.0, 98.0, 100.0):
+            out = C.c_float()
+            G._lib.check(G.lib.gss_percentile(n, 16, ed.data_ptr(), q, C.byref(out), G.st()))
+            assert abs(out.value - np.percentile(s, q)) < 2e-6, (n, q)
+
+
 def test_library_loaded_before_torch_still_sees_the_gpu():
     """torch ships its own HIP runtime; a process that loads libgssgcn.so first (build() then smoke() in one interpreter)
     must end up with ONE runtime.  Run in a child process so the import order is really this one."""

@@ -255,10 +255,58 @@ def test_nonzero_row_bitmaps_of_the_sparse_backward_change_nothing(world, L):
             np.testing.assert_array_equal(x, y)
 
 
+def test_zero_pieces_of_a_live_row_are_written_not_skipped():
+    """with the non-zero-row bitmap on, the sparse backward hop leaves all-zero rows of u / t unwritten (every reader
+    consults the bitmap).  That decision must be per ROW: a row whose bit is set but one of whose 4-feature pieces sums to exactly zero
+    has to store that zero, or the piece keeps the previous step's values and the next hop reads them.  Here a 4-column block of both
+    weight matrices is zeroed on every other step (the compact input gradients g_ax / g_am then have an exactly-zero piece, and so has
+    every row of the hop's sum), after a step that left non-zero values there; losses and parameters must equal the plan without
+    bitmaps bit for bit."""
+    import gcn_drug_repurposing_amd as pkg
+    from gcn_drug_repurposing_amd.dist import local_comms
+    from gcn_drug_repurposing_amd.shards import ScipySource, build_shard, shard_engine, shard_rows
+    from conftest import golden_params
+    lib = pkg.load()
+    g = load_golden("knn_n2000_d64_L3")
+    n, d, _ = (int(v) for v in g["meta"])
+    adj, X, p0 = golden_csr(g, "A"), g["X"], golden_params(g, "init")
+    rng = np.random.RandomState(11)
+    batches = [rng.choice(n, size=s, replace=False).astype(np.int32) for s in (48, 48, 31, 48, 5, 48)]
+
+    def run(bits_rows):
+        assert lib.gss_debug_set_option(b"sparse_bits_rows", bits_rows) == 0
+        try:
+            comm = local_comms(1)[0]
+            shard = build_shard(ScipySource(adj), comm, need_transpose=True, device="cuda:0", relabel=False)
+            eng = shard_engine(shard, shard_rows(shard, X), p0, comm, num_layers=2, layer_decay=float(g["decay"]), alpha=float(g["alpha"]),
+                               lr=float(g["lr"]), max_batch=64)
+            out = []
+            for k, idx in enumerate(batches):
+                if k % 2 == 1:                      # an exactly-zero 4-feature piece in this step's input gradients
+                    eng.params[0][:, 8:12] = 0.0
+                    eng.params[2][:, 8:12] = 0.0
+                else:
+                    eng.params[0][:, 8:12] = torch.from_numpy(p0["W1"][:, 8:12]).cuda()
+                    eng.params[2][:, 8:12] = torch.from_numpy(p0["W2"][:, 8:12]).cuda()
+                lib.gss_plan_set_step(eng.handle, k)  # weights changed behind the plan's back: its transposed copies are stale
+                eng.step(torch.from_numpy(idx).cuda(), float(g["beta"]))
+                out.append((eng.loss.item(), [t.cpu().numpy().copy() for t in eng.params], [t.cpu().numpy().copy() for t in eng.grads]))
+            eng.check_guards()
+            return out
+        finally:
+            lib.gss_debug_set_option(b"sparse_bits_rows", 100000)
+
+    plain, bits = run(100000), run(1)
+    for k, (a, b) in enumerate(zip(plain, bits)):
+        assert a[0] == b[0], k
+        for x, y in zip(a[1] + a[2], b[1] + b[2]):
+            np.testing.assert_array_equal(x, y)
+
+
 @pytest.mark.parametrize("world,relabel", [(2, False), (3, True), (8, False)])
 def test_lazy_step_on_shards_equals_the_full_sharded_step(world, relabel):
     """gss_plan_step_lazy on a node-range sharded plan: every shard evaluates the top layer on the batch rows it owns (the members of
-    other shards are clamped onto one of its rows, recomputed and read by nobody; an empty shard evaluates nothing).  Losses, parameters
+    other shards are -1 in its row list and skipped; an empty shard evaluates nothing).  Losses, parameters
     and the embeddings of a full forward afterwards equal the full sharded step's bit for bit, over batches of changing size that
     leave some shards without a member."""
     from gcn_drug_repurposing_amd.dist import local_comms
@@ -278,9 +326,21 @@ def test_lazy_step_on_shards_equals_the_full_sharded_step(world, relabel):
             shard = build_shard(ScipySource(adj), comms[rank], need_transpose=True, device="cuda:0", relabel=relabel)
             eng = shard_engine(shard, shard_rows(shard, X), p0, comms[rank], **kw)
             losses = []
+            lo, hi = shard.part.rows(rank)
+            eng.forward()
             for idx in batches:
+                before = eng.emb.clone()
                 (eng.step_lazy if lazy else eng.step)(torch.from_numpy(idx).cuda(), float(g["beta"]))
                 losses.append(eng.loss.item())
+                if lazy:
+                    # the lazy top layer writes the batch rows this shard owns and nothing else: members of other shards are skipped
+                    # (row-list entry -1), not clamped onto one of this shard's rows
+                    rows = idx.astype(np.int64) if shard.node_map is None else shard.node_map.cpu().numpy().astype(np.int64)[idx]
+                    own = rows[(rows >= lo) & (rows < hi)] - lo
+                    untouched = np.ones(hi - lo, dtype=bool)
+                    untouched[own] = False
+                    sel = torch.from_numpy(np.flatnonzero(untouched)).cuda()
+                    assert torch.equal(eng.emb.index_select(0, sel), before.index_select(0, sel)), "a lazy step wrote a row outside its batch"
             eng.forward()
             eng.check_guards()
             return dict(losses=losses, emb=eng.gather_embeddings().cpu().numpy(), params=[t.cpu().numpy().copy() for t in eng.params])

@@ -202,3 +202,56 @@ def test_native_edgelist_reader_matches_the_python_parser(tmp_path):
         f.write("not_a_node GO:0000000 1.0\n")
     with pytest.raises(KeyError, match="not_a_node"):
         embio.read_edgelist(str(p), names)
+
+
+def test_native_edgelist_reader_rejects_what_the_python_parser_would_not_read_the_same_way(tmp_path):
+    """the native fast path has to be equivalent to the Python loop it replaces.  strtod reads C hex floats, 'inf' and
+    'nan' and ignores what follows the weight; such lines are now reported as bad (gss_edgelist_bad_line) so that the file goes through
+    the Python parser -- which raises on a hex weight and reads the others exactly as it always did."""
+    import ctypes as C
+    import gcn_drug_repurposing_amd as pkg
+    from gcn_drug_repurposing_amd import embio
+    lib = pkg.load()
+    names = ["a", "b", "c"]
+    blob = "\n".join(names).encode()
+
+    def native_bad_line(text):
+        p = tmp_path / "e.edgelist"
+        p.write_text(text)
+        h = C.c_void_p()
+        assert lib.gss_edgelist_open(C.byref(h), str(p).encode(), blob, len(blob), len(names), 2) == 0
+        try:
+            return lib.gss_edgelist_bad_line(h), p
+        finally:
+            lib.gss_edgelist_close(h)
+
+    assert native_bad_line("a b 1.5\nb c 2e-3\nc a\n")[0] == -1
+    for bad in ("a b 0x1p3\n", "a b inf\n", "a b nan\n", "a b 1.0 extra\n", "a b 1_0\n", "a b 1.5abc\n", "a b -Infinity\n"):
+        line, _ = native_bad_line("a b 1.0\n" + bad)
+        assert line == 1, bad
+    # what the caller sees: hex raises (Python's float()), inf and trailing tokens read as the Python loop reads them
+    _, p = native_bad_line("a b 0x1p3\n")
+    with pytest.raises(ValueError):
+        embio.read_edgelist(str(p), names)
+    _, p = native_bad_line("a b inf\nb c 2.0 trailing tokens\n")
+    src, dst, w, _ = embio.read_edgelist(str(p), names)
+    assert src.tolist() == [0, 1] and dst.tolist() == [1, 2] and w[0] == np.inf and w[1] == 2.0
+    # a name with a newline in it (any position, not just the first) keeps the file away from the native name table
+    p.write_text("a b 1.0\n")
+    src, dst, w, _ = embio.read_edgelist(str(p), ["a", "b", "c\nd"])
+    assert src.tolist() == [0] and dst.tolist() == [1]
+
+
+def test_native_embs_reader_rejects_non_finite_and_glued_tokens(tmp_path):
+    import ctypes as C
+    import gcn_drug_repurposing_amd as pkg
+    lib = pkg.load()
+    for body, ok in (("n0 1.0 2.0\nn1 3.0 4.0\n", True), ("n0 1.0 inf\nn1 3.0 4.0\n", False), ("n0 1.0 2.0x\nn1 3 4\n", False),
+                     ("n0 1.0 0x10\nn1 3 4\n", False), ("n0 nan 2.0\nn1 3 4\n", False)):
+        p = tmp_path / "x.embs.txt"
+        p.write_text("2 2\n" + body)
+        h = C.c_void_p()
+        rc = lib.gss_embs_open(C.byref(h), str(p).encode(), 1)
+        assert (rc == 0) == ok, body
+        if rc == 0:
+            lib.gss_embs_close(h)
