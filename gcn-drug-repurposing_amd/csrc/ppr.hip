@@ -54,12 +54,18 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 template <bool NARROW>
 __global__ __launch_bounds__(kPprThreads) void ppr_spmm_kernel(const int32_t *__restrict__ col, const double *__restrict__ val,
                                                                const int4 *__restrict__ segs, const double *__restrict__ x,
-                                                               double *__restrict__ y, int kpad) {
+                                                               double *__restrict__ y, int kpad, const int32_t *__restrict__ done) {
   __shared__ double2 part[kPprWaves * 16];
   constexpr int LPR = 16, LOG = 4, GPW = 4;
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int g = lane >> LOG, li = lane & (LPR - 1);
   const int sblk = blockIdx.x >> 1, half = blockIdx.x & 1;
+  // gss_ppr_run: columns converge independently and are frozen (ppr_update_kernel leaves them alone); a workgroup whose 32 columns
+  // have all converged has nothing left to produce (padding columns count as converged from the start).  Workgroup-uniform.
+  if (done) {
+    const int c0 = blockIdx.y * 64 + half * 32;
+    if (__all(done[c0 + (lane & 31)] != 0)) return;
+  }
   const int4 sd = segs[((size_t)sblk * kPprWaves + wib) * GPW + g];  // {row, first entry, entries, flags | log2 p}
   const int row = sd.x;
   const int e0 = sd.y, e1 = sd.y + sd.z;
@@ -259,7 +265,7 @@ __global__ void ppr_finish_kernel(const double *__restrict__ part, int n_blocks,
   }
 }
 
-static int ppr_spmm_launch(gss_ppr *p, const double *x, double *y, hipStream_t st) {
+static int ppr_spmm_launch(gss_ppr *p, const double *x, double *y, hipStream_t st, const int32_t *done = nullptr) {
   const int4 *segs = nullptr;
   int nblk = 0;
   if (int rc = csr_segments(p->csr, 2, &segs, &nblk)) return rc;
@@ -267,10 +273,10 @@ static int ppr_spmm_launch(gss_ppr *p, const double *x, double *y, hipStream_t s
   const bool narrow = (double)p->d.n * p->d.kpad * 8.0 < 4.0e9 && p->d.n < (1 << 24) && (int64_t)p->d.kpad * 8 < (1 << 24);
   if (narrow)
     hipLaunchKernelGGL(ppr_spmm_kernel<true>, dim3(nblk * 2, p->d.kpad / 64), dim3(kPprThreads), 0, st, p->d.t_col, p->d.t_val, segs, x, y,
-                       p->d.kpad);
+                       p->d.kpad, done);
   else
     hipLaunchKernelGGL(ppr_spmm_kernel<false>, dim3(nblk * 2, p->d.kpad / 64), dim3(kPprThreads), 0, st, p->d.t_col, p->d.t_val, segs, x, y,
-                       p->d.kpad);
+                       p->d.kpad, done);
   GSS_LAUNCH_CHECK("ppr_spmm_kernel");
   return GSS_OK;
 }
@@ -401,7 +407,7 @@ int gss_ppr_run(gss_ppr *p, double alpha, double tol, int32_t max_iter, double *
     hipLaunchKernelGGL(ppr_column_kernel, dim3(ceil_div(D.k, 64)), dim3(64), 0, st, x, p->part, D.n_z > 0 ? p->n_zchunks : 0, p->stash_o,
                        D.zero_ptr, D.zero_ovr, D.start, D.start_dangling, D.keep_ptr, D.keep_row, D.keep_val, D.k, D.kpad, p->dsum, p->yself);
     GSS_LAUNCH_CHECK("ppr_column_kernel");
-    if (int rc = ppr_spmm_launch(p, x, p->y, st)) return rc;
+    if (int rc = ppr_spmm_launch(p, x, p->y, st, p->done)) return rc;   // converged 32-column groups are skipped
     if (D.n_ovr > 0) {
       hipLaunchKernelGGL(ppr_ovr_restore_kernel, dim3(ceil_div(D.n_ovr, 256)), dim3(256), 0, st, x, D.ovr_col, D.ovr_row, (long)D.n_ovr, D.kpad,
                          p->stash_o);

@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
+import tolerances as T
 from conftest import golden_batches, golden_csr, golden_params, load_golden
 
 torch = pytest.importorskip("torch")
@@ -82,10 +83,12 @@ def test_product_shards_as_gloo_processes_match_reference_trajectory(tmp_path, w
         assert outs[r]["lo"] == outs[r - 1]["hi"]
         for k in ("losses", "emb", "W1", "b1", "W2", "b2"):     # replicated state stays identical across ranks
             np.testing.assert_array_equal(outs[r][k], outs[0][k])
-    np.testing.assert_allclose(outs[0]["losses"], g["losses"], rtol=2e-4, atol=1e-8)
-    assert np.abs(outs[0]["emb"] - g["emb_last"]).max() / np.abs(g["emb_last"]).max() < 2e-3
-    for k in ("W1", "W2"):
-        assert np.abs(outs[0][k] - g["final_" + k]).max() < 2.5 * float(g["lr"])
+    # the mirror computes every op in fp64 and rounds to fp32 between ops: inside the spread between fp32 and fp64 executions of the
+    # reference's ops that tests/tolerances.py records
+    np.testing.assert_allclose(outs[0]["losses"], g["losses"], rtol=T.TRAJ_LOSS_RTOL, atol=1e-9)
+    assert np.abs(outs[0]["emb"] - g["emb_last"]).max() / np.abs(g["emb_last"]).max() < T.TRAJ_EMB_REL
+    for k in ("W1", "b1", "W2", "b2"):
+        assert np.abs(outs[0][k] - g["final_" + k]).max() < T.TRAJ_WEIGHT_LR * float(g["lr"])
     # what the step moves is what the halo layout announces (include/gssgcn.h, gss_plan_create_sharded): per step 2L - 2 exchanges of
     # A_hat's halo + 2L - 3 of A_hat^T's; the first step also fetches the constant boundary rows of X_0 and M_0
     steady = (2 * L - 2) + max(0, 2 * L - 3)
