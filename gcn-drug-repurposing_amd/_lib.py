@@ -40,7 +40,7 @@ class HaloDesc(C.Structure):
 
 class ShardDesc(C.Structure):
     _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("h_bounds", C.c_void_p), ("halo_a", HaloDesc), ("halo_at", HaloDesc),
-                ("d_gid2op_t", C.c_void_p)]
+                ("d_gid2op_t", C.c_void_p), ("a_own", C.c_void_p), ("a_halo", C.c_void_p), ("at_own", C.c_void_p), ("at_halo", C.c_void_p)]
 
 
 class PlanIO(C.Structure):
@@ -60,6 +60,7 @@ SIGNATURES = {
     "gss_csr_destroy": (None, [_P]),
     "gss_csr_set_hot": (C.c_int, [_P, _I32, _I32, _I32]),
     "gss_spmm": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P]),
+    "gss_spmm_add": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P]),
     "gss_spmm_bwd1": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "gss_spmm_bwd2": (C.c_int, [_P, _I32, _P, _P, _P, _F, _P, _P, _P, _P]),
     "gss_spmm_bwd1_sparse": (C.c_int, [_P, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -91,7 +91,7 @@ int gss_debug_set_option(const char *name, int value) {
     return GSS_OK;
   }
   if (strcmp(name, "gemm_prio") == 0) {
-    GSS_REQUIRE(value >= 0, "gemm_prio must be >= 0 (0 = off)");
+    GSS_REQUIRE(value >= -1, "gemm_prio must be >= -1 (0 = off, -1 = by wave slot)");
     g_gemm_prio = value;
     return GSS_OK;
   }

@@ -274,6 +274,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
   // lockstep: shared MFMA pipe at half rate each, then both store at once.  With the first generation at a higher wave priority it
   // takes the pipe, finishes early and stores while the second generation computes (MI355X guide, 'static priority').  Speed only.
   if (g.prio_cut > 0 && linear < g.prio_cut) __builtin_amdgcn_s_setprio(3);
+  // prio_cut < 0: by wave slot instead -- the waves a SIMD received first (even HW_ID.wave_id) win the pipe, whatever the dispatch order was
+  if (g.prio_cut < 0 && (__builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11)) & 1u) == 0u) __builtin_amdgcn_s_setprio(3);
   const int node_base = id.spread * BM;
   const int j0 = id.share * BN;
   const int jh = j0 >= g.jsplit ? 1 : 0;

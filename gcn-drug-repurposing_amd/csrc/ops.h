@@ -40,14 +40,19 @@ struct gss_comm {
 namespace gss {
 // nnz-balanced segment descriptors of a CSR for 2^gpw_log2 lane groups per wave (spmm.hip; cached in the handle)
 int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks);
+// Two-pass products (a shard's hop overlapped with its halo exchange, plan.hip): the rows' entries are split over two CSRs of the
+// same rows; the first pass is a plain product into `y`, the second pass -- any mode -- takes it as y_in, adds its own sums and
+// runs the epilogue.  y_in may be the buffer the second pass writes.
 int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream,
-             const int32_t *row_pos = nullptr,   // plain product only: compute rows with row_pos[row] >= 0 only
-             const uint32_t *row_bits = nullptr); // Hadamard-fused product only: compute rows whose bit is set only
+             const int32_t *row_pos = nullptr,    // plain product only: compute rows with row_pos[row] >= 0 only
+             const uint32_t *row_bits = nullptr,  // Hadamard-fused product only: compute rows whose bit is set only
+             const float *y_in = nullptr,
+             const uint32_t *gather_bits = nullptr);  // plain product only: neighbours whose bit is clear are skipped (their rows are zero)
 int mark_rows_and_neighbours(const gss_csr *a, const int32_t *rows, int32_t b, uint32_t *bits, void *stream);
 int spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
-              float *u, float *t, void *stream);
+              float *u, float *t, void *stream, const float *y_in = nullptr);
 int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
-              float *dp, float *gx_out, void *stream);
+              float *dp, float *gx_out, void *stream, const float *y_in = nullptr);
 int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
               const float *b2, const float *p_prev, float decay, float *p, float *x_next, void *stream,
               const int32_t *row_list = nullptr);  // row_list: the n tile rows are node rows row_list[0..n) of every operand; a negative
@@ -88,7 +93,8 @@ int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const fl
 int batch_bits(const int32_t *ids, int32_t b, uint32_t *bits, int set, void *stream);
 bool spmm_sparse_available();
 int spmm_bwd2_sparse_res(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res_b,
-                         const int32_t *pos_row, float *dp, float *gx_out, void *stream, const uint32_t *nzbits = nullptr);
+                         const int32_t *pos_row, float *dp, float *gx_out, void *stream, const uint32_t *nzbits = nullptr,
+                         const float *y_in = nullptr);
 // rlist (nullable): per member the local row when this shard owns it, -1 otherwise -- the row list of the lazy top layer
 int batch_prepare(const int32_t *idx, int32_t b, const int32_t *node_map, int32_t lo, int32_t nl, const int32_t *gid2op, int32_t *rloc,
                   int32_t *pid, float *keep, int32_t *pos, void *stream, int32_t *rlist = nullptr);

@@ -78,6 +78,11 @@ struct gss_plan {
   int32_t *rlist;          // shards, gss_plan_step_lazy: per member its local row when this shard owns it, -1 otherwise (the top layer's row list)
   float *keep;             // per batch: 1.0 where this shard owns the member
   float *gab;              // [2 * max_batch][d]: the top layer's compact input gradients, all-reduced as one buffer
+  // overlapped hops (gss_shard_desc a_own / a_halo / at_own / at_halo): the boundary rows of a hop travel on `xs` while the entries
+  // that reference the shard's own rows are multiplied on the caller's stream; the boundary-column entries are added afterwards
+  const gss_csr *a_own, *a_halo, *at_own, *at_halo;
+  hipStream_t xs;
+  hipEvent_t ev_ready, ev_halo;
 };
 
 // debug knob "sparse_bits_rows": operand rows from which a plan keeps the two bitmaps of the sparsity-aware backward hops (the
@@ -266,6 +271,18 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
               (long long)(desc->n + ha));
   GSS_REQUIRE(desc->num_layers == 1 || (at && at->n_rows == desc->n && at->n_cols == desc->n + hat),
               "plan_create: A^T missing or mis-shaped (needed for num_layers >= 2)");
+  if (shard && P > 1) {
+    const gss_csr *pairs[2][3] = {{shard->a_own, shard->a_halo, a}, {shard->at_own, shard->at_halo, at}};
+    for (int m = 0; m < 2; ++m) {
+      const gss_csr *own = pairs[m][0], *hal = pairs[m][1], *full = pairs[m][2];
+      GSS_REQUIRE((own == nullptr) == (hal == nullptr), "plan_create_sharded: the own-column and boundary-column halves of a matrix go together");
+      if (!own || !full) continue;
+      GSS_REQUIRE(own->n_rows == full->n_rows && hal->n_rows == full->n_rows && own->n_cols == full->n_cols && hal->n_cols == full->n_cols &&
+                      own->nnz + hal->nnz == full->nnz,
+                  "plan_create_sharded: the split halves of %s do not add up to the matrix (%lld + %lld entries of %lld)", m ? "A_hat^T" : "A_hat",
+                  (long long)own->nnz, (long long)hal->nnz, (long long)full->nnz);
+    }
+  }
   gss_plan *p = new gss_plan();
   p->desc = *desc;
   p->comm = P > 1 ? comm : nullptr;
@@ -280,6 +297,17 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
   p->rows_a = (size_t)desc->n + (size_t)ha;
   p->rows_t = (size_t)desc->n + (size_t)hat;
   p->gid2op_t = (P > 1 && desc->num_layers > 1) ? shard->d_gid2op_t : nullptr;
+  p->a_own = p->a_halo = p->at_own = p->at_halo = nullptr;
+  p->xs = nullptr;
+  p->ev_ready = p->ev_halo = nullptr;
+  if (P > 1 && shard->a_own && shard->a_halo) {
+    p->a_own = shard->a_own;
+    p->a_halo = shard->a_halo;
+  }
+  if (P > 1 && desc->num_layers > 1 && shard->at_own && shard->at_halo) {
+    p->at_own = shard->at_own;
+    p->at_halo = shard->at_halo;
+  }
   p->x0_ready = false;
   p->m0_ready = false;
   p->a = a;
@@ -348,6 +376,16 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
       return fail(GSS_EHIP, "plan_create: side stream/events -> %s", hipGetErrorString(e));
     }
   }
+  if (p->a_own || p->at_own) {
+    e = hipStreamCreateWithFlags(&p->xs, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_halo, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      (void)hipFree(p->slab);
+      delete p;
+      return fail(GSS_EHIP, "plan_create: exchange stream/events -> %s", hipGetErrorString(e));
+    }
+  }
   if (p->pos) {
     e = hipMemset(p->pos, 0xff, sizeof(int32_t) * (p->rows_t ? p->rows_t : 1));  // all -1
     if (e != hipSuccess) {
@@ -393,6 +431,25 @@ int plan_halo(gss_plan *p, const gss_plan::Halo &h, float *op, void *stream) {
   if (h.n_send > 0)
     if (int rc = pack_rows(d, op, h.d_send_rows, h.n_send, p->sendbuf, stream)) return rc;
   return p->comm->exchange_rows(p->sendbuf, h.send_off.data(), op + (size_t)p->desc.n * d, h.recv_off.data(), d, as_stream(stream));
+}
+
+// One hop over an operand whose boundary rows come from the peers.  Plain form: exchange, then `full` (the product over the shard's
+// whole CSR).  Overlapped form (the matrix was given split, gss_shard_desc): the exchange runs on p->xs while `own` multiplies the
+// entries that reference the shard's own rows -- complete as soon as the producing kernel is --, then `rest` adds the boundary-column
+// entries and runs the epilogue.  Both streams are re-joined before `rest`, so everything after the hop is ordered as before.
+template <typename Full, typename Own, typename Rest>
+int plan_hop(gss_plan *p, const gss_plan::Halo &h, bool overlapped, float *op, void *stream, Full full, Own own, Rest rest) {
+  if (p->P == 1 || !overlapped) {
+    if (int rc = plan_halo(p, h, op, stream)) return rc;
+    return full();
+  }
+  GSS_HIP(hipEventRecord(p->ev_ready, as_stream(stream)));     // the operand's own rows are complete here
+  GSS_HIP(hipStreamWaitEvent(p->xs, p->ev_ready, 0));
+  if (int rc = own()) return rc;                               // enqueued first: the in-process backend blocks the host in the exchange
+  if (int rc = plan_halo(p, h, op, p->xs)) return rc;
+  GSS_HIP(hipEventRecord(p->ev_halo, p->xs));
+  GSS_HIP(hipStreamWaitEvent(as_stream(stream), p->ev_halo, 0));
+  return rest();
 }
 
 int plan_allreduce(gss_plan *p, float *buf, size_t count, void *stream) {
@@ -462,11 +519,9 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
     const bool cached = (l == 0 && ((D.cache_layer1 && p->layer1_valid) || have_l0));
     if (!cached) {
       // AX = A x ; M = AX (.) x      (model.py:163,168); x's boundary rows come from their owners (C1)
-      if (l == 0) {
+      if (l == 0)
         if (int rc = plan_x0(p, stream)) return rc;
-      } else {
-        if (int rc = plan_halo(p, p->halo_a, xl, stream)) return rc;
-      }
+      const bool split_a = p->a_own != nullptr;
       // layer 1's inputs are constants, so are the boundary rows of its M: every shard recomputes its own rows each step
       // (the SpMM is executed), the boundary rows are exchanged once
       float *m = l == 0 ? p->m0op : p->m_tmp;
@@ -479,17 +534,46 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
         if (int rc = mark_rows_and_neighbours(p->a, lazy_rows, lazy_b, p->needbits, stream)) return rc;
       }
       {
-        PROF(GSS_PROF_SPMM_FWD_HAD);
-        if (int rc = spmm_fwd(p->a, D.d, xl, p->ax[l], xl, m, stream, nullptr, (lazy_l && p->needbits) ? p->needbits : nullptr)) return rc;
+        const uint32_t *rbits = (lazy_l && p->needbits) ? p->needbits : nullptr;   // (single-shard plans only: never with a split matrix)
+        auto full = [&]() {
+          PROF(GSS_PROF_SPMM_FWD_HAD);
+          return spmm_fwd(p->a, D.d, xl, p->ax[l], xl, m, stream, nullptr, rbits);
+        };
+        if (l == 0) {   // the boundary rows of X_0 are constants, fetched once by plan_x0: nothing to exchange, nothing to overlap
+          if (int rc = full()) return rc;
+        } else {
+          auto own = [&]() {
+            PROF(GSS_PROF_SPMM_FWD_HAD);
+            return spmm_fwd(p->a_own, D.d, xl, p->ax[l], nullptr, nullptr, stream);
+          };
+          auto rest = [&]() {
+            PROF(GSS_PROF_SPMM_FWD_HAD);
+            return spmm_fwd(p->a_halo, D.d, xl, p->ax[l], xl, m, stream, nullptr, nullptr, p->ax[l]);
+          };
+          if (int rc = plan_hop(p, p->halo_a, split_a, xl, stream, full, own, rest)) return rc;
+        }
       }
       // AM = A M                      (model.py:169)
-      if (l > 0 || !p->m0_ready) {
-        if (int rc = plan_halo(p, p->halo_a, m, stream)) return rc;
-        if (l == 0) p->m0_ready = true;
-      }
       {
-        PROF(GSS_PROF_SPMM_FWD);
-        if (int rc = spmm_fwd(p->a, D.d, m, p->am[l], nullptr, nullptr, stream, lazy_l ? p->pos : nullptr)) return rc;
+        const int32_t *rpos = lazy_l ? p->pos : nullptr;
+        auto full = [&]() {
+          PROF(GSS_PROF_SPMM_FWD);
+          return spmm_fwd(p->a, D.d, m, p->am[l], nullptr, nullptr, stream, rpos);
+        };
+        if (l == 0 && p->m0_ready) {   // layer 1's M: boundary rows are constants, fetched in the first step
+          if (int rc = full()) return rc;
+        } else {
+          auto own = [&]() {
+            PROF(GSS_PROF_SPMM_FWD);
+            return spmm_fwd(p->a_own, D.d, m, p->am[l], nullptr, nullptr, stream, rpos);
+          };
+          auto rest = [&]() {
+            PROF(GSS_PROF_SPMM_FWD);
+            return spmm_fwd(p->a_halo, D.d, m, p->am[l], nullptr, nullptr, stream, rpos, nullptr, p->am[l]);
+          };
+          if (int rc = plan_hop(p, p->halo_a, split_a, m, stream, full, own, rest)) return rc;
+          if (l == 0) p->m0_ready = true;
+        }
       }
       if (l == 0) p->layer1_valid = true;   // (the lazy top layer is never layer 1: gss_plan_step_lazy needs two layers)
     }
@@ -660,15 +744,26 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
       const float *res = (lp + 2 <= L - 1) ? p->gx[(lp + 2) & 1] : nullptr;
       float *gx_out = (lp >= 1 && L > 2) ? p->gx[(lp + 1) & 1] : nullptr;
       const bool fold_res = deferred_slices && sparse_top && lp + 2 == L;
-      if (int rc = plan_halo(p, p->halo_t, p->u, stream)) return rc;   // C1
       {
-        PROF(GSS_PROF_SPMM_BWD2);
-        if (fold_res) {
-          // dP += dx_b on the batch rows inside the SpMM epilogue (no separate scatter-add launch)
-          if (int rc = spmm_bwd2_sparse_res(p->at, D.d, p->u, p->t, p->p[lp], c, p->dx_b, pos_row, p->dp, gx_out, stream, p->nzbits)) return rc;
-        } else {
-          if (int rc = spmm_bwd2(p->at, D.d, p->u, p->t, p->p[lp], c, res, p->dp, gx_out, stream)) return rc;
-        }
+        // gx = t + A_hat^T u needs u's boundary rows (C1).  fold_res: dP += dx_b on the batch rows inside the SpMM epilogue (no separate
+        // scatter-add launch).  Overlapped: the own-column sums go to dp first (with the non-zero-row filter of u where there is one)
+        const bool split_t = p->at_own != nullptr;
+        auto full = [&]() {
+          PROF(GSS_PROF_SPMM_BWD2);
+          if (fold_res) return spmm_bwd2_sparse_res(p->at, D.d, p->u, p->t, p->p[lp], c, p->dx_b, pos_row, p->dp, gx_out, stream, p->nzbits);
+          return spmm_bwd2(p->at, D.d, p->u, p->t, p->p[lp], c, res, p->dp, gx_out, stream);
+        };
+        auto own = [&]() {
+          PROF(GSS_PROF_SPMM_BWD2);
+          return spmm_fwd(p->at_own, D.d, p->u, p->dp, nullptr, nullptr, stream, nullptr, nullptr, nullptr, fold_res ? p->nzbits : nullptr);
+        };
+        auto rest = [&]() {
+          PROF(GSS_PROF_SPMM_BWD2);
+          if (fold_res)
+            return spmm_bwd2_sparse_res(p->at_halo, D.d, p->u, p->t, p->p[lp], c, p->dx_b, pos_row, p->dp, gx_out, stream, p->nzbits, p->dp);
+          return spmm_bwd2(p->at_halo, D.d, p->u, p->t, p->p[lp], c, res, p->dp, gx_out, stream, p->dp);
+        };
+        if (int rc = plan_hop(p, p->halo_t, split_t, p->u, stream, full, own, rest)) return rc;
       }
       if (lp + 2 == L && !fold_res) {
         PROF(GSS_PROF_ELEMENTWISE);
@@ -692,9 +787,21 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
           PROF(GSS_PROF_DGRAD);
           if (int rc = dense_bwd_input(D.n, D.d, p->dp, p->w1t, p->w2t, nullptr, p->g_ax, p->g_am, stream)) return rc;
         }
-        if (int rc = plan_halo(p, p->halo_t, p->g_am, stream)) return rc;   // C1
-        PROF(GSS_PROF_SPMM_BWD1);
-        if (int rc = spmm_bwd1(p->at, D.d, p->g_am, p->g_ax, p->xin[lp], p->ax[lp], p->u, p->t, stream)) return rc;
+        // dm = A_hat^T g_am needs g_am's boundary rows (C1); overlapped: the own-column sums go to t first
+        const bool split_t = p->at_own != nullptr;
+        auto full = [&]() {
+          PROF(GSS_PROF_SPMM_BWD1);
+          return spmm_bwd1(p->at, D.d, p->g_am, p->g_ax, p->xin[lp], p->ax[lp], p->u, p->t, stream);
+        };
+        auto own = [&]() {
+          PROF(GSS_PROF_SPMM_BWD1);
+          return spmm_fwd(p->at_own, D.d, p->g_am, p->t, nullptr, nullptr, stream);
+        };
+        auto rest = [&]() {
+          PROF(GSS_PROF_SPMM_BWD1);
+          return spmm_bwd1(p->at_halo, D.d, p->g_am, p->g_ax, p->xin[lp], p->ax[lp], p->u, p->t, stream, p->t);
+        };
+        if (int rc = plan_hop(p, p->halo_t, split_t, p->g_am, stream, full, own, rest)) return rc;
       }
     }
   }
@@ -744,6 +851,12 @@ void gss_plan_destroy(gss_plan *p) {
     (void)hipStreamSynchronize(p->side);
     (void)hipStreamDestroy(p->side);
   }
+  if (p->xs) {
+    (void)hipStreamSynchronize(p->xs);
+    (void)hipStreamDestroy(p->xs);
+  }
+  if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
+  if (p->ev_halo) (void)hipEventDestroy(p->ev_halo);
   if (p->ev_main_ready) (void)hipEventDestroy(p->ev_main_ready);
   if (p->ev_side_done) (void)hipEventDestroy(p->ev_side_done);
   if (p->slab) (void)hipFree(p->slab);

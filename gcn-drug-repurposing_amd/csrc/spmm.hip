@@ -42,6 +42,11 @@ struct SpmmEpi {
                            // neighbour or is a batch row); the caller clears the map beforehand.  The next hop's posbits.
   int skip_zero_rows;      // SPMM_BWD1S with nzbits_out: rows whose bit stays clear are not written at all (their u and t are zero and
                            // every reader consults the bitmap first); only when no peer reads the rows either (single shard)
+  const float *y_in;       // second pass of a two-pass product (a shard's hop overlapped with its halo exchange): [n_rows][d] partial sums
+                           // over the entries of another CSR of the same rows; added to this pass's sums before the epilogue.
+                           // May alias an output (every element is read, then written, by the same lane)
+  const uint32_t *gather_bits;  // SPMM_PLAIN, optional: bit c clear => row c of the operand is all zeros, the neighbour is skipped (the
+                                // first pass of a two-pass SPMM_BWD2S, whose second pass carries the same bitmap as posbits)
 };
 
 struct CsrView {
@@ -365,13 +370,14 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
       }
     };
     constexpr int kFly = FLY;
-    if (MODE == SPMM_BWD1S || (MODE == SPMM_BWD2S && ep.posbits)) {
+    if (MODE == SPMM_BWD1S || (MODE == SPMM_BWD2S && ep.posbits) || (MODE == SPMM_PLAIN && ep.gather_bits)) {
       // row-sparse operand.  BWD1S: only neighbours that are batch rows contribute (about B/N of the entries): look the neighbour up in
       // the node -> compact-row map (behind the bitmap when there is one).  BWD2S with a bitmap: only neighbours whose row of u may be
       // non-zero.  The hits of a group are walked in entry order, kFly gathers in flight.
       int cp = -1;
       if (ce < e1) {
-        const bool member = !ep.posbits || ((ep.posbits[(unsigned)c >> 5] >> (c & 31)) & 1u);
+        const uint32_t *filter = MODE == SPMM_PLAIN ? ep.gather_bits : ep.posbits;
+        const bool member = !filter || ((filter[(unsigned)c >> 5] >> (c & 31)) & 1u);
         if (member) cp = MODE == SPMM_BWD1S ? ep.pos[c] : c;
       }
       const unsigned long long hits = __ballot(cp >= 0);
@@ -440,6 +446,13 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   if (pcount <= GPW) {
     if (row >= 0 && (g & (pcount - 1)) == 0) {
       bool tz = row_t_zero<MODE>(ep, row);
+      if (ep.y_in) {   // the other pass's partial sums of this row (two-pass product)
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int f4 = li + v * 64;
+          if (f4 < d4) acc[v] = add4(ld4(ep.y_in + ((size_t)row * rs4 + slice_f4 + f4) * 4), acc[v]);
+        }
+      }
       if (MODE == SPMM_BWD1S) {
         bool piece_live = ep.pos_row[row] >= 0;
 #pragma unroll
@@ -477,6 +490,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
       if (f4 >= d4) continue;
       t[v] = part[wib * d4 + f4];
       for (int k = 1; k < nw; ++k) t[v] = add4(t[v], part[(wib + k) * d4 + f4]);
+      if (ep.y_in) t[v] = add4(ld4(ep.y_in + ((size_t)row * rs4 + slice_f4 + f4) * 4), t[v]);
       piece_live |= !is_zero4(t[v]);
     }
     bool tz = row_t_zero<MODE>(ep, row);
@@ -622,23 +636,30 @@ static int launch_spmm(const gss_csr *a, int32_t d, const float *x, const SpmmEp
 
 // internal entry points shared with plan.hip
 int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream, const int32_t *row_pos,
-             const uint32_t *row_bits) {
+             const uint32_t *row_bits, const float *y_in, const uint32_t *gather_bits) {
   GSS_REQUIRE(y, "spmm: y is null");
   GSS_REQUIRE(!row_pos || (!m && g_spmm_variant == 2), "spmm: a row map goes with the plain product of the balanced SpMM only");
   GSS_REQUIRE(!row_bits || (m && g_spmm_variant == 2), "spmm: a row bitmap goes with the Hadamard-fused product of the balanced SpMM only");
+  GSS_REQUIRE((!y_in && !gather_bits) || g_spmm_variant == 2, "spmm: a two-pass product needs the balanced SpMM (spmm_variant 2)");
+  GSS_REQUIRE(!gather_bits || !m, "spmm: a gather filter goes with the plain product only");
   if (m) {
     GSS_REQUIRE(h, "spmm: m given without h");
     SpmmEpi ep{h, nullptr, nullptr, y, m, 0.f, nullptr, nullptr, row_bits};
+    ep.y_in = y_in;
     return launch_spmm<SPMM_FWD1>(a, d, x, ep, stream);
   }
   SpmmEpi ep{nullptr, nullptr, nullptr, y, nullptr, 0.f, row_pos, nullptr, nullptr};
+  ep.y_in = y_in;
+  ep.gather_bits = gather_bits;
   return launch_spmm<SPMM_PLAIN>(a, d, x, ep, stream);
 }
 
 int spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
-              float *u, float *t, void *stream) {
+              float *u, float *t, void *stream, const float *y_in) {
   GSS_REQUIRE(g_am && g_ax && x_in && ax && u && t, "spmm_bwd1: null operand");
+  GSS_REQUIRE(!y_in || g_spmm_variant == 2, "spmm_bwd1: a two-pass product needs the balanced SpMM (spmm_variant 2)");
   SpmmEpi ep{g_ax, x_in, ax, u, t, 0.f, nullptr, nullptr, nullptr, nullptr};
+  ep.y_in = y_in;
   return launch_spmm<SPMM_BWD1>(at, d, g_am, ep, stream);
 }
 
@@ -653,10 +674,11 @@ int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const fl
 }
 
 int spmm_bwd2_sparse_res(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res_b,
-                         const int32_t *pos_row, float *dp, float *gx_out, void *stream, const uint32_t *nzbits) {
+                         const int32_t *pos_row, float *dp, float *gx_out, void *stream, const uint32_t *nzbits, const float *y_in) {
   GSS_REQUIRE(u && t && p && res_b && pos_row && dp, "spmm_bwd2_sparse_res: null operand");
   GSS_REQUIRE(g_spmm_variant == 2, "spmm_bwd2_sparse_res needs the balanced SpMM (spmm_variant 2)");
   SpmmEpi ep{t, p, res_b, dp, gx_out, c, nullptr, pos_row, nzbits, nullptr, 0};
+  ep.y_in = y_in;
   return launch_spmm<SPMM_BWD2S>(at, d, u, ep, stream);
 }
 
@@ -686,9 +708,11 @@ int mark_rows_and_neighbours(const gss_csr *a, const int32_t *rows, int32_t b, u
 }
 
 int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
-              float *dp, float *gx_out, void *stream) {
+              float *dp, float *gx_out, void *stream, const float *y_in) {
   GSS_REQUIRE(u && t && p && dp, "spmm_bwd2: null operand");
+  GSS_REQUIRE(!y_in || g_spmm_variant == 2, "spmm_bwd2: a two-pass product needs the balanced SpMM (spmm_variant 2)");
   SpmmEpi ep{t, p, res, dp, gx_out, c, nullptr, nullptr, nullptr, nullptr};
+  ep.y_in = y_in;
   return launch_spmm<SPMM_BWD2>(at, d, u, ep, stream);
 }
 
@@ -861,6 +885,10 @@ void gss_csr_destroy(gss_csr *a) {
 
 int gss_spmm(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream) {
   return spmm_fwd(a, d, x, y, h, m, stream);
+}
+int gss_spmm_add(const gss_csr *a, int32_t d, const float *x, const float *y_in, float *y, const float *h, float *m, void *stream) {
+  GSS_REQUIRE(y_in, "spmm_add: y_in is null");
+  return spmm_fwd(a, d, x, y, h, m, stream, nullptr, nullptr, y_in);
 }
 int gss_spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
                   float *u, float *t, void *stream) {

@@ -213,17 +213,26 @@ class Halo:
 class ShardLayout:
     """everything gss_plan_create_sharded borrows for one shard; keeps the host arrays and device tensors alive"""
 
-    def __init__(self, part: Partition, rank, halo_a: Halo, halo_at, device):
+    def __init__(self, part: Partition, rank, halo_a: Halo, halo_at, device, split_a=None, split_at=None):
         self.part, self.rank, self.world = part, rank, part.parts
         self.bounds = np.ascontiguousarray(part.bounds, dtype=np.int64)
         self.halo_a, self.halo_at = halo_a, halo_at
+        # (own-column CSR, boundary-column CSR) of A_hat / A_hat^T, or None: with them the plan overlaps a hop with its exchange
+        self.split_a, self.split_at = split_a, split_at
         self.gid2op_t = torch.from_numpy(halo_at.gid2op).to(device) if halo_at is not None else None
         self._empty = np.zeros(part.parts + 1, dtype=np.int64)
 
     def c_desc(self):
         none = _lib.HaloDesc(self._empty.ctypes.data, self._empty.ctypes.data, None)
+        def h(pair, k):
+            return pair[k].handle if pair is not None else None
         return _lib.ShardDesc(self.world, self.rank, self.bounds.ctypes.data, self.halo_a.c_desc(),
-                              self.halo_at.c_desc() if self.halo_at is not None else none, _lib.ptr(self.gid2op_t))
+                              self.halo_at.c_desc() if self.halo_at is not None else none, _lib.ptr(self.gid2op_t),
+                              h(self.split_a, 0), h(self.split_a, 1), h(self.split_at, 0), h(self.split_at, 1))
+
+    @property
+    def overlapped(self):
+        return self.split_a is not None
 
     def halo_fraction(self):
         """rows received per hop / rows owned by the other shards: (A_hat, A_hat^T)"""
@@ -232,7 +241,7 @@ class ShardLayout:
 
 
 def sharded_plan_engine(adj, x_host, params_host, comm, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4, max_batch=None,
-                        betas=(0.9, 0.999), eps=1e-8, device=None, a_hat=None, cache_layer1=False, relabel="auto"):
+                        betas=(0.9, 0.999), eps=1e-8, device=None, a_hat=None, cache_layer1=False, relabel="auto", split="auto"):
     """One rank of the node-range sharded trainer on the NATIVE path: a gss_plan created with gss_plan_create_sharded
     that holds the communicator and enqueues kernels and collectives from C++ (no Python between kernels).  The shard's
     CSRs carry operand-row column ids: own rows first, then the boundary rows its entries reference (Halo).  Returns a
@@ -244,7 +253,7 @@ def sharded_plan_engine(adj, x_host, params_host, comm, num_layers=2, layer_deca
     if a_hat is None:
         # the regular path: this rank's rows only, normalised on the device (shards.py) -- the same bits as GssGraph's A_hat
         from .shards import ScipySource, build_shard, shard_engine, shard_rows
-        shard = build_shard(ScipySource(adj), comm, need_transpose=num_layers > 1, device=dev, relabel=relabel)
+        shard = build_shard(ScipySource(adj), comm, need_transpose=num_layers > 1, device=dev, relabel=relabel, split=split)
         return shard_engine(shard, shard_rows(shard, x_host), params_host, comm, num_layers=num_layers, layer_decay=layer_decay, alpha=alpha, lr=lr,
                             max_batch=max_batch, betas=betas, eps=eps, cache_layer1=cache_layer1)
     # a_hat given (an already normalised matrix, e.g. the reference's preprocess_graph output in tests): slice it on the host

@@ -310,9 +310,11 @@ class Shard:
     """one rank's part of the graph on the device: a / at (DeviceCSR with operand-row column ids), layout, part; relabel
     (or None) + node_map (device int32 [N], original id -> row) when the nodes were relabelled"""
 
-    def __init__(self, a, at, layout, part, nnz_global, rowsum, relabel=None, node_map=None):
+    def __init__(self, a, at, layout, part, nnz_global, rowsum, relabel=None, node_map=None, split_a=None, split_at=None):
         self.a, self.at, self.layout, self.part, self.nnz_global, self.rowsum = a, at, layout, part, nnz_global, rowsum
         self.relabel, self.node_map = relabel, node_map
+        # (own-column CSR, boundary-column CSR) of each matrix, or None: what an overlapped hop multiplies while / after the exchange
+        self.split_a, self.split_at = split_a, split_at
         self.n = a.n_rows
 
     @property
@@ -325,12 +327,34 @@ ROW_WEIGHT = 12      # what a row costs besides its stored entries (dense projec
                      # 0.064 ns per entry visit, 3 visits per entry)
 
 
-def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="auto", row_weight=ROW_WEIGHT, ops=None) -> Shard:
+SPLIT_MIN_HALO_ROWS = 65536   # split="auto": overlap a hop with its exchange from this many boundary rows on (32 MB at d = 128); below
+                              # it the exchange is latency-bound and the second SpMM launch + two events cost more than they hide
+
+
+def split_by_column(rowptr, col_local, val32, nl, device):
+    """entries of a shard CSR (operand-row column ids) -> (rowptr, col, val) of those with col < nl and of the others; a row's
+    entries keep their order"""
+    counts = (rowptr[1:] - rowptr[:-1]).long()
+    row_of = torch.repeat_interleave(torch.arange(nl, device=device), counts) if nl else torch.zeros(0, dtype=torch.long, device=device)
+    own = col_local[:row_of.numel()].long() < nl
+    out = []
+    for mask in (own, ~own):
+        rp = torch.zeros(nl + 1, dtype=torch.int64, device=device)
+        if nl:
+            rp[1:] = torch.cumsum(torch.bincount(row_of[mask], minlength=nl), 0)
+        out.append((rp.to(torch.int32), col_local[:row_of.numel()][mask].contiguous(), val32[:row_of.numel()][mask].contiguous()))
+    return out
+
+
+def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="auto", row_weight=ROW_WEIGHT, ops=None, split="auto") -> Shard:
     """relabel: True / False / "auto" (hub-first node order when the graph has >= RELABEL_MIN_NODES nodes; the non-temporal
     treatment of the cold rows additionally needs an operand far beyond the caches, gss_csr_set_hot).  Relabelling is invisible in
     the results: a row's entries keep their original
     order, so every sum is taken in the same order, batches name original ids (gss_plan_desc.node_map) and
-    GssEngine.gather_embeddings returns original order.  ops: the device side (NativeShardOps unless a test plugs its own)."""
+    GssEngine.gather_embeddings returns original order.  ops: the device side (NativeShardOps unless a test plugs its own).
+    split: True / False / "auto" -- also keep every matrix split into its own-column and boundary-column entries, so that the plan
+    overlaps each hop with its halo exchange (gss_shard_desc.a_own ...; results then differ from the single-GPU plan by rounding,
+    not bit for bit).  "auto": when a hop fetches >= SPLIT_MIN_HALO_ROWS boundary rows on some rank (RMAT scale), never on one rank."""
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     ops = ops or NativeShardOps()
     P, rank = comm.world, comm.rank
@@ -357,25 +381,38 @@ def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="a
         g2o = torch.from_numpy(halo.gid2op).to(dev)
         col_local = g2o[col.long()].contiguous() if col.numel() else col
         csr = ops.csr(rowptr.cpu().numpy(), col_local, val32[:col.numel()], nl, nl + halo.n_halo, dev)
+        hot = None
         if rl is not None:
             # the hubs are nodes [0, HOT_ROWS): this shard's own rows among them, and the head of its halo (ascending ids)
-            own_hot = int(min(max(HOT_ROWS - lo, 0), nl))
-            halo_hot = int(np.searchsorted(halo.remote, HOT_ROWS))
-            ops.set_hot(csr, own_hot, nl, nl + halo_hot)
-        return csr, halo
+            hot = (int(min(max(HOT_ROWS - lo, 0), nl)), nl, nl + int(np.searchsorted(halo.remote, HOT_ROWS)))
+            ops.set_hot(csr, *hot)
+        want_split = split
+        if split == "auto":
+            # every rank takes the same decision: the largest halo of the job
+            most = int(allgather_host(comm, np.array([halo.n_halo], dtype=np.int64), dev).max()) if P > 1 else 0
+            want_split = most >= SPLIT_MIN_HALO_ROWS
+        halves = None
+        if want_split and P > 1:
+            halves = []
+            for rp, cl, vl in split_by_column(rowptr, col_local, val32, nl, dev):
+                part_csr = ops.csr(rp.cpu().numpy(), cl, vl if vl.numel() else val32[:1], nl, nl + halo.n_halo, dev)
+                if hot is not None:
+                    ops.set_hot(part_csr, *hot)
+                halves.append(part_csr)
+        return csr, halo, halves
 
-    a, halo_a = finish(rowptr, col, val, 0)
+    a, halo_a, split_a = finish(rowptr, col, val, 0)
     del rowptr, col, val
-    at, halo_at = None, None
+    at, halo_at, split_at = None, None, None
     if need_transpose:
         rowptr, col, val = source.rows_t(lo, hi, dev, relabel=rl)
-        at, halo_at = finish(rowptr, col, val, 1)
+        at, halo_at, split_at = finish(rowptr, col, val, 1)
         del rowptr, col, val
     if hasattr(source, "release"):
         source.release()
-    layout = ShardLayout(part, rank, halo_a, halo_at, dev)
+    layout = ShardLayout(part, rank, halo_a, halo_at, dev, split_a=split_a, split_at=split_at)
     node_map = rl.inv_dev(dev).to(torch.int32).contiguous() if rl is not None else None
-    return Shard(a, at, layout, part, int(source.nnz), rowsum[:nl], rl, node_map)
+    return Shard(a, at, layout, part, int(source.nnz), rowsum[:nl], rl, node_map, split_a=split_a, split_at=split_at)
 
 
 def shard_rows(shard: Shard, x_all):

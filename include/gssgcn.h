@@ -74,6 +74,10 @@ int gss_csr_set_hot(gss_csr *a, int32_t own_hot, int32_t halo_begin, int32_t hal
  * y = A x  (x: [n_cols][d], y: [n_rows][d]).  If m != NULL also m = y (.) h, h: [n_rows][d]
  * (the Hadamard of model.py:168 fused into the epilogue of the first SpMM). */
 int gss_spmm(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream);
+/* The second pass of a two-pass product: y = y_in + A x (then m = y (.) h as above).  The entries of the rows may be split over two
+ * CSR handles of the same rows (e.g. a shard's own-column and boundary-column entries, gss_shard_desc): gss_spmm with the first,
+ * gss_spmm_add with the second.  y_in may be y itself. */
+int gss_spmm_add(const gss_csr *a, int32_t d, const float *x, const float *y_in, float *y, const float *h, float *m, void *stream);
 
 /* backward SpMMs (autograd of model.py:163-169 for layers >= 2), A here is CSR(A_hat^T):
  *   gss_spmm_bwd1: dm = A g_am;  u = g_ax + dm (.) x_in;  t = dm (.) ax
@@ -337,6 +341,13 @@ typedef struct gss_shard_desc {
   gss_halo_desc halo_at;       /* operand halo of A_hat^T's columns (ignored when num_layers == 1) */
   const int32_t *d_gid2op_t;   /* device [N], borrowed: node id -> operand row of A_hat^T's column space ([0, n) own rows, then
                                   halo), -1 where this shard never reads the node.  NULL when num_layers == 1 */
+  /* Optional: every matrix once more, split by column -- *_own holds the entries whose column is one of the shard's own rows
+   * (operand rows [0, n)), *_halo the entries that reference boundary rows; same rows, same operand-row column ids, entries in
+   * their original order.  With them a hop is overlapped with its exchange: the boundary rows travel on a second stream while the
+   * own-column entries are multiplied, the boundary-column entries are added afterwards (gss_spmm_add) and the epilogue runs
+   * there.  A row is then summed as (own entries) + (boundary entries) instead of in column order: results differ from the
+   * single-GPU plan by rounding (~1e-7 relative), no longer bit for bit.  All NULL: exchange, then one pass (the default). */
+  const gss_csr *a_own, *a_halo, *at_own, *at_halo;
 } gss_shard_desc;
 int gss_plan_create_sharded(gss_plan **out, const gss_plan_desc *desc, const gss_shard_desc *shard, gss_comm *comm,
                             const gss_csr *a, const gss_csr *at, const gss_plan_io *io);

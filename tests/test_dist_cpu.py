@@ -52,6 +52,21 @@ def _worker(rank, world, port, case, relabel, out_dir):
         ref = sp.csr_matrix(ahat[rows])
         ref.sort_indices()
         np.testing.assert_array_equal(np.asarray(shard.a.m.data, np.float32), ref.data.astype(np.float32))
+        # the same matrices once more, split by column for the overlapped hops: own-column + boundary-column entries = the matrix,
+        # every row's entries in their original order
+        split = build_shard(ScipySource(golden_csr(g, "A")), comm, need_transpose=L > 1, device="cpu", relabel=relabel, ops=NumpyShardOps(), split=True)
+        for full, halves in ((split.a, split.split_a), (split.at, split.split_at)):
+            if full is None:
+                continue
+            assert (halves is not None) == (world > 1)
+            if halves is None:
+                continue
+            own, hal = halves
+            assert own.nnz + hal.nnz == full.nnz and abs((own.m + hal.m) - full.m).max() == 0
+            assert (own.m.indices < (hi - lo)).all() and (hal.m.indices >= (hi - lo)).all()
+            for r in range(hi - lo):
+                both = np.concatenate([own.m.indices[own.m.indptr[r]:own.m.indptr[r + 1]], hal.m.indices[hal.m.indptr[r]:hal.m.indptr[r + 1]]])
+                assert sorted(both.tolist()) == sorted(full.m.indices[full.m.indptr[r]:full.m.indptr[r + 1]].tolist())
         eng = ShardStepMirror(shard, shard_rows(shard, g["X"]), golden_params(g, "init"), comm, num_layers=L, layer_decay=float(g["decay"]),
                               alpha=float(g["alpha"]), lr=float(g["lr"]))
         losses, ex_per_step, rows_per_step = [], [], []

@@ -125,6 +125,40 @@ def test_spmm_all_widths_with_hub_and_empty_rows(G, d, spmm_variant):
     assert torch.equal(y, y2)  # bitwise reproducible, with and without the fused epilogue
 
 
+@pytest.mark.parametrize("d", [16, 128, 256])
+def test_spmm_add_second_pass_of_a_two_pass_product(G, d):
+    """gss_spmm_add: the entries of every row split over two CSRs by column (a shard's own-column / boundary-column halves): the plain
+    product of the first, then y = y_in + A2 x with the fused epilogue, in place, equals the one-pass product up to the changed
+    summation order -- and bit for bit on rows whose entries all sit in one half"""
+    rng = np.random.RandomState(100 + d)
+    n, c0 = 1400, 500
+    a = random_graph(rng, n, 9, hub_rows=(5, 900), hub_deg=1100, empty_rows=(2, n - 1))
+    a32 = sp.csr_matrix((a.data.astype(np.float32), a.indices, a.indptr), shape=a.shape)
+    coo = a32.tocoo()
+    halves = []
+    for mask in (coo.col < c0, coo.col >= c0):
+        h = sp.csr_matrix((coo.data[mask], (coo.row[mask], coo.col[mask])), shape=a32.shape)
+        h.sort_indices()
+        halves.append(h)
+    full = G.graph.DeviceCSR(a32.indptr, a32.indices, a32.data, n, n, "cuda")
+    own = G.graph.DeviceCSR(halves[0].indptr, halves[0].indices, halves[0].data, n, n, "cuda")
+    rest = G.graph.DeviceCSR(halves[1].indptr, halves[1].indices, halves[1].data, n, n, "cuda")
+    x, hh = rng.randn(n, d).astype(np.float32), rng.randn(n, d).astype(np.float32)
+    xd, hd = cu(x), cu(hh)
+    y1, m1 = torch.empty(n, d, device="cuda"), torch.empty(n, d, device="cuda")
+    G._lib.check(G.lib.gss_spmm(full.handle, d, xd.data_ptr(), y1.data_ptr(), hd.data_ptr(), m1.data_ptr(), G.st()))
+    y2, m2 = torch.full((n, d), float("nan"), device="cuda"), torch.full((n, d), float("nan"), device="cuda")
+    G._lib.check(G.lib.gss_spmm(own.handle, d, xd.data_ptr(), y2.data_ptr(), None, None, G.st()))
+    G._lib.check(G.lib.gss_spmm_add(rest.handle, d, xd.data_ptr(), y2.data_ptr(), y2.data_ptr(), hd.data_ptr(), m2.data_ptr(), G.st()))
+    ref = a32.astype(np.float64) @ x.astype(np.float64)
+    assert rel_err(y2.cpu().numpy(), ref) < 2e-6 and rel_err(m2.cpu().numpy(), ref * hh) < 2e-6
+    assert rel_err(y2.cpu().numpy(), y1.cpu().numpy()) < 1e-6
+    one_sided = np.flatnonzero((np.diff(halves[0].indptr) == 0) | (np.diff(halves[1].indptr) == 0))
+    assert len(one_sided) > 50
+    sel = torch.from_numpy(one_sided).cuda()
+    assert torch.equal(y1.index_select(0, sel), y2.index_select(0, sel)) and torch.equal(m1.index_select(0, sel), m2.index_select(0, sel))
+
+
 @pytest.mark.parametrize("d", [64, 128, 256])
 def test_spmm_hot_cold_split_and_deeper_queues_do_not_change_a_bit(G, d):
     """gss_csr_set_hot / the large-table kernel path (non-temporal gathers of the rows outside the hubs' set, 8 gathers in
