@@ -300,6 +300,9 @@ def main():
                        else "single")
         if shard.relabel is not None:
             parallelism += "; nodes relabelled hub-first"
+        if shard.layout.overlapped:
+            parallelism += "; hops overlapped with their boundary exchange (own-column product on the main stream, exchange on a second one)"
+        halo_info["overlapped_hops"] = bool(shard.layout.overlapped)
     else:
         from gcn_drug_repurposing_amd.engine import GssEngine
         graph = GssGraph(adj, need_transpose=L > 1)

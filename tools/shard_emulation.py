@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A sharded job on a ONE-GPU box: `world` ranks as threads of this process (gss_comm_create_local), each building only its
 own rows of an RMAT graph (shards.RmatSource / build_shard) and running the native sharded plan.
-usage: shard_emulation.py <nodes> <edges> <world> [steps] [d]
+usage: shard_emulation.py <nodes> <edges> <world> [steps] [d] [split: auto | 0 | 1]
 Reports per rank: rows, stored entries, boundary rows per hop (halo) and their fraction of the other shards' rows, plan
 bytes; for the job: host peak RSS, setup time, ms/step (NOT a performance figure: the ranks share one GPU and the exchanges
 are host-synchronised copies), and the loss after the steps -- compare it with the world = 1 run of the same command."""
@@ -24,6 +24,7 @@ pkg.load()
 n, m, world = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 d = int(sys.argv[5]) if len(sys.argv) > 5 else 128
+split = {"auto": "auto", "0": False, "1": True}[sys.argv[6] if len(sys.argv) > 6 else "auto"]
 L, B = 2, 2048
 np.random.seed(7)
 w = np.random.randn(d, d) * 1e-5
@@ -41,7 +42,7 @@ def worker(rank):
         torch.cuda.set_device(0)
         with torch.cuda.stream(torch.cuda.Stream()):
             t0 = time.perf_counter()
-            shard = build_shard(RmatSource(n, m, seed=4, device="cuda:0"), comms[rank], need_transpose=True, device="cuda:0")
+            shard = build_shard(RmatSource(n, m, seed=4, device="cuda:0"), comms[rank], need_transpose=True, device="cuda:0", split=split)
             lo, hi = shard.part.rows(rank)
             eng = shard_engine(shard, gaussian_rows(lo, hi, d, 5), params, comms[rank], num_layers=L, layer_decay=0.3, alpha=1.0, lr=3e-4, max_batch=B)
             torch.cuda.current_stream().synchronize()
@@ -56,7 +57,11 @@ def worker(rank):
             fa, ft = shard.layout.halo_fraction()
             out[rank] = dict(rank=rank, rows=hi - lo, nnz=shard.a.nnz, halo_rows_a=shard.layout.halo_a.n_halo, halo_rows_at=shard.layout.halo_at.n_halo,
                              halo_fraction_a=round(fa, 4), halo_fraction_at=round(ft, 4), send_rows_a=int(shard.layout.halo_a.send_off[-1]),
-                             plan_gb=round(eng.device_bytes() / 2 ** 30, 2), setup_s=round(setup, 1),
+                             plan_gb=round(eng.device_bytes() / 2 ** 30, 2), setup_s=round(setup, 1), overlapped_hops=shard.layout.overlapped,
+                             own_column_entries_a=(shard.split_a[0].nnz if shard.split_a else None),
+                             own_column_entries_at=(shard.split_at[0].nnz if shard.split_at else None),
+                             exchanged_mb_per_hop_a=round(shard.layout.halo_a.n_halo * d * 4 / 2 ** 20, 1),
+                             exchanged_mb_per_hop_at=round(shard.layout.halo_at.n_halo * d * 4 / 2 ** 20, 1),
                              ms_per_step=round((time.perf_counter() - t1) / steps * 1e3, 2), loss=eng.loss.item(), relabelled=shard.relabel is not None)
     except Exception as e:  # noqa: BLE001
         import traceback
