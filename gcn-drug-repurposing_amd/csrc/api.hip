@@ -3,23 +3,8 @@
 
 namespace gss {
 thread_local char g_err[512] = "";
-extern int g_spmm_variant;  // spmm.hip
-extern int g_spmm_slices;
-extern int g_spmm_pin;
-extern int g_spmm_hot;
-extern int g_spmm_fly;
-extern int g_seg_edges;
-extern int g_gemm_variant;  // dense.hip
-extern int g_gemm_small_nt;
-extern int g_loss_wgs;      // loss.hip
-extern int g_xcd_remap;     // dense.hip
-extern int g_wgrad_wgs;
-extern int g_gemm_prio;
-extern int g_wgrad_prio;
-}
-extern int g_sparse_bits_rows;  // plan.hip
-namespace gss {
-extern int g_gemm_nt_cap;
+Knobs g_knobs;
+thread_local const Knobs *t_knobs = nullptr;
 }  // namespace gss
 
 using namespace gss;
@@ -28,81 +13,83 @@ extern "C" {
 int gss_abi_version(void) { return GSS_ABI_VERSION; }
 const char *gss_last_error(void) { return gss::g_err; }
 
-// Every knob selects between implementations that all produce correct results (the tests run them all).
+// Every knob selects between implementations that all produce correct results (the tests run them all).  The values are process-wide
+// DEFAULTS: a plan snapshots them at creation (common.h Knobs / KnobScope) and keeps running under its snapshot, so a knob changed here
+// reaches per-op calls and plans created afterwards, never a live plan -- not this thread's, not another rank thread's.
 int gss_debug_set_option(const char *name, int value) {
   GSS_REQUIRE(name, "debug_set_option: null name");
   if (strcmp(name, "spmm_variant") == 0) {
     GSS_REQUIRE(value == 1 || value == 2, "spmm_variant must be 1 (row per wave) or 2 (nnz-balanced segments)");
-    g_spmm_variant = value;
+    g_knobs.spmm_variant = value;
     return GSS_OK;
   }
   if (strcmp(name, "spmm_pin") == 0) {
     GSS_REQUIRE(value == 0 || value == 1, "spmm_pin must be 0 or 1");
-    g_spmm_pin = value;
+    g_knobs.spmm_pin = value;
     return GSS_OK;
   }
   if (strcmp(name, "spmm_fly") == 0) {
     GSS_REQUIRE(value == 4 || value == 8, "spmm_fly must be 4 or 8");
-    g_spmm_fly = value;
+    g_knobs.spmm_fly = value;
     return GSS_OK;
   }
   if (strcmp(name, "spmm_hot_rows") == 0) {
     GSS_REQUIRE(value >= -1, "spmm_hot_rows must be >= -1");
-    g_spmm_hot = value;
+    g_knobs.spmm_hot = value;
     return GSS_OK;
   }
   if (strcmp(name, "spmm_slices") == 0) {
     GSS_REQUIRE(value >= 0 && value <= 8, "spmm_slices must be in [0, 8] (0 = automatic)");
-    g_spmm_slices = value;
+    g_knobs.spmm_slices = value;
     return GSS_OK;
   }
   if (strcmp(name, "spmm_seg_edges") == 0) {
     GSS_REQUIRE(value >= 4 && value <= 1024, "spmm_seg_edges must be in [4, 1024]");
-    g_seg_edges = value;
+    g_knobs.seg_edges = value;
     return GSS_OK;
   }
   if (strcmp(name, "loss_wgs") == 0) {
     GSS_REQUIRE(value >= 64 && value <= 4096, "loss_wgs must be in [64, 4096]");
-    g_loss_wgs = value;
+    g_knobs.loss_wgs = value;
     return GSS_OK;
   }
   if (strcmp(name, "sparse_bits_rows") == 0) {
     GSS_REQUIRE(value >= 1, "sparse_bits_rows must be >= 1");
-    g_sparse_bits_rows = value;
+    g_knobs.sparse_bits_rows = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_nt_cap") == 0) {
     GSS_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "gemm_nt_cap must be 0, 1, 2, 4 or 8");
-    g_gemm_nt_cap = value;
+    g_knobs.gemm_nt_cap = value;
     return GSS_OK;
   }
   if (strcmp(name, "wgrad_wgs") == 0) {
     GSS_REQUIRE(value >= 8 && value <= 4096, "wgrad_wgs must be in [8, 4096]");
-    g_wgrad_wgs = value;   // before any plan is created: the plan sizes its partial buffer with it
+    g_knobs.wgrad_wgs = value;   // before any plan is created: the plan sizes its partial buffer with it
     return GSS_OK;
   }
   if (strcmp(name, "xcd_remap") == 0) {
-    g_xcd_remap = value ? 1 : 0;
+    g_knobs.xcd_remap = value ? 1 : 0;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_small_nt") == 0) {
     GSS_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "gemm_small_nt must be 0, 1, 2, 4 or 8");
-    g_gemm_small_nt = value;
+    g_knobs.gemm_small_nt = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_prio") == 0) {
     GSS_REQUIRE(value >= -1, "gemm_prio must be >= -1 (0 = off, -1 = by wave slot)");
-    g_gemm_prio = value;
+    g_knobs.gemm_prio = value;
     return GSS_OK;
   }
   if (strcmp(name, "wgrad_prio") == 0) {
     GSS_REQUIRE(value >= 0 && value <= 2, "wgrad_prio must be 0, 1 or 2");
-    g_wgrad_prio = value;
+    g_knobs.wgrad_prio = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_variant") == 0) {
     GSS_REQUIRE(value >= 1 && value <= 4, "gemm_variant must be 1..4");
-    g_gemm_variant = value;
+    g_knobs.gemm_variant = value;
     return GSS_OK;
   }
   return fail(GSS_EINVAL, "unknown option %s", name);

@@ -12,6 +12,38 @@ namespace gss {
 
 constexpr int kWave = 64;
 
+// ---- tuning / A-B knobs (gss_debug_set_option) ---------------------------------------------------------------------------
+// Process-wide defaults in g_knobs; a plan SNAPSHOTS them when it is created and every gss_plan_* call runs under its own snapshot
+// (KnobScope), so changing a knob never changes what a live plan does -- in particular not the plans of other rank threads of the
+// same process (VERDICT round 2, weak spot 10).  The per-op entry points (gss_spmm, gss_dense_fwd ...) read the process-wide values.
+struct Knobs {
+  int spmm_variant = 2;      // 1 = row per wave, 2 = nnz-balanced segments (default; shards and the lazy step need it)
+  int spmm_slices = 0;       // 0 = automatic feature slicing (launch_balanced)
+  int spmm_pin = 0;          // with a manual spmm_slices: slices pinned to XCDs (1) or time-separated (0)
+  int spmm_hot = -1;         // overrides every CSR's hot set with rows [0, value) (-1 = the CSR's own, 0 = none)
+  int spmm_fly = 4;          // row gathers in flight per lane group on the large-table path (4 or 8)
+  int seg_edges = 32;        // entries per SpMM segment (CSR handles created afterwards)
+  int gemm_variant = 2;      // 1 = L1/L2-fed GEMM, 2 = LDS-DMA staged (default), 3 / 4 = forced 128- / 64-node tiles
+  int gemm_nt_cap = 0;       // cap of the feature tile width (16-feature units), 0 = none
+  int gemm_small_nt = 2;     // narrowest feature tile for small problems, 0 = never narrow
+  int gemm_prio = 0;         // static wave priority experiment of the projection (0 = off; see dense.hip)
+  int wgrad_prio = 0;        // the same for the weight gradient
+  int wgrad_wgs = 256;       // workgroups of a full-size weight-gradient launch (sizes the plan's partial buffer)
+  int xcd_remap = 1;         // workgroups that share input rows on one XCD
+  int loss_wgs = 256;        // workgroups the loss sweep's grid aims at
+  int sparse_bits_rows = 100000;  // operand rows from which a plan keeps the bitmaps of the sparsity-aware backward hops
+};
+extern Knobs g_knobs;
+extern thread_local const Knobs *t_knobs;
+inline const Knobs &K() { return t_knobs ? *t_knobs : g_knobs; }
+struct KnobScope {
+  const Knobs *prev;
+  explicit KnobScope(const Knobs *k) : prev(t_knobs) { t_knobs = k; }
+  ~KnobScope() { t_knobs = prev; }
+  KnobScope(const KnobScope &) = delete;
+  KnobScope &operator=(const KnobScope &) = delete;
+};
+
 // ---- error plumbing (thread-local last error text) ------------------------------------------
 extern thread_local char g_err[512];
 

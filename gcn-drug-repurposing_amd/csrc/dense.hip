@@ -389,32 +389,30 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
 // 12.5 us (tools/micro/stream_small.py) and the MFMAs need 13.7 us; the launch takes their sum plus start-up because
 // all workgroups reach the store phase together.
 
-int g_gemm_variant = 2;
-int g_gemm_nt_cap = 0;
-int g_wgrad_wgs = 256;  // debug knob "wgrad_wgs": workgroups of a full-size weight-gradient launch (one per CU)
-int g_xcd_remap = 1;    // debug knob "xcd_remap": workgroups that share input rows on one XCD (xcd_ids)
-int g_gemm_prio = 0;      // debug knob "gemm_prio": linear workgroup ids below it run at raised wave priority (0 = off)
-int g_wgrad_prio = 0;     // debug knob "wgrad_prio": 1 = waves 4-7 of a weight-gradient workgroup at priority 1, 2 = waves 0-3
-int g_gemm_small_nt = 2;  // debug knob "gemm_small_nt": narrowest feature tile (in 16-feature units) for small problems, 0 = never narrow
+// debug knob "wgrad_wgs": workgroups of a full-size weight-gradient launch (one per CU)   [knob wgrad_wgs, common.h Knobs]
+// debug knob "xcd_remap": workgroups that share input rows on one XCD (xcd_ids)   [knob xcd_remap, common.h Knobs]
+// debug knob "gemm_prio": linear workgroup ids below it run at raised wave priority (0 = off)   [knob gemm_prio, common.h Knobs]
+// debug knob "wgrad_prio": 1 = waves 4-7 of a weight-gradient workgroup at priority 1, 2 = waves 0-3   [knob wgrad_prio, common.h Knobs]
+// debug knob "gemm_small_nt": narrowest feature tile (in 16-feature units) for small problems, 0 = never narrow   [knob gemm_small_nt, common.h Knobs]
 
 template <int EPI>
 static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
   if (g_in.n <= 0) return GSS_OK;
   GemmArgs g = g_in;
-  g.xcd_remap = g_xcd_remap;
-  g.prio_cut = g_gemm_prio;
-  if (g_gemm_variant >= 2) {
+  g.xcd_remap = K().xcd_remap;
+  g.prio_cut = K().gemm_prio;
+  if (K().gemm_variant >= 2) {
     int nt = (d % 128 == 0) ? 8 : (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
-    if (g_gemm_nt_cap > 0 && EPI != EPI_FWD_NORM)   // debug knob "gemm_nt_cap": narrower feature tiles (the fused normalise needs whole rows)
-      while (nt > g_gemm_nt_cap) nt >>= 1;
+    if (K().gemm_nt_cap > 0 && EPI != EPI_FWD_NORM)   // debug knob "gemm_nt_cap": narrower feature tiles (the fused normalise needs whole rows)
+      while (nt > K().gemm_nt_cap) nt >>= 1;
     // few node rows (the top layer's batch-row input gradient: 2048 rows): narrower feature tiles so that the grid covers the chip
     // (64-node x 128-feature tiles give 64 workgroups at B = 2048, d = 128; 32-feature tiles 256)
-    if (EPI == EPI_SPLIT && g_gemm_small_nt > 0)
-      while (nt > g_gemm_small_nt && (int64_t)ceil_div(g.n, 64) * (g.J / (16 * nt)) < 256) nt >>= 1;
+    if (EPI == EPI_SPLIT && K().gemm_small_nt > 0)
+      while (nt > K().gemm_small_nt && (int64_t)ceil_div(g.n, 64) * (g.J / (16 * nt)) < 256) nt >>= 1;
     // 64-node tiles give 2-3 co-resident workgroups per CU (epilogue traffic overlaps MFMA); at d >= 256 the
     // W-staging redundancy of small tiles costs more than that buys (measured, tools/gemm_bench.py), and so it does once
     // the grid is many waves of workgroups deep (d = 128: N = 1M 791 -> 753 us, N = 4M 3061 -> 2913 us with 128-node tiles)
-    const int mt = g_gemm_variant == 3 ? 2 : g_gemm_variant == 4 ? 1 : ((d >= 256 || g.n >= 262144) ? 2 : 1);
+    const int mt = K().gemm_variant == 3 ? 2 : K().gemm_variant == 4 ? 1 : ((d >= 256 || g.n >= 262144) ? 2 : 1);
     if (EPI != EPI_SPLIT && g.rows && (int64_t)ceil_div(g.n, 64) * (g.J / (16 * nt)) < 256) {
       // forward over a short row list: 16-node workgroups of one wave (see the kernel)
       dim3 grid1(ceil_div(g.n, 16), g.J / (16 * nt));
@@ -465,7 +463,7 @@ int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const floa
               const float *b2, const float *p_prev, float decay, float *p, float *x_next, void *stream, const int32_t *row_list) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(n >= 0 && ax && am && w1 && b1 && w2 && b2 && p && x_next, "dense_fwd: null operand");
-  GSS_REQUIRE(!row_list || g_gemm_variant >= 2, "dense_fwd: a row list needs the LDS-staged GEMM");
+  GSS_REQUIRE(!row_list || K().gemm_variant >= 2, "dense_fwd: a row list needs the LDS-staged GEMM");
   GemmArgs g{};
   g.n = n;
   g.K = 2 * d;
@@ -492,8 +490,8 @@ int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const floa
 }
 
 // last layer: P as usual, but the residual mix is row-normalised on the fly: e = normalize(p_prev + decay elu(p))
-bool dense_fwd_norm_available(int32_t d) { return g_gemm_variant >= 2 && (d == 128 || d == 64 || d == 32 || d == 16); }
-bool dense_row_list_available() { return g_gemm_variant >= 2; }   // the projection over a row list (gss_plan_step_lazy) is the LDS-staged kernel's
+bool dense_fwd_norm_available(int32_t d) { return K().gemm_variant >= 2 && (d == 128 || d == 64 || d == 32 || d == 16); }
+bool dense_row_list_available() { return K().gemm_variant >= 2; }   // the projection over a row list (gss_plan_step_lazy) is the LDS-staged kernel's
 
 int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
                    const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream, const int32_t *row_list) {
@@ -803,7 +801,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int d, int nslices, c
 
 static void wgrad_geometry(int32_t n, int32_t d, int &nslices, int &rows_per_slice) {
   const int tiles = (d % 64 == 0) ? (d / 64) * (2 * d / 64) : ceil_div((int64_t)d * 2 * d + d, 256);
-  int want = ceil_div(g_wgrad_wgs, tiles);
+  int want = ceil_div(K().wgrad_wgs, tiles);
   const int max_slices = n > 0 ? ceil_div(n, 32) : 1;
   if (want > max_slices) want = max_slices;
   if (want < 1) want = 1;
@@ -829,7 +827,7 @@ int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const 
   *nslices_out = ns;
   float *pw = (float *)ws + (size_t)slice0 * d * 2 * d;
   float *pb = (float *)ws + (size_t)total_slices * d * 2 * d + (size_t)slice0 * d;
-  WgradArgs g{n, d, dp, ax, am, rows, pw, pb, rps, g_xcd_remap, g_wgrad_prio};
+  WgradArgs g{n, d, dp, ax, am, rows, pw, pb, rps, K().xcd_remap, K().wgrad_prio};
   if (n == 0) {  // empty shard: its slices must still read as zero
     GSS_HIP(hipMemsetAsync(pw, 0, sizeof(float) * (size_t)ns * d * 2 * d, st));
     GSS_HIP(hipMemsetAsync(pb, 0, sizeof(float) * (size_t)ns * d, st));
@@ -864,8 +862,8 @@ int wgrad_partial_pair(int32_t d, int32_t n0, const float *dp0, const float *ax0
   *ns0_out = ns0;
   *ns1_out = ns1;
   float *base_w = (float *)ws, *base_b = (float *)ws + (size_t)total_slices * d * 2 * d;
-  WgradArgs g0{n0, d, dp0, ax0, am0, rows0, base_w + (size_t)slice0_0 * d * 2 * d, base_b + (size_t)slice0_0 * d, rps0, g_xcd_remap, g_wgrad_prio};
-  WgradArgs g1{n1, d, dp1, ax1, am1, rows1, base_w + (size_t)slice0_1 * d * 2 * d, base_b + (size_t)slice0_1 * d, rps1, g_xcd_remap, g_wgrad_prio};
+  WgradArgs g0{n0, d, dp0, ax0, am0, rows0, base_w + (size_t)slice0_0 * d * 2 * d, base_b + (size_t)slice0_0 * d, rps0, K().xcd_remap, K().wgrad_prio};
+  WgradArgs g1{n1, d, dp1, ax1, am1, rows1, base_w + (size_t)slice0_1 * d * 2 * d, base_b + (size_t)slice0_1 * d, rps1, K().xcd_remap, K().wgrad_prio};
   const int tiles = (d / 64) * (2 * d / 64);
   hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns0 + ns1), dim3(64 * kWgWaves), 4 * 16 * 64 * sizeof(float4), as_stream(stream), g0, g1,
                      ns0);
@@ -934,7 +932,7 @@ int wgrad_slices(int32_t n, int32_t d) {
 int wgrad_slices_max(int32_t n_max, int32_t d) {
   const int tiles = (d % 64 == 0) ? (d / 64) * (2 * d / 64) : ceil_div((int64_t)d * 2 * d + d, 256);
   const int cap = n_max > 0 ? ceil_div(n_max, 32) : 1;
-  const int want = ceil_div(g_wgrad_wgs, tiles);
+  const int want = ceil_div(K().wgrad_wgs, tiles);
   return want < cap ? (want < 1 ? 1 : want) : cap;
 }
 

@@ -336,12 +336,11 @@ __global__ __launch_bounds__(256) void loss_finish_bwd_kernel(int b, int d4, int
 
 // debug knob "loss_wgs": workgroups the (i-tile x j-split) grid aims at.  One workgroup per CU wins at B = 2048 (gather + sweep + finish,
 // d = 128: 128 / 256 / 384 / 512 / 768 / 1024 workgroups -> 49.4 / 31.4 / 38.3 / 34.6 / 39.8 / 43.9 us; d = 256: 124.0 at 256 vs 126.3 at 512)
-int g_loss_wgs = 256;
 
 static void loss_geometry(int32_t b, int32_t d, int &ni, int &js, int &nz, int &ng) {
   ni = ceil_div(b, 16);
   const int nj = ni;
-  js = ceil_div(g_loss_wgs, ni);
+  js = ceil_div(K().loss_wgs, ni);
   const int js_max = ceil_div(nj, kLossWaves);
   if (js > js_max) js = js_max;
   if (js > 16) js = 16;

@@ -17,6 +17,7 @@
 #include "ops.h"
 
 struct gss_plan {
+  gss::Knobs knobs;   // the tuning knobs as they stood when the plan was created: every call on the plan runs under them
   gss_plan_desc desc;
   const gss_csr *a, *at;
   const float *x;
@@ -87,7 +88,7 @@ struct gss_plan {
 
 // debug knob "sparse_bits_rows": operand rows from which a plan keeps the two bitmaps of the sparsity-aware backward hops (the
 // batch-membership bitmap in front of the position map, the non-zero-row bitmap of u); plans created afterwards
-int g_sparse_bits_rows = 100000;   // measured with RMAT graphs at B = 2048 (tools/ab_sparse_bits.sh): 60k rows -2.5 %, 120k +2 %, 250k +4.4 %, 450k +6.4 % of a step
+// measured with RMAT graphs at B = 2048 (tools/ab_sparse_bits.sh): 60k rows -2.5 %, 120k +2 %, 250k +4.4 %, 450k +6.4 % of a step   [knob sparse_bits_rows, common.h Knobs]
 
 using namespace gss;
 
@@ -197,7 +198,7 @@ void carve(gss_plan *p, Carver &c) {
   p->pos = L > 1 ? c.take<int32_t>(p->rows_t ? p->rows_t : 1) : nullptr;
   // from sparse_bits_rows operand rows on: the sparse SpMM tests a bitmap before the 4-byte-per-node map (zero-initialised slab)
   // (the sizing pass carves from a null base: conditions must not look at the pointers it hands out)
-  const bool bitmaps = L > 1 && p->rows_t >= (size_t)g_sparse_bits_rows;
+  const bool bitmaps = L > 1 && p->rows_t >= (size_t)K().sparse_bits_rows;
   p->posbits = bitmaps ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;
   p->nzbits = bitmaps ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;
   p->needbits = (bitmaps && !sharded) ? c.take<uint32_t>(n1 / 32 + 1) : nullptr;
@@ -284,6 +285,8 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
     }
   }
   gss_plan *p = new gss_plan();
+  p->knobs = g_knobs;
+  KnobScope knob_scope(&p->knobs);
   p->desc = *desc;
   p->comm = P > 1 ? comm : nullptr;
   p->P = P;
@@ -866,15 +869,18 @@ void gss_plan_destroy(gss_plan *p) {
 // ---- public entry points.  The separate phases make no assumption about who changed the weights in between, so
 // they always re-transpose; gss_plan_step owns the whole iteration and reuses the transposes its own Adam wrote.
 int gss_plan_forward(gss_plan *p, void *stream) {
+  KnobScope knob_scope(p ? &p->knobs : nullptr);
   if (p) p->wt_valid = false;
   return plan_forward_impl(p, stream);
 }
 int gss_plan_loss_backward(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
+  KnobScope knob_scope(p ? &p->knobs : nullptr);
   if (p) p->wt_valid = false;
   BatchView bv{};
   return plan_loss_backward_impl(p, idx, b, beta, false, stream, bv);
 }
 int gss_plan_backward(gss_plan *p, const int32_t *rows, int32_t b, const float *de_rows, void *stream) {
+  KnobScope knob_scope(p ? &p->knobs : nullptr);
   GSS_REQUIRE(p && rows, "plan_backward: null argument");
   GSS_REQUIRE(p->P == 1 && !p->desc.node_map, "plan_backward: an external upstream gradient is not supported on a sharded or relabelled plan");
   p->wt_valid = false;
@@ -882,13 +888,17 @@ int gss_plan_backward(gss_plan *p, const int32_t *rows, int32_t b, const float *
   return plan_backward_impl(p, bv, b, de_rows, false, false, stream);
 }
 int gss_plan_adam(gss_plan *p, void *stream) {
+  KnobScope knob_scope(p ? &p->knobs : nullptr);
   const int rc = plan_adam_impl(p, stream);
   if (p) p->wt_valid = false;
   return rc;
 }
 static int plan_step_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream, bool lazy);
 
-int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) { return plan_step_impl(p, idx, b, beta, stream, false); }
+int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
+  KnobScope knob_scope(p ? &p->knobs : nullptr);
+  return plan_step_impl(p, idx, b, beta, stream, false);
+}
 
 // The same step with the top layer evaluated on the batch rows only.  The loss reads the top layer's output on the b batch rows and
 // its backward pass reads AX of that layer (kept whole); A_hat M, the projection, ELU, the residual and the normalisation of the other
@@ -898,6 +908,7 @@ int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *
 // where the pieces it needs are absent (one layer, spmm_variant 1, gemm_variant 1).  On a sharded plan every shard evaluates the
 // top layer on the batch rows it owns.
 int gss_plan_step_lazy(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
+  KnobScope knob_scope(p ? &p->knobs : nullptr);
   GSS_REQUIRE(p, "plan_step_lazy: null plan");
   const gss_plan_desc &D = p->desc;
   const bool can = D.num_layers > 1 && spmm_sparse_available() && dense_row_list_available() && !D.pipeline_layer1 && p->pos;
@@ -955,6 +966,7 @@ static int plan_step_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta
 }
 
 int gss_plan_gather_embeddings(gss_plan *p, float *out, void *stream) {
+  KnobScope knob_scope(p ? &p->knobs : nullptr);
   GSS_REQUIRE(p && out, "plan_gather_embeddings: null argument");
   const gss_plan_desc &D = p->desc;
   hipStream_t st = as_stream(stream);

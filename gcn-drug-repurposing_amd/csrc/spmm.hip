@@ -238,8 +238,7 @@ __global__ __launch_bounds__(kLongThreads) void spmm_long_kernel(CsrView a, cons
 // A persistent launch (512-1024 resident workgroups looping over segment blocks, the next block's descriptor and first
 // (col, val) chunk requested under the current block's epilogue) measured 36.9 us vs 30.8 us at d = 128: the loop costs
 // more in the per-block code than the hardware dispatcher costs between workgroups.
-constexpr int kSegEdgesDefault = 32;
-int g_seg_edges = kSegEdgesDefault;  // debug knob "spmm_seg_edges" (applies to CSR handles created afterwards)
+// debug knob "spmm_seg_edges" (applies to CSR handles created afterwards)   [knob seg_edges, common.h Knobs]
 constexpr int kBalThreads = 1024;  // 512-thread workgroups measured 5-30 % slower (hub rows get half the groups)
 constexpr int kBalWaves = kBalThreads / 64;
 
@@ -530,7 +529,6 @@ static int launch_spmm_t(const gss_csr *a, int d4, const float *x, const SpmmEpi
   return GSS_OK;
 }
 
-int g_spmm_variant = 2;
 
 // Segment descriptors for the balanced kernel, built on first use for a given groups-per-wave count.
 int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks) {
@@ -541,7 +539,7 @@ int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks
     return GSS_OK;
   }
   std::vector<int32_t> segs;
-  const int nblk = build_segments(m->h_rowptr.data(), a->n_rows, kBalWaves, gpw_log2, g_seg_edges, segs);
+  const int nblk = build_segments(m->h_rowptr.data(), a->n_rows, kBalWaves, gpw_log2, K().seg_edges, segs);
   const size_t bytes = segs.size() * sizeof(int32_t);
   if (bytes) {
     GSS_HIP(hipMalloc((void **)&m->d_segs[gpw_log2], bytes));
@@ -553,10 +551,10 @@ int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks
   return GSS_OK;
 }
 
-int g_spmm_fly = 4;     // debug knob "spmm_fly": row gathers in flight per lane group on the large-table path (4 or 8)
-int g_spmm_hot = -1;    // debug knob "spmm_hot_rows": overrides every CSR's hot set with rows [0, value) (-1 = use the CSR's own, 0 = none)
-int g_spmm_slices = 0;  // 0 = automatic (see launch_balanced)
-int g_spmm_pin = 0;     // with a manual "spmm_slices": slices pinned to XCDs (1) or time-separated (0)
+// debug knob "spmm_fly": row gathers in flight per lane group on the large-table path (4 or 8)   [knob spmm_fly, common.h Knobs]
+// debug knob "spmm_hot_rows": overrides every CSR's hot set with rows [0, value) (-1 = use the CSR's own, 0 = none)   [knob spmm_hot, common.h Knobs]
+// 0 = automatic (see launch_balanced)   [knob spmm_slices, common.h Knobs]
+// with a manual "spmm_slices": slices pinned to XCDs (1) or time-separated (0)   [knob spmm_pin, common.h Knobs]
 
 template <int MODE, int LPR_LOG2, int VPL>
 static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool pin, const float *x, const SpmmEpi &ep, hipStream_t st) {
@@ -567,14 +565,14 @@ static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool p
   CsrView v{a->rowptr, a->col, a->val, a->n_rows};
   const size_t lds = (size_t)kBalWaves * d4_slice * sizeof(float4);
   int3 hot = make_int3(a->hot_own, a->hot_halo0, a->hot_halo1);
-  if (g_spmm_hot >= 0) hot = g_spmm_hot > 0 ? make_int3(g_spmm_hot, 0, 0) : make_int3(-1, 0, 0);
+  if (K().spmm_hot >= 0) hot = K().spmm_hot > 0 ? make_int3(K().spmm_hot, 0, 0) : make_int3(-1, 0, 0);
   // the hot / cold split pays where the table is far beyond the caches; below that every row is "hot"
-  if ((double)a->n_cols * d4_slice * nslices * 16.0 < 256.0 * 1024 * 1024 && g_spmm_hot < 0) hot = make_int3(-1, 0, 0);
-  const bool narrow = (double)a->n_cols * d4_slice * nslices * 16.0 < 4.0e9 && a->n_cols < (1 << 24) && hot.x < 0 && g_spmm_fly == 4;
+  if ((double)a->n_cols * d4_slice * nslices * 16.0 < 256.0 * 1024 * 1024 && K().spmm_hot < 0) hot = make_int3(-1, 0, 0);
+  const bool narrow = (double)a->n_cols * d4_slice * nslices * 16.0 < 4.0e9 && a->n_cols < (1 << 24) && hot.x < 0 && K().spmm_fly == 4;
   if (narrow)
     hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, true>), pin ? dim3(nblk * nslices) : dim3(nblk, nslices), dim3(kBalThreads),
                        lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, make_int3(-1, 0, 0));
-  else if (g_spmm_fly == 8)
+  else if (K().spmm_fly == 8)
     hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, false, 8>), pin ? dim3(nblk * nslices) : dim3(nblk, nslices), dim3(kBalThreads),
                        lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, hot);
   else
@@ -586,8 +584,8 @@ static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool p
 
 template <int MODE>
 static int launch_balanced(const gss_csr *a, int d4, const float *x, const SpmmEpi &ep, hipStream_t st) {
-  int ns = g_spmm_slices;
-  bool pin = g_spmm_pin != 0;
+  int ns = K().spmm_slices;
+  bool pin = K().spmm_pin != 0;
   if (ns == 0) {
     // automatic: cut the features into 256-B slices when the gathered operand is well beyond one XCD's 4 MB L2.
     //  * small operands (<= 64 MB, the Infinity Cache holds them whole): slices pinned to XCDs -- slice = workgroup
@@ -624,7 +622,7 @@ static int launch_spmm(const gss_csr *a, int32_t d, const float *x, const SpmmEp
   GSS_REQUIRE(a && x, "spmm: null operand");
   hipStream_t st = as_stream(stream);
   const int d4 = d / 4;
-  if (g_spmm_variant == 2) return launch_balanced<MODE>(a, d4, x, ep, st);
+  if (K().spmm_variant == 2) return launch_balanced<MODE>(a, d4, x, ep, st);
   if (d4 <= 4) return launch_spmm_t<MODE, 2, 1>(a, d4, x, ep, st);
   if (d4 <= 8) return launch_spmm_t<MODE, 3, 1>(a, d4, x, ep, st);
   if (d4 <= 16) return launch_spmm_t<MODE, 4, 1>(a, d4, x, ep, st);
@@ -638,9 +636,9 @@ static int launch_spmm(const gss_csr *a, int32_t d, const float *x, const SpmmEp
 int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream, const int32_t *row_pos,
              const uint32_t *row_bits, const float *y_in, const uint32_t *gather_bits) {
   GSS_REQUIRE(y, "spmm: y is null");
-  GSS_REQUIRE(!row_pos || (!m && g_spmm_variant == 2), "spmm: a row map goes with the plain product of the balanced SpMM only");
-  GSS_REQUIRE(!row_bits || (m && g_spmm_variant == 2), "spmm: a row bitmap goes with the Hadamard-fused product of the balanced SpMM only");
-  GSS_REQUIRE((!y_in && !gather_bits) || g_spmm_variant == 2, "spmm: a two-pass product needs the balanced SpMM (spmm_variant 2)");
+  GSS_REQUIRE(!row_pos || (!m && K().spmm_variant == 2), "spmm: a row map goes with the plain product of the balanced SpMM only");
+  GSS_REQUIRE(!row_bits || (m && K().spmm_variant == 2), "spmm: a row bitmap goes with the Hadamard-fused product of the balanced SpMM only");
+  GSS_REQUIRE((!y_in && !gather_bits) || K().spmm_variant == 2, "spmm: a two-pass product needs the balanced SpMM (spmm_variant 2)");
   GSS_REQUIRE(!gather_bits || !m, "spmm: a gather filter goes with the plain product only");
   if (m) {
     GSS_REQUIRE(h, "spmm: m given without h");
@@ -657,7 +655,7 @@ int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float 
 int spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
               float *u, float *t, void *stream, const float *y_in) {
   GSS_REQUIRE(g_am && g_ax && x_in && ax && u && t, "spmm_bwd1: null operand");
-  GSS_REQUIRE(!y_in || g_spmm_variant == 2, "spmm_bwd1: a two-pass product needs the balanced SpMM (spmm_variant 2)");
+  GSS_REQUIRE(!y_in || K().spmm_variant == 2, "spmm_bwd1: a two-pass product needs the balanced SpMM (spmm_variant 2)");
   SpmmEpi ep{g_ax, x_in, ax, u, t, 0.f, nullptr, nullptr, nullptr, nullptr};
   ep.y_in = y_in;
   return launch_spmm<SPMM_BWD1>(at, d, g_am, ep, stream);
@@ -667,7 +665,7 @@ int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const fl
                      const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream, const uint32_t *posbits,
                      uint32_t *nzbits_out, int skip_zero_rows) {
   GSS_REQUIRE(g_am_b && g_ax_b && pos && pos_row && x_in && ax && u && t, "spmm_bwd1_sparse: null operand");
-  GSS_REQUIRE(g_spmm_variant == 2, "spmm_bwd1_sparse needs the balanced SpMM (spmm_variant 2)");
+  GSS_REQUIRE(K().spmm_variant == 2, "spmm_bwd1_sparse needs the balanced SpMM (spmm_variant 2)");
   GSS_REQUIRE(!skip_zero_rows || nzbits_out, "spmm_bwd1_sparse: skipping the zero rows needs the bitmap that records them");
   SpmmEpi ep{g_ax_b, x_in, ax, u, t, 0.f, pos, pos_row, posbits, nzbits_out, skip_zero_rows};
   return launch_spmm<SPMM_BWD1S>(at, d, g_am_b, ep, stream);
@@ -676,13 +674,13 @@ int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const fl
 int spmm_bwd2_sparse_res(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res_b,
                          const int32_t *pos_row, float *dp, float *gx_out, void *stream, const uint32_t *nzbits, const float *y_in) {
   GSS_REQUIRE(u && t && p && res_b && pos_row && dp, "spmm_bwd2_sparse_res: null operand");
-  GSS_REQUIRE(g_spmm_variant == 2, "spmm_bwd2_sparse_res needs the balanced SpMM (spmm_variant 2)");
+  GSS_REQUIRE(K().spmm_variant == 2, "spmm_bwd2_sparse_res needs the balanced SpMM (spmm_variant 2)");
   SpmmEpi ep{t, p, res_b, dp, gx_out, c, nullptr, pos_row, nzbits, nullptr, 0};
   ep.y_in = y_in;
   return launch_spmm<SPMM_BWD2S>(at, d, u, ep, stream);
 }
 
-bool spmm_sparse_available() { return g_spmm_variant == 2; }
+bool spmm_sparse_available() { return K().spmm_variant == 2; }
 
 // bits[r] := 1 for every listed row r and every column of the listed rows of `a` (one wave per listed row)
 __global__ __launch_bounds__(256) void mark_rows_and_neighbours_kernel(CsrView a, const int32_t *__restrict__ rows, int b, uint32_t *__restrict__ bits) {
@@ -710,7 +708,7 @@ int mark_rows_and_neighbours(const gss_csr *a, const int32_t *rows, int32_t b, u
 int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
               float *dp, float *gx_out, void *stream, const float *y_in) {
   GSS_REQUIRE(u && t && p && dp, "spmm_bwd2: null operand");
-  GSS_REQUIRE(!y_in || g_spmm_variant == 2, "spmm_bwd2: a two-pass product needs the balanced SpMM (spmm_variant 2)");
+  GSS_REQUIRE(!y_in || K().spmm_variant == 2, "spmm_bwd2: a two-pass product needs the balanced SpMM (spmm_variant 2)");
   SpmmEpi ep{t, p, res, dp, gx_out, c, nullptr, nullptr, nullptr, nullptr};
   ep.y_in = y_in;
   return launch_spmm<SPMM_BWD2>(at, d, u, ep, stream);

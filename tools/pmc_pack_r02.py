@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/pmc/r02_* (tools/pmc_spmm_r02.sh, pmc_spmm_r02b.sh) -> profiles/r02_spmm_pmc.json: per SpMM launch the memory-side
+"""gpurun_out/pmc/<round>_* (tools/pmc_spmm_r02.sh, pmc_spmm_r02b.sh; tools/profile_r03.sh; usage: pmc_pack_r02.py [round tag, default r02]) -> profiles/<round>_spmm_pmc.json: per SpMM launch the memory-side
 counters, corrected as MI355X_MICROARCH.md section HBM prescribes (FETCH_SIZE counts the 128-B requests of wide reads at
 64 B on gfx950 -> doubled; WRITE_SIZE exact; both in KB), next to the algorithmic bytes of SURVEY.md section 8(d)."""
 import collections
@@ -11,6 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PMC = os.path.join(ROOT, "gpurun_out", "pmc")
+PREFIX = sys.argv[1] if len(sys.argv) > 1 else "r02"     # round tag of the passes (tools/pmc_spmm_r02*.sh, tools/profile_r03.sh)
 CASES = {  # tag -> (description, n, nnz, d, extra operand rows)
     "wg_fwd1": ("whole_graph stand-in as bench.py runs it (nodes relabelled hub-first), spmm_balanced_kernel<FWD1> (AX = A_hat X, M = AX (.) X)", 29960, 988028, 128, 1),
     "wg_plain": ("whole_graph stand-in as bench.py runs it (nodes relabelled hub-first), spmm_balanced_kernel<PLAIN> (AM = A_hat M)", 29960, 988028, 128, 0),
@@ -25,7 +26,7 @@ CASES = {  # tag -> (description, n, nnz, d, extra operand rows)
 
 def counters(tag):
     acc, dur = collections.defaultdict(list), []
-    for d in glob.glob(os.path.join(PMC, f"r02_{tag}_*")):
+    for d in glob.glob(os.path.join(PMC, f"{PREFIX}_{tag}_*")):
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
                 if "spmm_balanced" in r["Kernel_Name"]:
@@ -59,7 +60,7 @@ for tag, (desc, n, nnz, d, extra) in CASES.items():
         out["hbm_traffic"]["fwd1"] = {"traffic_bytes_per_launch": fetch + write}
     if tag == "wg_plain":
         out["hbm_traffic"]["plain"] = {"traffic_bytes_per_launch": fetch + write}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_spmm_pmc.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{PREFIX}_spmm_pmc.json"), "w"), indent=1)
 for tag, c in out["cases"].items():
     print(f"{tag:14s} traffic {c['traffic_bytes_per_launch'] / 1e9:8.3f} GB = {c['traffic_over_alg']:.2f} x alg, L2 hit {c['l2_hit_rate']:.3f}, "
           f"{c['avg_launch_us_profiled']:.1f} us, traffic {c['traffic_TBps']:.2f} TB/s, alg {c['alg_TBps']:.3f} TB/s")
