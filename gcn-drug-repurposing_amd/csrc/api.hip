@@ -87,6 +87,11 @@ int gss_debug_set_option(const char *name, int value) {
     g_knobs.wgrad_prio = value;
     return GSS_OK;
   }
+  if (strcmp(name, "gemm_lds_kb") == 0 || strcmp(name, "wgrad_lds_kb") == 0 || strcmp(name, "loss_lds_kb") == 0) {
+    GSS_REQUIRE(value >= 0 && value <= 160, "%s must be in [0, 160] (KB of dynamic LDS per workgroup, 0 = what the kernel needs)", name);
+    (name[0] == 'g' ? g_knobs.gemm_lds_kb : name[0] == 'w' ? g_knobs.wgrad_lds_kb : g_knobs.loss_lds_kb) = value;
+    return GSS_OK;
+  }
   if (strcmp(name, "gemm_variant") == 0) {
     GSS_REQUIRE(value >= 1 && value <= 4, "gemm_variant must be 1..4");
     g_knobs.gemm_variant = value;

@@ -32,7 +32,18 @@ struct Knobs {
   int xcd_remap = 1;         // workgroups that share input rows on one XCD
   int loss_wgs = 256;        // workgroups the loss sweep's grid aims at
   int sparse_bits_rows = 100000;  // operand rows from which a plan keeps the bitmaps of the sparsity-aware backward hops
+  // occupancy control by LDS footprint (KB of dynamic LDS requested per workgroup, 0 = what the kernel needs): the hardware dispatcher
+  // places as many workgroups on a CU as fit, not one per CU -- a grid of 256 "one per CU" workgroups may double up on some CUs and
+  // leave others idle.  > 80 KB admits one workgroup per CU, 54-80 KB two.
+  int gemm_lds_kb = 0, wgrad_lds_kb = 0, loss_lds_kb = 0;
 };
+template <typename F>
+inline size_t lds_request(F kernel, size_t need, int knob_kb) {
+  size_t lds = need;
+  if (knob_kb > 0 && (size_t)knob_kb * 1024 > lds) lds = (size_t)knob_kb * 1024;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  return lds;
+}
 extern Knobs g_knobs;
 extern thread_local const Knobs *t_knobs;
 inline const Knobs &K() { return t_knobs ? *t_knobs : g_knobs; }

@@ -431,9 +431,9 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
 #define GSS_GEMM_CASE(NTV)                                                                              \
   case NTV:                                                                                             \
     if (mt == 2)                                                                                        \
-      hipLaunchKernelGGL((gemm_nt_lds_kernel<NTV, 2, EPI>), grid, dim3(256), lds, st, g);               \
+      hipLaunchKernelGGL((gemm_nt_lds_kernel<NTV, 2, EPI>), grid, dim3(256), lds_request(gemm_nt_lds_kernel<NTV, 2, EPI>, lds, K().gemm_lds_kb), st, g); \
     else                                                                                                \
-      hipLaunchKernelGGL((gemm_nt_lds_kernel<NTV, 1, EPI>), grid, dim3(256), lds, st, g);               \
+      hipLaunchKernelGGL((gemm_nt_lds_kernel<NTV, 1, EPI>), grid, dim3(256), lds_request(gemm_nt_lds_kernel<NTV, 1, EPI>, lds, K().gemm_lds_kb), st, g); \
     break;
     switch (nt) {
       GSS_GEMM_CASE(8)
@@ -835,7 +835,8 @@ int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const 
   }
   if (d % 64 == 0) {
     const int tiles = (d / 64) * (2 * d / 64);
-    hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns), dim3(64 * kWgWaves), 4 * 16 * 64 * sizeof(float4), st, g, g, ns);
+    hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns), dim3(64 * kWgWaves), lds_request(wgrad_tn_kernel, 4 * 16 * 64 * sizeof(float4), K().wgrad_lds_kb),
+                       st, g, g, ns);
     GSS_LAUNCH_CHECK("wgrad_tn_kernel");
   } else {
     hipLaunchKernelGGL(wgrad_simple_kernel, dim3(ceil_div((int64_t)d * 2 * d + d, 256), ns), dim3(256), 0, st, g);
@@ -865,8 +866,8 @@ int wgrad_partial_pair(int32_t d, int32_t n0, const float *dp0, const float *ax0
   WgradArgs g0{n0, d, dp0, ax0, am0, rows0, base_w + (size_t)slice0_0 * d * 2 * d, base_b + (size_t)slice0_0 * d, rps0, K().xcd_remap, K().wgrad_prio};
   WgradArgs g1{n1, d, dp1, ax1, am1, rows1, base_w + (size_t)slice0_1 * d * 2 * d, base_b + (size_t)slice0_1 * d, rps1, K().xcd_remap, K().wgrad_prio};
   const int tiles = (d / 64) * (2 * d / 64);
-  hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns0 + ns1), dim3(64 * kWgWaves), 4 * 16 * 64 * sizeof(float4), as_stream(stream), g0, g1,
-                     ns0);
+  hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns0 + ns1), dim3(64 * kWgWaves),
+                     lds_request(wgrad_tn_kernel, 4 * 16 * 64 * sizeof(float4), K().wgrad_lds_kb), as_stream(stream), g0, g1, ns0);
   GSS_LAUNCH_CHECK("wgrad_tn_kernel");
   return GSS_OK;
 }
