@@ -31,7 +31,7 @@ class PprDesc(C.Structure):
                 + [("n_z", C.c_int32), ("z_rows", C.c_void_p), ("n_ovr", C.c_int64)]
                 + [(k, C.c_void_p) for k in ("ovr_col", "ovr_row", "ovr_ratio", "zero_ptr", "zero_ovr")]
                 + [("n_sel", C.c_int64)]
-                + [(k, C.c_void_p) for k in ("sel_col", "sel_row", "sel_val", "keep_ptr", "keep_row", "keep_val")])
+                + [(k, C.c_void_p) for k in ("sel_col", "sel_row", "sel_val", "keep_ptr", "keep_row", "keep_val", "ovr_ptr")])
 
 
 class HaloDesc(C.Structure):

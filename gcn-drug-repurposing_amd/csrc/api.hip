@@ -92,6 +92,10 @@ int gss_debug_set_option(const char *name, int value) {
     (name[0] == 'g' ? g_knobs.gemm_lds_kb : name[0] == 'w' ? g_knobs.wgrad_lds_kb : g_knobs.loss_lds_kb) = value;
     return GSS_OK;
   }
+  if (strcmp(name, "ppr_fused") == 0) {
+    g_knobs.ppr_fused = value ? 1 : 0;   // handles created afterwards
+    return GSS_OK;
+  }
   if (strcmp(name, "gemm_variant") == 0) {
     GSS_REQUIRE(value >= 1 && value <= 4, "gemm_variant must be 1..4");
     g_knobs.gemm_variant = value;

@@ -36,6 +36,7 @@ struct Knobs {
   // places as many workgroups on a CU as fit, not one per CU -- a grid of 256 "one per CU" workgroups may double up on some CUs and
   // leave others idle.  > 80 KB admits one workgroup per CU, 54-80 KB two.
   int gemm_lds_kb = 0, wgrad_lds_kb = 0, loss_lds_kb = 0;
+  int ppr_fused = 1;         // diffusion profiles: the update and the column errors in the SpMM's epilogue (0 = separate update pass)
 };
 template <typename F>
 inline size_t lds_request(F kernel, size_t need, int knob_kb) {

@@ -14,6 +14,8 @@
 // time.  The 20-KB rows are walked in 512-B column chunks, time-separated (grid.y is the slow dispatch dimension), each
 // chunk as two 256-B slices pinned to XCD parity -- the configuration that won for the 15-MB fp32 table in spmm.hip
 // (one chunk of this matrix is exactly that table).  Partial sums meet in fixed order: bitwise reproducible.
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "ops.h"
@@ -33,6 +35,13 @@ struct gss_ppr {
   int32_t *iters;     // [kpad]
   int32_t *n_active;  // [1]
   int32_t n_rowblocks, n_zchunks;
+  // fused update (gss_ppr_desc.ovr_ptr / sel_ptr given): the SpMM's epilogue writes the next iterate and the column errors
+  double *ysel;       // [n][kpad], zero except the start nodes' "selected" rows: ysel[sel_row][c] = sel_val x[start[c]][c], rewritten every iteration
+  uint32_t *rowflag;  // [n bits]: row has an entry in ysel
+  double *part_e;     // [segment blocks][kpad]: per workgroup and column, sum of |x_new - x| over the rows the workgroup wrote
+  double *err_corr;   // [kpad]: correction of the column errors for the override entries (x was scaled in place during the product)
+  int32_t n_segblocks;
+  bool fused;
 };
 
 namespace gss {
@@ -51,11 +60,51 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 }
 
 // y[row][chunk] = sum_e val[e] * x[col[e]][chunk] for the segments of one workgroup; kpad doubles per row
-template <bool NARROW>
+// Fused update (gss_ppr_run with grouped override / start-row lists): instead of y the kernel writes the NEXT iterate
+//   x_new = alpha (y + ysel + dangling e_s) + (1 - alpha) e_s      (diffusion_profiles.py:84; the start node's own entry takes yself)
+// into the other half of a double buffer -- converged columns are copied across --, and per workgroup and column the sum of
+// |x_new - x| over the rows it wrote, reduced in a fixed order (lane groups by shuffles, waves through LDS).
+struct PprFuse {
+  const double *ysel;
+  const uint32_t *rowflag;
+  const int32_t *start, *iters;
+  const double *dsum, *yself;
+  double *part_e;
+  double alpha;
+  int k, it;
+};
+
+__device__ __forceinline__ double2 ppr_fuse_row(const PprFuse &f, int row, double2 acc, const double *__restrict__ x_cur, double *__restrict__ x_nxt,
+                                                 size_t off, int sA, int sB, bool dA, bool dB, double dsA, double dsB, double ysA, double ysB) {
+  if ((f.rowflag[(unsigned)row >> 5] >> (row & 31)) & 1u) {
+    const double2 s = *reinterpret_cast<const double2 *>(f.ysel + off);
+    acc.x += s.x;
+    acc.y += s.y;
+  }
+  const double2 xo = *reinterpret_cast<const double2 *>(x_cur + off);
+  double2 xn, err = make_double2(0.0, 0.0);
+  {
+    const double p = row == sA ? 1.0 : 0.0;
+    const double yv = row == sA ? ysA : acc.x;
+    xn.x = f.alpha * (yv + dsA * p) + (1.0 - f.alpha) * p;
+  }
+  {
+    const double p = row == sB ? 1.0 : 0.0;
+    const double yv = row == sB ? ysB : acc.y;
+    xn.y = f.alpha * (yv + dsB * p) + (1.0 - f.alpha) * p;
+  }
+  if (dA) xn.x = xo.x; else err.x = fabs(xn.x - xo.x);
+  if (dB) xn.y = xo.y; else err.y = fabs(xn.y - xo.y);
+  *reinterpret_cast<double2 *>(x_nxt + off) = xn;
+  return err;
+}
+
+template <bool NARROW, bool FUSED = false>
 __global__ __launch_bounds__(kPprThreads) void ppr_spmm_kernel(const int32_t *__restrict__ col, const double *__restrict__ val,
                                                                const int4 *__restrict__ segs, const double *__restrict__ x,
-                                                               double *__restrict__ y, int kpad, const int32_t *__restrict__ done) {
+                                                               double *__restrict__ y, int kpad, const int32_t *__restrict__ done, PprFuse f) {
   __shared__ double2 part[kPprWaves * 16];
+  __shared__ double2 errs[kPprWaves * 16];
   constexpr int LPR = 16, LOG = 4, GPW = 4;
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int g = lane >> LOG, li = lane & (LPR - 1);
@@ -64,7 +113,14 @@ __global__ __launch_bounds__(kPprThreads) void ppr_spmm_kernel(const int32_t *__
   // have all converged has nothing left to produce (padding columns count as converged from the start).  Workgroup-uniform.
   if (done) {
     const int c0 = blockIdx.y * 64 + half * 32;
-    if (__all(done[c0 + (lane & 31)] != 0)) return;
+    if (FUSED) {
+      // double-buffered x: a converged column is copied across once more in the iteration after it converged (both halves of the
+      // buffer then hold its final values); from the iteration after that its group may be skipped (padding columns: iters = -1)
+      const int ic = f.iters[c0 + (lane & 31)];
+      if (__all(ic != 0 && ic <= f.it - 2)) return;
+    } else if (__all(done[c0 + (lane & 31)] != 0)) {
+      return;
+    }
   }
   const int4 sd = segs[((size_t)sblk * kPprWaves + wib) * GPW + g];  // {row, first entry, entries, flags | log2 p}
   const int row = sd.x;
@@ -126,19 +182,68 @@ __global__ __launch_bounds__(kPprThreads) void ppr_spmm_kernel(const int32_t *__
       acc.y += ty;
     }
   }
-  if (pcount <= GPW && row >= 0 && (g & (pcount - 1)) == 0) *reinterpret_cast<double2 *>(y + (size_t)row * kpad + coff) = acc;
-  if (!multiwave) return;
-  const int nw = pcount > GPW ? pcount / GPW : 1;
-  if (nw > 1 && g == 0) part[wib * 16 + li] = acc;
-  __syncthreads();
-  if (nw > 1 && (wib & (nw - 1)) == 0 && g == 0 && row >= 0) {
-    double2 t = part[wib * 16 + li];
-    for (int k = 1; k < nw; ++k) {
-      const double2 q = part[(wib + k) * 16 + li];
-      t.x += q.x;
-      t.y += q.y;
+  // this lane's two columns in the fused update
+  int sA = -1, sB = -1;
+  bool dA = true, dB = true;
+  double dsA = 0.0, dsB = 0.0, ysA = 0.0, ysB = 0.0;
+  double2 err = make_double2(0.0, 0.0);
+  if (FUSED) {
+    const int cA = (int)coff, cB = (int)coff + 1;
+    dA = done[cA] != 0;
+    dB = done[cB] != 0;
+    if (cA < f.k) {
+      sA = f.start[cA];
+      dsA = f.dsum[cA];
+      ysA = f.yself[cA];
     }
-    *reinterpret_cast<double2 *>(y + (size_t)row * kpad + coff) = t;
+    if (cB < f.k) {
+      sB = f.start[cB];
+      dsB = f.dsum[cB];
+      ysB = f.yself[cB];
+    }
+  }
+  if (pcount <= GPW && row >= 0 && (g & (pcount - 1)) == 0) {
+    const size_t off = (size_t)row * kpad + coff;
+    if (FUSED)
+      err = ppr_fuse_row(f, row, acc, x, y, off, sA, sB, dA, dB, dsA, dsB, ysA, ysB);
+    else
+      *reinterpret_cast<double2 *>(y + off) = acc;
+  }
+  if (!FUSED && !multiwave) return;
+  const int nw = pcount > GPW ? pcount / GPW : 1;
+  if (multiwave) {   // workgroup-uniform
+    if (nw > 1 && g == 0) part[wib * 16 + li] = acc;
+    __syncthreads();
+    if (nw > 1 && (wib & (nw - 1)) == 0 && g == 0 && row >= 0) {
+      double2 t = part[wib * 16 + li];
+      for (int k = 1; k < nw; ++k) {
+        const double2 q = part[(wib + k) * 16 + li];
+        t.x += q.x;
+        t.y += q.y;
+      }
+      const size_t off = (size_t)row * kpad + coff;
+      if (FUSED)
+        err = ppr_fuse_row(f, row, t, x, y, off, sA, sB, dA, dB, dsA, dsB, ysA, ysB);
+      else
+        *reinterpret_cast<double2 *>(y + off) = t;
+    }
+  }
+  if (!FUSED) return;
+  // column errors of this workgroup: the 4 lane groups of a wave by shuffles, the 16 waves through LDS, always in the same order
+#pragma unroll
+  for (int o = 1; o < GPW; o <<= 1) {
+    err.x += shfl_xor_f64(err.x, o * LPR);
+    err.y += shfl_xor_f64(err.y, o * LPR);
+  }
+  if (g == 0) errs[wib * 16 + li] = err;
+  __syncthreads();
+  if (wib == 0 && g == 0) {
+    double2 t = errs[li];
+    for (int k = 1; k < kPprWaves; ++k) {
+      t.x += errs[k * 16 + li].x;
+      t.y += errs[k * 16 + li].y;
+    }
+    *reinterpret_cast<double2 *>(f.part_e + (size_t)sblk * kpad + coff) = t;
   }
 }
 
@@ -162,7 +267,7 @@ __global__ void ppr_init_kernel(double *x, size_t total, int kpad, int k, double
   if (i < total) x[i] = (int)(i % kpad) < k ? v : 0.0;
   if (i < (size_t)kpad) {
     done[i] = (int)i < k ? 0 : 1;
-    iters[i] = 0;
+    iters[i] = (int)i < k ? 0 : -1;   // padding columns: converged "before the first iteration" (the fused kernel's skip rule)
   }
 }
 
@@ -252,6 +357,61 @@ __global__ __launch_bounds__(256) void ppr_update_kernel(double *__restrict__ x,
   part[(size_t)blockIdx.y * kpad + c] = err;
 }
 
+// fused update: the start nodes' "selected" rows as a sparse addend of the product, ysel[row][c] = val * x[start[c]][c]  (x unscaled:
+// this runs before ppr_ovr_scale_kernel)
+__global__ void ppr_ysel_kernel(double *__restrict__ ysel, const double *__restrict__ x, const int32_t *__restrict__ sel_col,
+                                const int32_t *__restrict__ sel_row, const double *__restrict__ sel_val, long n_sel,
+                                const int32_t *__restrict__ start, int kpad) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_sel) return;
+  const int c = sel_col[e];
+  ysel[(size_t)sel_row[e] * kpad + c] = sel_val[e] * x[(size_t)start[c] * kpad + c];
+}
+__global__ void ppr_rowflag_kernel(uint32_t *__restrict__ flag, const int32_t *__restrict__ sel_row, long n_sel) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n_sel) atomicOr(&flag[(unsigned)sel_row[e] >> 5], 1u << (sel_row[e] & 31));
+}
+
+// fused update, after the product: the override entries of x were scaled IN PLACE while the fused epilogue read x as "the previous
+// iterate".  One wave per column walks the column's overrides (grouped by column: ovr_ptr) and repairs what that touched: a converged
+// column's copy takes the true value; for the others the column error gets |x_new - true| - |x_new - scaled|, summed over the
+// entries in a fixed order (lanes stride the list, shuffle tree).
+__global__ __launch_bounds__(256) void ppr_ovr_fix_kernel(double *__restrict__ x_nxt, const int32_t *__restrict__ ovr_ptr,
+                                                          const int32_t *__restrict__ ovr_row, const double *__restrict__ ratio,
+                                                          const double *__restrict__ stash_o, const int32_t *__restrict__ done, int k, int kpad,
+                                                          double *__restrict__ err_corr) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= k) return;
+  const bool dn = done[c] != 0;
+  double corr = 0.0;
+  for (int e = ovr_ptr[c] + lane; e < ovr_ptr[c + 1]; e += 64) {
+    const size_t i = (size_t)ovr_row[e] * kpad + c;
+    const double tru = stash_o[e], scaled = tru * ratio[e];
+    if (dn) {
+      x_nxt[i] = tru;
+    } else {
+      const double xn = x_nxt[i];
+      corr += fabs(xn - tru) - fabs(xn - scaled);
+    }
+  }
+  corr = wave_sum_d(corr);
+  if (lane == 0) err_corr[c] = corr;
+}
+
+__global__ void ppr_finish_fused_kernel(const double *__restrict__ part_e, int n_blocks, const double *__restrict__ err_corr, int k, int kpad,
+                                        double thr, int it, int32_t *__restrict__ done, int32_t *__restrict__ iters, int32_t *__restrict__ n_active) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= k || done[c]) return;
+  const double err = column_sum(part_e, n_blocks, kpad, c) + err_corr[c];
+  if (err < thr) {
+    done[c] = 1;
+    iters[c] = it;
+  } else {
+    atomicAdd(n_active, 1);
+  }
+}
+
 __global__ void ppr_finish_kernel(const double *__restrict__ part, int n_blocks, int k, int kpad, double thr, int it, int32_t *__restrict__ done,
                                   int32_t *__restrict__ iters, int32_t *__restrict__ n_active) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -265,18 +425,25 @@ __global__ void ppr_finish_kernel(const double *__restrict__ part, int n_blocks,
   }
 }
 
-static int ppr_spmm_launch(gss_ppr *p, const double *x, double *y, hipStream_t st, const int32_t *done = nullptr) {
+static int ppr_spmm_launch(gss_ppr *p, const double *x, double *y, hipStream_t st, const int32_t *done = nullptr, const PprFuse *fuse = nullptr) {
   const int4 *segs = nullptr;
   int nblk = 0;
   if (int rc = csr_segments(p->csr, 2, &segs, &nblk)) return rc;
   if (nblk == 0) return GSS_OK;
+  GSS_REQUIRE(!fuse || nblk == p->n_segblocks, "ppr: the segment schedule changed under a fused plan (%d blocks, %d expected)", nblk, p->n_segblocks);
   const bool narrow = (double)p->d.n * p->d.kpad * 8.0 < 4.0e9 && p->d.n < (1 << 24) && (int64_t)p->d.kpad * 8 < (1 << 24);
-  if (narrow)
-    hipLaunchKernelGGL(ppr_spmm_kernel<true>, dim3(nblk * 2, p->d.kpad / 64), dim3(kPprThreads), 0, st, p->d.t_col, p->d.t_val, segs, x, y,
-                       p->d.kpad, done);
-  else
-    hipLaunchKernelGGL(ppr_spmm_kernel<false>, dim3(nblk * 2, p->d.kpad / 64), dim3(kPprThreads), 0, st, p->d.t_col, p->d.t_val, segs, x, y,
-                       p->d.kpad, done);
+  const dim3 grid(nblk * 2, p->d.kpad / 64), block(kPprThreads);
+  const PprFuse none{};
+  if (fuse) {
+    if (narrow)
+      hipLaunchKernelGGL((ppr_spmm_kernel<true, true>), grid, block, 0, st, p->d.t_col, p->d.t_val, segs, x, y, p->d.kpad, done, *fuse);
+    else
+      hipLaunchKernelGGL((ppr_spmm_kernel<false, true>), grid, block, 0, st, p->d.t_col, p->d.t_val, segs, x, y, p->d.kpad, done, *fuse);
+  } else if (narrow) {
+    hipLaunchKernelGGL((ppr_spmm_kernel<true, false>), grid, block, 0, st, p->d.t_col, p->d.t_val, segs, x, y, p->d.kpad, done, none);
+  } else {
+    hipLaunchKernelGGL((ppr_spmm_kernel<false, false>), grid, block, 0, st, p->d.t_col, p->d.t_val, segs, x, y, p->d.kpad, done, none);
+  }
   GSS_LAUNCH_CHECK("ppr_spmm_kernel");
   return GSS_OK;
 }
@@ -309,14 +476,28 @@ int gss_ppr_create(gss_ppr **out, const gss_ppr_desc *desc) {
   }
   p->n_rowblocks = ceil_div(D.n, kPprRows);
   p->n_zchunks = ceil_div(D.n_z, kPprRows);
+  // fused update: needs the overrides grouped by column (ovr_ptr); knob "ppr_fused" = 0 keeps the separate update pass (A/B)
+  p->fused = K().ppr_fused != 0 && (D.n_ovr == 0 || D.ovr_ptr != nullptr);
+  p->n_segblocks = 0;
+  p->ysel = p->part_e = p->err_corr = nullptr;
+  p->rowflag = nullptr;
+  if (p->fused) {
+    const int4 *segs = nullptr;
+    if (int rc = csr_segments(p->csr, 2, &segs, &p->n_segblocks)) {
+      gss_csr_destroy(p->csr);
+      delete p;
+      return rc;
+    }
+  }
   const size_t row = (size_t)D.kpad * sizeof(double);
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const size_t b_y = al((size_t)D.n * row), b_so = al((size_t)D.n_ovr * sizeof(double)),
                b_part = al((size_t)std::max(p->n_rowblocks, std::max(p->n_zchunks, 1)) * row), b_col = al(row),
                b_int = al((size_t)D.kpad * sizeof(int32_t));
+  const size_t b_flag = al(((size_t)D.n / 32 + 1) * sizeof(uint32_t)), b_pe = al((size_t)std::max(p->n_segblocks, 1) * row);
   // every carved buffer is followed by a 256-byte guard (as in plan.hip): gss_ppr_check_guards verifies that no kernel wrote one
   constexpr size_t kGuard = 256;
-  p->slab_bytes = b_y + b_so + b_part + 2 * b_col + 2 * b_int + 256 + 8 * kGuard;
+  p->slab_bytes = b_y + b_so + b_part + 2 * b_col + 2 * b_int + 256 + 8 * kGuard + (p->fused ? b_y + b_flag + b_pe + b_col + 4 * kGuard : 0);
   if (hipMalloc((void **)&p->slab, p->slab_bytes) != hipSuccess) {
     gss_csr_destroy(p->csr);
     const size_t want = p->slab_bytes;
@@ -340,6 +521,20 @@ int gss_ppr_create(gss_ppr **out, const gss_ppr_desc *desc) {
   p->iters = (int32_t *)take(b_int);
   p->n_active = (int32_t *)take(256);
   hipError_t ge = hipSuccess;
+  if (p->fused) {
+    p->ysel = (double *)take(b_y);
+    p->rowflag = (uint32_t *)take(b_flag);
+    p->part_e = (double *)take(b_pe);
+    p->err_corr = (double *)take(b_col);
+    ge = hipMemset(p->ysel, 0, b_y);
+    if (ge == hipSuccess) ge = hipMemset(p->rowflag, 0, b_flag);
+    if (ge == hipSuccess) ge = hipMemset(p->part_e, 0, b_pe);
+    if (ge == hipSuccess) ge = hipMemset(p->err_corr, 0, b_col);
+    if (ge == hipSuccess && D.n_sel > 0) {
+      hipLaunchKernelGGL(ppr_rowflag_kernel, dim3(ceil_div(D.n_sel, 256)), dim3(256), 0, nullptr, p->rowflag, D.sel_row, (long)D.n_sel);
+      ge = hipGetLastError();
+    }
+  }
   for (size_t g : p->guard_off)
     if (ge == hipSuccess) ge = hipMemset(p->slab + g, 0xA5, kGuard);
   if (ge == hipSuccess) ge = hipDeviceSynchronize();
@@ -393,41 +588,66 @@ int gss_ppr_run(gss_ppr *p, double alpha, double tol, int32_t max_iter, double *
   const double thr = (double)D.n * tol;  // diffusion_profiles.py:87
   int32_t active = D.k;
   int it = 0;
+  // fused: x is double-buffered (the caller's buffer and p->y swap roles every iteration); `cur` holds the current iterate
+  double *cur = x, *nxt = p->y;
   while (active > 0 && it < max_iter) {
     ++it;
     if (D.n_z > 0) {
-      hipLaunchKernelGGL(ppr_dangling_kernel, dim3(col_tiles.x, p->n_zchunks), dim3(256), 0, st, x, D.z_rows, D.n_z, D.start, D.k, D.kpad, p->part);
+      hipLaunchKernelGGL(ppr_dangling_kernel, dim3(col_tiles.x, p->n_zchunks), dim3(256), 0, st, cur, D.z_rows, D.n_z, D.start, D.k, D.kpad, p->part);
       GSS_LAUNCH_CHECK("ppr_dangling_kernel");
     }
+    if (p->fused && D.n_sel > 0) {   // before the overrides are scaled: it reads the start nodes' own entries
+      hipLaunchKernelGGL(ppr_ysel_kernel, dim3(ceil_div(D.n_sel, 256)), dim3(256), 0, st, p->ysel, cur, D.sel_col, D.sel_row, D.sel_val, (long)D.n_sel,
+                         D.start, D.kpad);
+      GSS_LAUNCH_CHECK("ppr_ysel_kernel");
+    }
     if (D.n_ovr > 0) {
-      hipLaunchKernelGGL(ppr_ovr_scale_kernel, dim3(ceil_div(D.n_ovr, 256)), dim3(256), 0, st, x, D.ovr_col, D.ovr_row, D.ovr_ratio, (long)D.n_ovr,
+      hipLaunchKernelGGL(ppr_ovr_scale_kernel, dim3(ceil_div(D.n_ovr, 256)), dim3(256), 0, st, cur, D.ovr_col, D.ovr_row, D.ovr_ratio, (long)D.n_ovr,
                          D.kpad, p->stash_o);
       GSS_LAUNCH_CHECK("ppr_ovr_scale_kernel");
     }
-    hipLaunchKernelGGL(ppr_column_kernel, dim3(ceil_div(D.k, 64)), dim3(64), 0, st, x, p->part, D.n_z > 0 ? p->n_zchunks : 0, p->stash_o,
+    hipLaunchKernelGGL(ppr_column_kernel, dim3(ceil_div(D.k, 64)), dim3(64), 0, st, cur, p->part, D.n_z > 0 ? p->n_zchunks : 0, p->stash_o,
                        D.zero_ptr, D.zero_ovr, D.start, D.start_dangling, D.keep_ptr, D.keep_row, D.keep_val, D.k, D.kpad, p->dsum, p->yself);
     GSS_LAUNCH_CHECK("ppr_column_kernel");
-    if (int rc = ppr_spmm_launch(p, x, p->y, st, p->done)) return rc;   // converged 32-column groups are skipped
+    if (p->fused) {
+      const PprFuse f{p->ysel, p->rowflag, D.start, p->iters, p->dsum, p->yself, p->part_e, alpha, D.k, it};
+      if (int rc = ppr_spmm_launch(p, cur, nxt, st, p->done, &f)) return rc;   // writes the next iterate and the column errors
+    } else {
+      if (int rc = ppr_spmm_launch(p, cur, p->y, st, p->done)) return rc;   // converged 32-column groups are skipped
+    }
     if (D.n_ovr > 0) {
-      hipLaunchKernelGGL(ppr_ovr_restore_kernel, dim3(ceil_div(D.n_ovr, 256)), dim3(256), 0, st, x, D.ovr_col, D.ovr_row, (long)D.n_ovr, D.kpad,
+      hipLaunchKernelGGL(ppr_ovr_restore_kernel, dim3(ceil_div(D.n_ovr, 256)), dim3(256), 0, st, cur, D.ovr_col, D.ovr_row, (long)D.n_ovr, D.kpad,
                          p->stash_o);
       GSS_LAUNCH_CHECK("ppr_ovr_restore_kernel");
     }
-    if (D.n_sel > 0) {
-      hipLaunchKernelGGL(ppr_sel_kernel, dim3(ceil_div(D.n_sel, 256)), dim3(256), 0, st, p->y, x, D.sel_col, D.sel_row, D.sel_val, (long)D.n_sel,
-                         D.start, D.kpad);
-      GSS_LAUNCH_CHECK("ppr_sel_kernel");
-    }
     GSS_HIP(hipMemsetAsync(p->n_active, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(ppr_update_kernel, dim3(col_tiles.x, p->n_rowblocks), dim3(256), 0, st, x, p->y, D.start, p->dsum, p->yself, p->done, D.n, D.k,
-                       D.kpad, alpha, p->part);
-    GSS_LAUNCH_CHECK("ppr_update_kernel");
-    hipLaunchKernelGGL(ppr_finish_kernel, dim3(ceil_div(D.k, 64)), dim3(64), 0, st, p->part, p->n_rowblocks, D.k, D.kpad, thr, it, p->done, p->iters,
-                       p->n_active);
-    GSS_LAUNCH_CHECK("ppr_finish_kernel");
+    if (p->fused) {
+      if (D.n_ovr > 0) {
+        hipLaunchKernelGGL(ppr_ovr_fix_kernel, dim3(ceil_div(D.k, 4)), dim3(256), 0, st, nxt, D.ovr_ptr, D.ovr_row, D.ovr_ratio, p->stash_o, p->done, D.k,
+                           D.kpad, p->err_corr);
+        GSS_LAUNCH_CHECK("ppr_ovr_fix_kernel");
+      }
+      hipLaunchKernelGGL(ppr_finish_fused_kernel, dim3(ceil_div(D.k, 64)), dim3(64), 0, st, p->part_e, p->n_segblocks, p->err_corr, D.k, D.kpad, thr, it,
+                         p->done, p->iters, p->n_active);
+      GSS_LAUNCH_CHECK("ppr_finish_fused_kernel");
+      std::swap(cur, nxt);
+    } else {
+      if (D.n_sel > 0) {
+        hipLaunchKernelGGL(ppr_sel_kernel, dim3(ceil_div(D.n_sel, 256)), dim3(256), 0, st, p->y, cur, D.sel_col, D.sel_row, D.sel_val, (long)D.n_sel,
+                           D.start, D.kpad);
+        GSS_LAUNCH_CHECK("ppr_sel_kernel");
+      }
+      hipLaunchKernelGGL(ppr_update_kernel, dim3(col_tiles.x, p->n_rowblocks), dim3(256), 0, st, cur, p->y, D.start, p->dsum, p->yself, p->done, D.n, D.k,
+                         D.kpad, alpha, p->part);
+      GSS_LAUNCH_CHECK("ppr_update_kernel");
+      hipLaunchKernelGGL(ppr_finish_kernel, dim3(ceil_div(D.k, 64)), dim3(64), 0, st, p->part, p->n_rowblocks, D.k, D.kpad, thr, it, p->done, p->iters,
+                         p->n_active);
+      GSS_LAUNCH_CHECK("ppr_finish_kernel");
+    }
     GSS_HIP(hipMemcpyAsync(&active, p->n_active, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GSS_HIP(hipStreamSynchronize(st));
   }
+  if (cur != x) GSS_HIP(hipMemcpyAsync(x, cur, (size_t)D.n * D.kpad * sizeof(double), hipMemcpyDeviceToDevice, st));   // the last iterate, in the caller's buffer
   GSS_HIP(hipMemcpyAsync(iters_out, p->iters, (size_t)D.k * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   GSS_HIP(hipStreamSynchronize(st));
   if (active > 0) return fail(GSS_ENOTCONV, "ppr_run: %d of %d columns did not converge in %d iterations", active, D.k, max_iter);

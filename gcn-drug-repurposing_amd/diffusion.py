@@ -98,6 +98,9 @@ class PprProblem:
         self.ovr_col = np.asarray(ovr_col, np.int32); self.ovr_row = np.asarray(ovr_row, np.int32)
         self.ovr_ratio = np.asarray(ovr_ratio, np.float64)
         self.zero_ptr = np.asarray(zero_ptr, np.int32); self.zero_ovr = np.asarray(zero_ovr, np.int32)
+        # the overrides were appended column by column: entries [ovr_ptr[c], ovr_ptr[c + 1]) belong to column c (gss_ppr_desc.ovr_ptr)
+        assert np.all(np.diff(self.ovr_col) >= 0)
+        self.ovr_ptr = np.searchsorted(self.ovr_col, np.arange(self.k + 1)).astype(np.int32)
         self.sel_col = np.asarray(sel_col, np.int32); self.sel_row = np.asarray(sel_row, np.int32)
         self.sel_val = np.asarray(sel_val, np.float64)
         self.keep_ptr = np.asarray(keep_ptr, np.int32); self.keep_row = np.asarray(keep_row, np.int32)
@@ -121,7 +124,7 @@ class PprEngine:
                          start=t(prob.starts), start_dangling=t(prob.start_dangling), z_rows=t(prob.z_rows),
                          ovr_col=t(prob.ovr_col), ovr_row=t(prob.ovr_row), ovr_ratio=t(prob.ovr_ratio), zero_ptr=t(prob.zero_ptr),
                          zero_ovr=t(prob.zero_ovr), sel_col=t(prob.sel_col), sel_row=t(prob.sel_row), sel_val=t(prob.sel_val),
-                         keep_ptr=t(prob.keep_ptr), keep_row=t(prob.keep_row), keep_val=t(prob.keep_val))
+                         keep_ptr=t(prob.keep_ptr), keep_row=t(prob.keep_row), keep_val=t(prob.keep_val), ovr_ptr=t(prob.ovr_ptr))
         d = _lib.PprDesc()
         d.n, d.k, d.kpad, d.nnz = prob.n, prob.k, prob.kpad, int(mt.nnz)
         d.h_rowptr = self.h_rowptr.ctypes.data

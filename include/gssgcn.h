@@ -235,6 +235,9 @@ typedef struct gss_ppr_desc {
   const double *sel_val;
   const int32_t *keep_ptr, *keep_row;      /* [k+1], rows */
   const double *keep_val;
+  const int32_t *ovr_ptr;                  /* optional, [k+1]: the overrides of column c are entries [ovr_ptr[c], ovr_ptr[c+1]) (ovr_col
+                                              non-decreasing).  With it (or with n_ovr == 0) the update x <- alpha (...) + (1 - alpha) e_s and
+                                              the column errors run in the SpMM's epilogue instead of in a pass of their own */
 } gss_ppr_desc;
 int gss_ppr_create(gss_ppr **out, const gss_ppr_desc *desc);
 void gss_ppr_destroy(gss_ppr *p);

@@ -208,3 +208,35 @@ def test_gpu_ppr_workspace_guards_over_a_size_sweep():
         for c in (0, n_start - 1):
             ref, ref_it = O.diffusion_profile(m0, int(starts[c]), prot, *hp)
             assert np.abs(got[c] - ref).max() < 1e-13 and it[c] == ref_it, (n, n_start, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["msi_small", "edge"])
+def test_gpu_fused_update_equals_the_separate_update_pass(gold, case):
+    """round 3: the update x <- alpha (y + dangling e_s) + (1 - alpha) e_s and the column L1 errors run in the SpMM's epilogue (double-buffered
+    x, the start nodes' "selected" rows as a sparse addend, the in-place override scaling repaired afterwards).  Against the separate
+    update pass (knob ppr_fused = 0): the same iteration counts, profiles equal to rounding (the selected row is added before instead
+    of after the store of y; the column errors are summed in another order), guards intact."""
+    import gcn_drug_repurposing_amd as pkg
+    from gcn_drug_repurposing_amd.diffusion import PprEngine, PprProblem
+    lib = pkg.load()
+    if case == "msi_small":
+        m0, starts, prot, hp = gold["m0"], gold["start_idx"], gold["prot"], gold["hp"]
+    else:
+        (m0, prot), starts, hp = edge_case_graph(), np.array([0, 1, 2, 3]), (0.85, 500, 1e-9)
+    res = {}
+    for fused in (1, 0):
+        assert lib.gss_debug_set_option(b"ppr_fused", fused) == 0
+        try:
+            eng = PprEngine(PprProblem(m0, np.asarray(starts), prot))
+            x, it = eng.run(hp[0], hp[2], hp[1])
+            eng.check_guards()
+            res[fused] = (x[:, :len(starts)].t().contiguous().cpu().numpy(), it.copy())
+            x2, it2 = eng.run(hp[0], hp[2], hp[1])          # a second run on the same handle starts from scratch
+            assert (x2[:, :len(starts)].t().cpu().numpy() == res[fused][0]).all() and (it2 == it).all()
+        finally:
+            lib.gss_debug_set_option(b"ppr_fused", 1)
+    assert (res[1][1] == res[0][1]).all()
+    assert np.abs(res[1][0] - res[0][0]).max() < 1e-15
+    ref, ref_it = oracle_profiles(m0, starts, prot, hp)
+    assert np.abs(res[1][0] - ref).max() < 1e-13 and (res[1][1] == ref_it).all()
