@@ -152,6 +152,7 @@ def bench_diffusion(args, rank, world, local_rank):
     out = {"metric": "diffusion_profiles_per_s", "value": len(di) * args.steps / elapsed, "unit": "profiles/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           **({"knobs": list(args.set)} if args.set else {}),
            "config": {"workload": f"diffusion profiles of the whole_graph stand-in: N={n}, nnz(M')={nnz}, {len(di)} start nodes "
                                   f"(all drugs and indications), alpha={alpha}, tol={tol}; {int(it.max())} power iterations",
                       "parallelism": "single" if world == 1 else f"start nodes split over {world} ranks, no collective"}}
@@ -234,12 +235,6 @@ def main():
         import datetime
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=2 * COLLECTIVE_TIMEOUT_S))
 
-    if args.workload == "diffusion":
-        bench_diffusion(args, rank, world, local_rank)
-        if dist.is_initialized():
-            dist.destroy_process_group()
-        return
-
     import gcn_drug_repurposing_amd as pkg
     from gcn_drug_repurposing_amd.graph import GssGraph
     lib_ = pkg.load()
@@ -247,6 +242,12 @@ def main():
         name, _, val = kv.partition("=")
         if lib_.gss_debug_set_option(name.encode(), int(val)) != 0:
             raise SystemExit(f"--set {kv}: {lib_.gss_last_error().decode()}")
+
+    if args.workload == "diffusion":
+        bench_diffusion(args, rank, world, local_rank)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
 
     adj, x_host, d, L, B = build_workload(args.workload, args.hidden_units)
     from_source = x_host is None           # a row source instead of a matrix in memory (RMAT)
