@@ -7,9 +7,17 @@ Knobs g_knobs;
 thread_local const Knobs *t_knobs = nullptr;
 }  // namespace gss
 
+namespace gss {
+extern unsigned long long *g_gemm_stamps;   // dense.hip
+}
 using namespace gss;
 
 extern "C" {
+// diagnostic: a device buffer of 6 x 8 bytes per wave of the next projection launches (NULL switches it off); tools/gemm_stamps.py
+int gss_debug_set_stamp_buffer(void *device_buffer) {
+  g_gemm_stamps = static_cast<unsigned long long *>(device_buffer);
+  return GSS_OK;
+}
 int gss_abi_version(void) { return GSS_ABI_VERSION; }
 const char *gss_last_error(void) { return gss::g_err; }
 
@@ -90,6 +98,11 @@ int gss_debug_set_option(const char *name, int value) {
   if (strcmp(name, "gemm_lds_kb") == 0 || strcmp(name, "wgrad_lds_kb") == 0 || strcmp(name, "loss_lds_kb") == 0) {
     GSS_REQUIRE(value >= 0 && value <= 160, "%s must be in [0, 160] (KB of dynamic LDS per workgroup, 0 = what the kernel needs)", name);
     (name[0] == 'g' ? g_knobs.gemm_lds_kb : name[0] == 'w' ? g_knobs.wgrad_lds_kb : g_knobs.loss_lds_kb) = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "gemm_stagger") == 0) {
+    GSS_REQUIRE(value >= 0 && value <= 256, "gemm_stagger must be in [0, 256] (units of 512 cycles)");
+    g_knobs.gemm_stagger = value;
     return GSS_OK;
   }
   if (strcmp(name, "ppr_fused") == 0) {

@@ -27,6 +27,7 @@ struct Knobs {
   int gemm_nt_cap = 0;       // cap of the feature tile width (16-feature units), 0 = none
   int gemm_small_nt = 2;     // narrowest feature tile for small problems, 0 = never narrow
   int gemm_prio = 0;         // static wave priority experiment of the projection (0 = off; see dense.hip)
+  int gemm_stagger = 0;      // second-generation projection workgroups start this many x 512 cycles late (0 = off)
   int wgrad_prio = 0;        // the same for the weight gradient
   int wgrad_wgs = 256;       // workgroups of a full-size weight-gradient launch (sizes the plan's partial buffer)
   int xcd_remap = 1;         // workgroups that share input rows on one XCD

@@ -46,6 +46,9 @@ struct GemmArgs {
   float *inv_den;       // EPI_FWD_NORM: 1 / max(||x_row||, eps) per node (x_next then receives the unit-norm rows)
   int xcd_remap;        // renumber the workgroups so that those sharing input rows sit on one XCD (xcd_ids below)
   int prio_cut;         // > 0: workgroups whose linear id is below it raise their wave priority (debug knob "gemm_prio")
+  int stagger;          // > 0: workgroups of the second generation (linear id >= 256) start this many x 512 cycles late (knob "gemm_stagger")
+  unsigned long long *stamps;  // diagnostic (gss_debug_set_stamp_buffer, NULL in production): per wave {start, loop begin, loop end, end} in
+                               // 100 MHz wall-clock ticks + {linear workgroup id, HW_ID}; tools/gemm_stamps.py reads it
 };
 
 template <int FT, int EPI>
@@ -269,12 +272,22 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
   const int r = lane & 15, q = lane >> 4;
   // grid = (node tiles, column tiles): the column tiles of a node tile read the same input rows
   const int linear = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+  unsigned long long *stamp = g.stamps ? g.stamps + ((size_t)linear * WAVES + (threadIdx.x >> 6)) * 6 : nullptr;
+  if (stamp && (threadIdx.x & 63) == 0) {
+    stamp[0] = wall_clock64();
+    stamp[4] = (unsigned long long)linear;
+    stamp[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | ((16 - 1) << 11));
+  }
   const XcdIds id = xcd_ids(linear, (int)gridDim.x, (int)gridDim.y, g.xcd_remap != 0);
   // The first generation of workgroups (one per CU) and the ones that double up on the CUs start together and otherwise run in
   // lockstep: shared MFMA pipe at half rate each, then both store at once.  With the first generation at a higher wave priority it
   // takes the pipe, finishes early and stores while the second generation computes (MI355X guide, 'static priority').  Speed only.
   if (g.prio_cut > 0 && linear < g.prio_cut) __builtin_amdgcn_s_setprio(3);
   // prio_cut < 0: by wave slot instead -- the waves a SIMD received first (even HW_ID.wave_id) win the pipe, whatever the dispatch order was
+  // de-phasing experiment: the second generation of workgroups (those that double up on the CUs) waits a fraction of a K chunk, so that
+  // its per-chunk barrier / fragment-read bubbles fall under the first generation's MFMAs instead of coinciding with its bubbles
+  if (g.stagger > 0 && linear >= 256)
+    for (int k = 0; k < g.stagger; ++k) __builtin_amdgcn_s_sleep(8);
   if (g.prio_cut < 0 && (__builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11)) & 1u) == 0u) __builtin_amdgcn_s_setprio(3);
   const int node_base = id.spread * BM;
   const int j0 = id.share * BN;
@@ -322,6 +335,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
     for (int u = 0; u < NT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int c = 0; c < PF && c < nchunk; ++c) stage(c);
+  if (stamp && lane == 0) stamp[1] = wall_clock64();
   for (int ci = 0; ci < nchunk; ++ci) {
     // chunk ci has landed once at most min(PF-1, nchunk-1-ci) younger chunks of this wave are outstanding
     const int younger = min(PF - 1, nchunk - 1 - ci);
@@ -354,6 +368,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);  // keep the MFMA cluster inside its iteration
   }
 
+  if (stamp && lane == 0) stamp[2] = wall_clock64();
   // epilogue: lane (r, q) holds OUT[node_base + 16 (MT w + t) + r][j0 + 16 u + 4 q + 0..3]
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -373,6 +388,10 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
     } else {
       fwd_epilogue<NT, EPI>(g, acc[t], nd, j0, q);
     }
+  }
+  if (stamp) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores of this wave have left
+    if (lane == 0) stamp[3] = wall_clock64();
   }
 }
 
@@ -395,12 +414,16 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
 // debug knob "wgrad_prio": 1 = waves 4-7 of a weight-gradient workgroup at priority 1, 2 = waves 0-3   [knob wgrad_prio, common.h Knobs]
 // debug knob "gemm_small_nt": narrowest feature tile (in 16-feature units) for small problems, 0 = never narrow   [knob gemm_small_nt, common.h Knobs]
 
+unsigned long long *g_gemm_stamps = nullptr;   // gss_debug_set_stamp_buffer: diagnostic only, process-wide, not a knob
+
 template <int EPI>
 static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
   if (g_in.n <= 0) return GSS_OK;
   GemmArgs g = g_in;
   g.xcd_remap = K().xcd_remap;
   g.prio_cut = K().gemm_prio;
+  g.stagger = K().gemm_stagger;
+  g.stamps = g_gemm_stamps;
   if (K().gemm_variant >= 2) {
     int nt = (d % 128 == 0) ? 8 : (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
     if (K().gemm_nt_cap > 0 && EPI != EPI_FWD_NORM)   // debug knob "gemm_nt_cap": narrower feature tiles (the fused normalise needs whole rows)

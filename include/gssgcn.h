@@ -39,6 +39,10 @@ typedef struct gss_plan gss_plan; /* activations + workspace of one training rep
 typedef struct gss_comm gss_comm; /* the communicator of a node-range sharded job (RCCL over xGMI, or in-process ranks) */
 
 int gss_abi_version(void);
+/* Diagnostic builds of a measurement only (tools/gemm_stamps.py): while a device buffer is set, every wave of a projection launch
+ * (gss_dense_fwd) stores its wall-clock stamps {start, loop begin, loop end, end} + {workgroup id, HW_ID} there (6 x 8 bytes per wave).
+ * NULL (the default) switches it off; no production path sets it. */
+int gss_debug_set_stamp_buffer(void *device_buffer);
 const char *gss_last_error(void);
 
 /* ---- K11  preprocess_graph, helpers/helper.py:82-89 (+ fp32 cast helper.py:95) ----------
