@@ -100,6 +100,11 @@ int gss_debug_set_option(const char *name, int value) {
     (name[0] == 'g' ? g_knobs.gemm_lds_kb : name[0] == 'w' ? g_knobs.wgrad_lds_kb : g_knobs.loss_lds_kb) = value;
     return GSS_OK;
   }
+  if (strcmp(name, "wgrad_variant") == 0) {
+    GSS_REQUIRE(value == 1 || value == 2, "wgrad_variant must be 1 (direct loads) or 2 (LDS-DMA ring)");
+    g_knobs.wgrad_variant = value;
+    return GSS_OK;
+  }
   if (strcmp(name, "gemm_stagger") == 0) {
     GSS_REQUIRE(value >= 0 && value <= 256, "gemm_stagger must be in [0, 256] (units of 512 cycles)");
     g_knobs.gemm_stagger = value;

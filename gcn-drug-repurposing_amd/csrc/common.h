@@ -29,6 +29,7 @@ struct Knobs {
   int gemm_prio = 0;         // static wave priority experiment of the projection (0 = off; see dense.hip)
   int gemm_stagger = 0;      // second-generation projection workgroups start this many x 512 cycles late (0 = off)
   int wgrad_prio = 0;        // the same for the weight gradient
+  int wgrad_variant = 1;     // 1 = operands by direct loads from L2, 2 = by LDS-DMA into a per-wave ring, one trip ahead (same bits)
   int wgrad_wgs = 256;       // workgroups of a full-size weight-gradient launch (sizes the plan's partial buffer)
   int xcd_remap = 1;         // workgroups that share input rows on one XCD
   int loss_wgs = 256;        // workgroups the loss sweep's grid aims at

@@ -584,6 +584,7 @@ int dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t, con
 // set costs more in registers than the exposed latency it covers (the SIMD's partner wave already covers it).
 
 constexpr int kWgWaves = 8;
+constexpr size_t kWgradRingLds = (size_t)kWgWaves * 2 * 2 * 4 * 1024;   // RING: 8 waves x 2 trips x (4 + 4) fragment blocks of 1 KB = 128 KB
 
 struct WgradArgs {
   int n, d;
@@ -598,6 +599,12 @@ struct WgradArgs {
 
 // Two problems may share one launch (grid.y = ns0 + slices of the second): the top layer's batch-row gradient is 64
 // latency-bound workgroups on its own (10 us) and rides along with a full-N launch for free.
+// RING (round 3, knob wgrad_variant = 2): the operand rows of a trip arrive by LDS-DMA in a per-wave private ring (2 trips x 8
+// fragment blocks of 1 KB: 16 KB per wave, 128 KB per workgroup), requested one trip ahead of the MFMAs that consume them and read back
+// with one conflict-free ds_read_b128 per lane -- the operand fetch from L2 then sits under the previous trip's 64 MFMAs instead of in
+// front of its own (the direct-load form parks a wave at s_waitcnt for a quarter of its life: SQ_WAIT_ANY 26 %).  No
+// barrier in the loop: a wave stages and reads only its own rows.  The MFMA order is untouched, so the results keep their bits.
+template <bool RING>
 __global__ __launch_bounds__(64 * kWgWaves) void wgrad_tn_kernel(WgradArgs g0, WgradArgs g1, int ns0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // grid = (output tiles, node slices): the output tiles of a slice read the same dP / Z rows
@@ -633,6 +640,58 @@ __global__ __launch_bounds__(64 * kWgWaves) void wgrad_tn_kernel(WgradArgs g0, W
   // four row-steps per trip: all 8 operand loads are issued first (branch-free: rows beyond the slice read a
   // valid row and are multiplied by 0), then the 64 MFMAs run while the next trip's loads are in flight
   constexpr int U = 4;
+  if (RING && !g.rows) {   // (the batch-row problem gathers Z rows through an index: it keeps the direct loads below)
+    constexpr int D = 2;                                   // trips in flight
+    const int wu = __builtin_amdgcn_readfirstlane(w);   // wave-uniform: the LDS destination of a DMA travels in M0 (an SGPR)
+    const unsigned ring = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem + (unsigned)wu * (D * 2 * U * 1024);
+    const float *ringf = reinterpret_cast<const float *>(smem) + (size_t)wu * (D * 2 * U * 256);
+    const int first = __builtin_amdgcn_readfirstlane(r0) + 4 * wu;
+    const int step = 4 * kWgWaves * U;
+    const int r1u = __builtin_amdgcn_readfirstlane(r1);
+    const int ntrips = first < r1u ? (r1u - first + step - 1) / step : 0;
+    auto issue = [&](int t) {
+      const int base = first + t * step;
+      const unsigned slot = __builtin_amdgcn_readfirstlane(ring + (unsigned)((t % D) * 2 * U * 1024));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = base + u * 4 * kWgWaves + q;
+        const int rc = row < r1 ? row : r1 - 1;
+        glds16(g.dp + (size_t)rc * g.d + ac, slot + (unsigned)(u * 1024));
+        glds16(z + (size_t)rc * g.d + zc, slot + (unsigned)((U + u) * 1024));
+      }
+    };
+    for (int t = 0; t < D && t < ntrips; ++t) issue(t);
+    for (int t = 0; t < ntrips; ++t) {
+      if (t + 1 < ntrips)
+        wait_vmcnt<2 * U>();      // trip t has landed once at most the 2 U requests of trip t + 1 are outstanding
+      else
+        wait_vmcnt<0>();
+      const float *slot = ringf + (size_t)(t % D) * (2 * U * 256);
+      float4 a4[U], b4[U];
+      float msk[U];
+      const int base = first + t * step;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        a4[u] = *reinterpret_cast<const float4 *>(slot + u * 256 + lane * 4);
+        b4[u] = *reinterpret_cast<const float4 *>(slot + (U + u) * 256 + lane * 4);
+        msk[u] = (base + u * 4 * kWgWaves + q) < r1 ? 1.f : 0.f;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments are in registers: the slot may be refilled
+      if (t + D < ntrips) issue(t + D);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float4 am = scale4(msk[u], a4[u]);
+        cs = add4(cs, am);
+        const float av[4] = {am.x, am.y, am.z, am.w};
+        const float bv[4] = {b4[u].x, b4[u].y, b4[u].z, b4[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) acc[e][e2] = mfma16(av[e], bv[e2], acc[e][e2]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else
   for (int base = r0 + 4 * w; base < r1; base += 4 * kWgWaves * U) {
     float4 a4[U], b4[U];
     float msk[U];
@@ -660,6 +719,7 @@ __global__ __launch_bounds__(64 * kWgWaves) void wgrad_tn_kernel(WgradArgs g0, W
     }
   }
 
+  if (RING) __syncthreads();   // the reduction slots below alias the rings: every wave is done reading its own first
   // tree reduction over the 8 waves (fixed order): 4..7 -> 0..3, 2..3 -> 0..1, 1 -> 0
   for (int half = kWgWaves / 2; half >= 1; half >>= 1) {
     if (w >= half && w < 2 * half) {
@@ -858,8 +918,12 @@ int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const 
   }
   if (d % 64 == 0) {
     const int tiles = (d / 64) * (2 * d / 64);
-    hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns), dim3(64 * kWgWaves), lds_request(wgrad_tn_kernel, 4 * 16 * 64 * sizeof(float4), K().wgrad_lds_kb),
-                       st, g, g, ns);
+    if (K().wgrad_variant == 2)
+      hipLaunchKernelGGL(wgrad_tn_kernel<true>, dim3(tiles, ns), dim3(64 * kWgWaves), lds_request(wgrad_tn_kernel<true>, kWgradRingLds, K().wgrad_lds_kb),
+                         st, g, g, ns);
+    else
+      hipLaunchKernelGGL(wgrad_tn_kernel<false>, dim3(tiles, ns), dim3(64 * kWgWaves),
+                         lds_request(wgrad_tn_kernel<false>, 4 * 16 * 64 * sizeof(float4), K().wgrad_lds_kb), st, g, g, ns);
     GSS_LAUNCH_CHECK("wgrad_tn_kernel");
   } else {
     hipLaunchKernelGGL(wgrad_simple_kernel, dim3(ceil_div((int64_t)d * 2 * d + d, 256), ns), dim3(256), 0, st, g);
@@ -889,8 +953,12 @@ int wgrad_partial_pair(int32_t d, int32_t n0, const float *dp0, const float *ax0
   WgradArgs g0{n0, d, dp0, ax0, am0, rows0, base_w + (size_t)slice0_0 * d * 2 * d, base_b + (size_t)slice0_0 * d, rps0, K().xcd_remap, K().wgrad_prio};
   WgradArgs g1{n1, d, dp1, ax1, am1, rows1, base_w + (size_t)slice0_1 * d * 2 * d, base_b + (size_t)slice0_1 * d, rps1, K().xcd_remap, K().wgrad_prio};
   const int tiles = (d / 64) * (2 * d / 64);
-  hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns0 + ns1), dim3(64 * kWgWaves),
-                     lds_request(wgrad_tn_kernel, 4 * 16 * 64 * sizeof(float4), K().wgrad_lds_kb), as_stream(stream), g0, g1, ns0);
+  if (K().wgrad_variant == 2)
+    hipLaunchKernelGGL(wgrad_tn_kernel<true>, dim3(tiles, ns0 + ns1), dim3(64 * kWgWaves),
+                       lds_request(wgrad_tn_kernel<true>, kWgradRingLds, K().wgrad_lds_kb), as_stream(stream), g0, g1, ns0);
+  else
+    hipLaunchKernelGGL(wgrad_tn_kernel<false>, dim3(tiles, ns0 + ns1), dim3(64 * kWgWaves),
+                       lds_request(wgrad_tn_kernel<false>, 4 * 16 * 64 * sizeof(float4), K().wgrad_lds_kb), as_stream(stream), g0, g1, ns0);
   GSS_LAUNCH_CHECK("wgrad_tn_kernel");
   return GSS_OK;
 }

@@ -307,6 +307,29 @@ def test_dense_bwd_weight(G, n, d):
     assert rel_err(gw2.cpu().numpy(), dp[:b].T.astype(np.float64) @ am[rows]) < 3e-6
 
 
+@pytest.mark.parametrize("n,d", [(29960, 128), (1000, 64), (777, 256), (33, 64)])
+def test_dense_bwd_weight_lds_ring_variant_keeps_the_bits(G, n, d):
+    """wgrad_variant 2 (operands by LDS-DMA into a per-wave ring, one trip ahead; measured 2-3 % slower than the direct loads and
+    therefore not the default, profiles/r03_wgrad_variant_ab.txt): the MFMA order is untouched, so dW1 / dW2 / db equal the default's
+    bit for bit -- slices whose rows end inside a trip, a slice count that leaves some waves without rows"""
+    rng = np.random.RandomState(n * 3 + d)
+    dp, ax, am = (cu(rng.randn(n, d).astype(np.float32)) for _ in range(3))
+    ws = torch.empty(G.lib.gss_wgrad_workspace_bytes(n, d), dtype=torch.uint8, device="cuda")
+    out = {}
+    try:
+        for v in (1, 2):
+            G._lib.check(G.lib.gss_debug_set_option(b"wgrad_variant", v))
+            gw1, gw2, gb = (torch.full(sh, float("nan"), device="cuda") for sh in ((d, d), (d, d), (d,)))
+            G._lib.check(G.lib.gss_dense_bwd_weight(n, d, dp.data_ptr(), ax.data_ptr(), am.data_ptr(), None, gw1.data_ptr(), gw2.data_ptr(),
+                                                    gb.data_ptr(), 0, ws.data_ptr(), G.st()))
+            torch.cuda.synchronize()
+            out[v] = (gw1, gw2, gb)
+    finally:
+        G._lib.check(G.lib.gss_debug_set_option(b"wgrad_variant", 1))
+    for a, b in zip(out[1], out[2]):
+        assert torch.equal(a, b)
+
+
 # ---------------------------------------------------------------- K5
 @pytest.mark.parametrize("n,d", [(1000, 128), (33, 16), (257, 64), (100, 512), (64, 1024)])
 def test_rownorm_fwd_and_bwd(G, n, d):
