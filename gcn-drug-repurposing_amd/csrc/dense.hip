@@ -255,7 +255,9 @@ __device__ __forceinline__ XcdIds xcd_ids(int L, int n_spread, int n_share, bool
 
 // WAVES = 1 (forward over a short row list, gss_plan_step_lazy's 2048 batch rows): one wave and 16 MT nodes per workgroup, so that the
 // few rows spread over 4 x as many CUs; a row's MFMA chain is the same, its result has the same bits
-template <int NT, int MT, int EPI, int WAVES = 4>
+// STAMP: the diagnostic instantiation of tools/gemm_stamps.py (per-wave wall-clock stamps); production launches use STAMP = false,
+// whose code carries none of it
+template <int NT, int MT, int EPI, int WAVES = 4, bool STAMP = false>
 __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BN = 16 * NT;
@@ -272,8 +274,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
   const int r = lane & 15, q = lane >> 4;
   // grid = (node tiles, column tiles): the column tiles of a node tile read the same input rows
   const int linear = (int)(blockIdx.x + gridDim.x * blockIdx.y);
-  unsigned long long *stamp = g.stamps ? g.stamps + ((size_t)linear * WAVES + (threadIdx.x >> 6)) * 6 : nullptr;
-  if (stamp && (threadIdx.x & 63) == 0) {
+  unsigned long long *stamp = (STAMP && g.stamps) ? g.stamps + ((size_t)linear * WAVES + (threadIdx.x >> 6)) * 6 : nullptr;
+  if (STAMP && stamp && (threadIdx.x & 63) == 0) {
     stamp[0] = wall_clock64();
     stamp[4] = (unsigned long long)linear;
     stamp[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | ((16 - 1) << 11));
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
     for (int u = 0; u < NT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int c = 0; c < PF && c < nchunk; ++c) stage(c);
-  if (stamp && lane == 0) stamp[1] = wall_clock64();
+  if (STAMP && stamp && lane == 0) stamp[1] = wall_clock64();
   for (int ci = 0; ci < nchunk; ++ci) {
     // chunk ci has landed once at most min(PF-1, nchunk-1-ci) younger chunks of this wave are outstanding
     const int younger = min(PF - 1, nchunk - 1 - ci);
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);  // keep the MFMA cluster inside its iteration
   }
 
-  if (stamp && lane == 0) stamp[2] = wall_clock64();
+  if (STAMP && stamp && lane == 0) stamp[2] = wall_clock64();
   // epilogue: lane (r, q) holds OUT[node_base + 16 (MT w + t) + r][j0 + 16 u + 4 q + 0..3]
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
       fwd_epilogue<NT, EPI>(g, acc[t], nd, j0, q);
     }
   }
-  if (stamp) {
+  if (STAMP && stamp) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores of this wave have left
     if (lane == 0) stamp[3] = wall_clock64();
   }
@@ -451,6 +453,11 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
     }
     dim3 grid(ceil_div(g.n, 64 * mt), g.J / (16 * nt));
     const size_t lds = 4 * (size_t)(64 * mt * 16 + 16 * nt * 16) * sizeof(float);
+    if (g.stamps && EPI == EPI_FWD && nt == 8 && mt == 1) {   // diagnostic twin (tools/gemm_stamps.py): the d = 128 projection only
+      hipLaunchKernelGGL((gemm_nt_lds_kernel<8, 1, EPI_FWD, 4, true>), grid, dim3(256), lds, st, g);
+      GSS_LAUNCH_CHECK("gemm_nt_lds_kernel (stamped)");
+      return GSS_OK;
+    }
 #define GSS_GEMM_CASE(NTV)                                                                              \
   case NTV:                                                                                             \
     if (mt == 2)                                                                                        \
