@@ -175,6 +175,47 @@ def test_config4_sharded_plan_equals_single_gpu_plan(config3, world):
     assert abs(out[0]["loss2"] - single.loss.item()) < 1e-6 * abs(single.loss.item())
 
 
+def test_config4_overlapped_hops_at_full_size(config3):
+    """config 4's workload (whole_graph + pathway edges, d = 256, L = 3) at world 4 with every hop overlapped with its boundary exchange
+    (split CSRs, second stream; all five kinds of hop occur at three layers).  A row is then summed as own-column entries + boundary-column
+    entries: embeddings, loss and gradients agree with the single-GPU plan to rounding instead of bit for bit; replicas stay identical."""
+    import tolerances as T
+    from gcn_drug_repurposing_amd.dist import local_comms, sharded_plan_engine
+    c = config3
+    _, _, g_cpu, g64, _, a_hat = c["ref"]
+    single, _ = _single_gpu(c)
+    emb1, loss1 = single.emb.cpu().numpy(), single.loss.item()
+    world = 4
+    comms = local_comms(world)
+    idx32 = c["idx"].astype(np.int32)
+
+    def rank_fn(rank):
+        eng = sharded_plan_engine(c["adj"], c["X"], c["p"], comms[rank], num_layers=c["L"], layer_decay=DECAY, alpha=ALPHA, lr=LR,
+                                  max_batch=c["B"], device=torch.device("cuda:0"), split=True)
+        assert eng.layout.overlapped
+        t = torch.from_numpy(idx32).cuda()
+        eng.forward()
+        eng.loss_backward(t, BETA)
+        res = dict(emb=eng.gather_embeddings().cpu().numpy(), loss=eng.loss.item(), grads=[g.cpu().numpy() for g in eng.grads])
+        eng.adam()
+        eng.step_lazy(t, BETA)
+        eng.check_guards()
+        res["loss2"] = eng.loss.item()
+        res["w1"] = eng.params[0].cpu().numpy()
+        return res
+
+    out = _threaded(world, rank_fn, comms)
+    for o in out[1:]:
+        np.testing.assert_array_equal(o["emb"], out[0]["emb"])
+        assert o["loss"] == out[0]["loss"] and o["loss2"] == out[0]["loss2"] and np.array_equal(o["w1"], out[0]["w1"])
+    assert np.abs(out[0]["emb"] - emb1).max() < T.TRAJ_EMB_REL * np.abs(emb1).max()
+    assert abs(out[0]["loss"] - loss1) < T.TRAJ_LOSS_RTOL * abs(loss1)
+    _check_grads(dict(zip(("W1", "b1", "W2", "b2"), out[0]["grads"])), emb1, g64, "config4 world 4, overlapped hops")
+    single.adam()
+    single.step(torch.from_numpy(idx32).cuda(), BETA)
+    assert abs(out[0]["loss2"] - single.loss.item()) < T.TRAJ_LOSS_RTOL * abs(single.loss.item())
+
+
 @pytest.fixture(scope="module")
 def rmat_mid():
     from gcn_drug_repurposing_amd import synth
