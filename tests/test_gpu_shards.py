@@ -303,6 +303,54 @@ def test_overlapped_hops_agree_with_the_plain_sharded_plan(world, case, relabel)
     np.testing.assert_allclose(b["losses"], g["losses"], rtol=T.TRAJ_LOSS_RTOL, atol=1e-9)
 
 
+@pytest.mark.parametrize("world,L", [(3, 2), (2, 3)])
+def test_overlapped_hops_with_the_nonzero_row_bitmaps(world, L):
+    """the two round-2/3 mechanisms together: plans over huge operands filter the second backward hop by the bitmap of non-zero rows of u
+    (forced on here, sparse_bits_rows = 1) AND the hops are overlapped with their exchange -- the own-column pass then is a plain product
+    with that bitmap as its gather filter, the boundary-column pass the sparse epilogue.  Small batches, so most rows are skipped."""
+    import gcn_drug_repurposing_amd as pkg
+    from gcn_drug_repurposing_amd.dist import local_comms
+    from gcn_drug_repurposing_amd.shards import ScipySource, build_shard, shard_engine, shard_rows
+    from conftest import golden_params
+    lib = pkg.load()
+    g = load_golden("knn_n2000_d64_L3")
+    n, d, _ = (int(v) for v in g["meta"])
+    adj, X, p0 = golden_csr(g, "A"), g["X"], golden_params(g, "init")
+    rng = np.random.RandomState(21)
+    batches = [rng.choice(n, size=s, replace=False).astype(np.int32) for s in (40, 7, 64, 1)]
+    kw = dict(num_layers=L, layer_decay=float(g["decay"]), alpha=float(g["alpha"]), lr=float(g["lr"]), max_batch=64)
+
+    def run(split, bits_rows):
+        assert lib.gss_debug_set_option(b"sparse_bits_rows", bits_rows) == 0
+        try:
+            comms = local_comms(world)
+
+            def fn(rank):
+                shard = build_shard(ScipySource(adj), comms[rank], need_transpose=True, device="cuda:0", relabel=False, split=split)
+                eng = shard_engine(shard, shard_rows(shard, X), p0, comms[rank], **kw)
+                losses = []
+                for k, idx in enumerate(batches):
+                    (eng.step_lazy if k % 2 else eng.step)(torch.from_numpy(idx).cuda(), float(g["beta"]))
+                    losses.append(eng.loss.item())
+                eng.forward()
+                eng.check_guards()
+                return dict(losses=losses, emb=eng.gather_embeddings().cpu().numpy(), params=[t.cpu().numpy().copy() for t in eng.params])
+
+            return _threaded(world, fn, comms)
+        finally:
+            lib.gss_debug_set_option(b"sparse_bits_rows", 100000)
+
+    ref, both = run(False, 100000), run(True, 1)
+    for r in range(1, world):
+        assert both[r]["losses"] == both[0]["losses"]
+        np.testing.assert_array_equal(both[r]["emb"], both[0]["emb"])
+    a, b = ref[0], both[0]
+    np.testing.assert_allclose(b["losses"], a["losses"], rtol=T.TRAJ_LOSS_RTOL, atol=1e-9)
+    assert np.abs(b["emb"] - a["emb"]).max() / np.abs(a["emb"]).max() < T.TRAJ_EMB_REL
+    for x, y in zip(a["params"], b["params"]):
+        assert np.abs(x - y).max() < T.TRAJ_WEIGHT_LR * float(g["lr"])
+
+
 def test_zero_pieces_of_a_live_row_are_written_not_skipped():
     """with the non-zero-row bitmap on, the sparse backward hop leaves all-zero rows of u / t unwritten (every reader
     consults the bitmap).  That decision must be per ROW: a row whose bit is set but one of whose 4-feature pieces sums to exactly zero
