@@ -422,8 +422,13 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
  * 16-feature units (0 = automatic); "xcd_remap" = 0 / 1 (default): workgroups that read the same rows share an XCD (dense kernels);
  * "wgrad_wgs", "loss_wgs" = workgroups of a full-size weight-gradient launch / the loss sweep (default 256 = one per CU; set
  * before plans are created); "sparse_bits_rows" = operand rows from which a plan keeps the bitmaps of the sparsity-aware backward hops
- * (default 100000).  Every setting computes the same results (some in a different summation order); the defaults are the
- * measured optima recorded in DESIGN.md section 4. */
+ * (default 100000); round-3 experiments, all off by default: "gemm_prio", "wgrad_prio" (static wave priorities), "gemm_stagger" (late
+ * start of the second generation of projection workgroups), "gemm_lds_kb" / "wgrad_lds_kb" / "loss_lds_kb" (occupancy by LDS
+ * footprint), "wgrad_variant" = 1 (default) / 2 (operands through an LDS-DMA ring), "ppr_fused" = 1 (default) / 0 (separate update
+ * pass of the diffusion profiles).  Every setting computes the same results (some in a different summation order); the defaults are
+ * the measured optima recorded in DESIGN.md section 4.  The values are process-wide DEFAULTS: a plan (and a gss_ppr handle) takes a
+ * snapshot when it is created and runs under it from then on, so changing a knob never re-shapes a live plan -- in particular not
+ * the plans of other rank threads of the same process; per-op entry points read the current defaults. */
 int gss_debug_set_option(const char *name, int value);
 /* plain device-to-device copy on `stream` (lets a ctypes host read plan-owned activations) */
 int gss_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
