@@ -102,6 +102,7 @@ def build_workload(name, d_override=None):
 
 
 _RESULT_FD = 1
+_PG_DEVICE = "cuda"          # where the tensors of torch.distributed collectives live ("cpu" under GSS_COMM_BACKEND=host: gloo)
 
 
 def emit(result):
@@ -142,7 +143,7 @@ def bench_diffusion(args, rank, world, local_rank):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=_PG_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     sums = x[:, :prob.k].sum(0)
@@ -229,11 +230,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # GSS_COMM_BACKEND=host: the ranks are still separate processes with a plan each, but their collectives are staged through host
+    # memory over gloo and they may share a GPU -- how a ONE-GPU box rehearses `--gpus N` (RCCL refuses two ranks on a device).
+    # Never a measurement: the JSON line says so in config.parallelism and carries "rehearsal": true.
+    host_backend = os.environ.get("GSS_COMM_BACKEND", "rccl").lower() == "host"
+    global _PG_DEVICE
+    _PG_DEVICE = "cpu" if host_backend else "cuda"
+    if host_backend:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=2 * COLLECTIVE_TIMEOUT_S))
+        if host_backend:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=2 * COLLECTIVE_TIMEOUT_S))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=2 * COLLECTIVE_TIMEOUT_S))
 
     import gcn_drug_repurposing_amd as pkg
     from gcn_drug_repurposing_amd.graph import GssGraph
@@ -271,7 +283,10 @@ def main():
     if sharded and world == 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        if host_backend:
+            dist.init_process_group("gloo", rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
     halo_info = None
     shard = None
     # one GPU, a matrix in memory: the same builder as the shards (it relabels the nodes hub-first: -1.7 % of a step at config 2);
@@ -281,9 +296,9 @@ def main():
         # the native sharded path (also world = 1 for a row source): a gss_plan per rank that owns an RCCL communicator
         # (gss_plan_create_sharded); torch.distributed only hands the communicator's 128-byte id around and takes the MAX of
         # the timings.  Every rank builds its own rows only (shards.build_shard).
-        from gcn_drug_repurposing_amd.dist import local_comms, rccl_comm
+        from gcn_drug_repurposing_amd.dist import job_comm as make_job_comm, local_comms
         from gcn_drug_repurposing_amd.shards import ScipySource, build_shard, gaussian_rows, shard_engine
-        comm = rccl_comm(world, rank) if sharded else local_comms(1)[0]
+        comm = make_job_comm(world, rank) if sharded else local_comms(1)[0]
         t_setup = time.perf_counter()
         shard = build_shard(adj if from_source else ScipySource(adj), comm, need_transpose=L > 1)
         lo_, hi_ = shard.part.rows(rank)
@@ -299,6 +314,9 @@ def main():
                      "plan_bytes": engine.device_bytes()}
         parallelism = (f"node-range shards x{world}, native plan, boundary rows by grouped ncclSend/ncclRecv per SpMM hop" if sharded
                        else "single")
+        if sharded and host_backend:
+            parallelism = (f"REHEARSAL (GSS_COMM_BACKEND=host): node-range shards x{world}, one process and one native plan per rank, "
+                           f"collectives staged through host memory over gloo, {torch.cuda.device_count()} GPU(s) shared by the ranks -- not a measurement")
         if shard.relabel is not None:
             parallelism += "; nodes relabelled hub-first"
         if shard.layout.overlapped:
@@ -334,16 +352,16 @@ def main():
     def max_over_ranks(v):
         if world == 1:
             return float(v)
-        t = torch.tensor([v], dtype=torch.float64, device="cuda")
+        t = torch.tensor([v], dtype=torch.float64, device=_PG_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def all_ranks(vals):
         """[world][len(vals)] of every rank's floats"""
-        t = torch.tensor(list(vals), dtype=torch.float64, device="cuda")
+        t = torch.tensor(list(vals), dtype=torch.float64, device=_PG_DEVICE)
         if world == 1:
             return t.cpu().numpy()[None]
-        out = torch.empty(world * t.numel(), dtype=torch.float64, device="cuda")
+        out = torch.empty(world * t.numel(), dtype=torch.float64, device=_PG_DEVICE)
         dist.all_gather_into_tensor(out, t)
         return out.cpu().numpy().reshape(world, -1)
 
@@ -359,7 +377,7 @@ def main():
         per = max((time.perf_counter() - t_) / args.warmup, 1e-6)
         reps = int(min(args.spinup_time / per / args.warmup, 2000))
         if world > 1:
-            t = torch.tensor([reps], dtype=torch.int64, device="cuda")
+            t = torch.tensor([reps], dtype=torch.int64, device=_PG_DEVICE)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             reps = int(t.item())
         for _ in range(reps):
@@ -566,6 +584,8 @@ def main():
         # is max over pairs of bytes / link rate; the all-reduces (B d, 2 B d and 2 (d^2 + d) floats) are latency-bound and not priced
         ideal_us = (hops_a * allv[:, 4].max() + hops_t * allv[:, 5].max()) / (XGMI_LINK_GBS * 1e9) * 1e6
         out["rccl_ranks"] = job_comm.count()
+        if host_backend:
+            out["rehearsal"] = True
         out["per_rank"] = {"ms_per_step": allv[:, 0].tolist(), "ms_per_step_min": float(allv[:, 0].min()), "ms_per_step_max": float(allv[:, 0].max()),
                            "comm_ms_per_step": allv[:, 1].tolist(), "rows": allv[:, 8].astype(int).tolist(), "nnz": allv[:, 9].astype(int).tolist(),
                            "spmm_fwd1_us": allv[:, 7].tolist(), "spmm_fwd1_roofline_frac": allv[:, 6].tolist()}

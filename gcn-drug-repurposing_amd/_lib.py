@@ -77,6 +77,7 @@ SIGNATURES = {
     "gss_comm_unique_id": (C.c_int, [_P]),
     "gss_comm_create_rccl": (C.c_int, [C.POINTER(_P), _I32, _I32, _P]),
     "gss_comm_create_local": (C.c_int, [C.POINTER(_P), _I32]),
+    "gss_comm_create_host": (C.c_int, [C.POINTER(_P), _I32, _I32, _P, _P]),
     "gss_comm_destroy": (None, [_P]),
     "gss_comm_abort": (None, [_P]),
     "gss_comm_check": (C.c_int, [_P]),

@@ -245,11 +245,120 @@ struct LocalComm final : gss_comm {
   }
 };
 
+// ---- host-staged (a transport callback supplied by the host language) --------------------------------------------------------
+// One process per rank like RCCL, but the bytes travel device -> pinned host buffer -> callback -> pinned host buffer -> device.
+// The callback is whatever the host has (the Python package passes torch.distributed's gloo).  Purpose: RCCL refuses two ranks on
+// one device, so on a ONE-GPU box the real multi-PROCESS job -- torch.distributed.run, train.py --ngpus N, bench.py --gpus N, every
+// rank its own process and plan -- can still run with all ranks sharing the GPU (GSS_COMM_BACKEND=host).  Same interface, same
+// results (exchanges are copies; sums are taken in rank order, identical on every rank); not a fast path.
+struct HostComm final : gss_comm {
+  gss_host_xfer_fn fn = nullptr;
+  void *user = nullptr;
+  bool broken = false;
+  char *hsend = nullptr, *hrecv = nullptr;
+  size_t cap_send = 0, cap_recv = 0;
+  ~HostComm() override {
+    if (hsend) (void)hipHostFree(hsend);
+    if (hrecv) (void)hipHostFree(hrecv);
+  }
+  void abort() override { broken = true; }
+  int check_async() override { return broken ? fail(GSS_ECOMM, "host-staged communicator of rank %d failed earlier", rank) : GSS_OK; }
+  int count(int32_t *out) override {
+    *out = world;
+    return GSS_OK;
+  }
+  int sync(hipStream_t st, double) override {
+    GSS_HIP(hipStreamSynchronize(st));
+    return check_async();
+  }
+  int reserve(size_t ns, size_t nr) {
+    if (ns > cap_send) {
+      if (hsend) GSS_HIP(hipHostFree(hsend));
+      hsend = nullptr;
+      GSS_HIP(hipHostMalloc((void **)&hsend, ns, hipHostMallocDefault));
+      cap_send = ns;
+    }
+    if (nr > cap_recv) {
+      if (hrecv) GSS_HIP(hipHostFree(hrecv));
+      hrecv = nullptr;
+      GSS_HIP(hipHostMalloc((void **)&hrecv, nr, hipHostMallocDefault));
+      cap_recv = nr;
+    }
+    return GSS_OK;
+  }
+  int call(int kind, const int64_t *soff, const int64_t *roff, int64_t count) {
+    if (int rc = check_async()) return rc;
+    const int rc = fn(user, kind, hsend, soff, hrecv, roff, count);
+    if (rc != 0) {
+      broken = true;
+      return fail(GSS_ECOMM, "host-staged communicator: the transport callback failed (kind %d, code %d)", kind, rc);
+    }
+    return GSS_OK;
+  }
+  int all_gather(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) override {
+    if (int rc = reserve(bytes_per_rank ? bytes_per_rank : 1, bytes_per_rank * (size_t)world + 1)) return rc;
+    GSS_HIP(hipMemcpyAsync(hsend, send, bytes_per_rank, hipMemcpyDeviceToHost, st));
+    GSS_HIP(hipStreamSynchronize(st));
+    if (int rc = call(GSS_HOST_ALLGATHER, nullptr, nullptr, (int64_t)bytes_per_rank)) return rc;
+    GSS_HIP(hipMemcpyAsync(recv, hrecv, bytes_per_rank * (size_t)world, hipMemcpyHostToDevice, st));
+    GSS_HIP(hipStreamSynchronize(st));   // the staging buffer is reused by the next call
+    return GSS_OK;
+  }
+  int all_reduce_sum(float *const *bufs, const size_t *counts, int nbuf, hipStream_t st) override {
+    for (int k = 0; k < nbuf; ++k) {
+      const size_t bytes = counts[k] * sizeof(float);
+      if (bytes == 0) continue;
+      if (int rc = reserve(bytes, bytes * (size_t)world)) return rc;
+      GSS_HIP(hipMemcpyAsync(hsend, bufs[k], bytes, hipMemcpyDeviceToHost, st));
+      GSS_HIP(hipStreamSynchronize(st));
+      // every rank's contribution, then the sum in rank order on the host: the same bits on every rank
+      if (int rc = call(GSS_HOST_ALLGATHER, nullptr, nullptr, (int64_t)bytes)) return rc;
+      float *acc = reinterpret_cast<float *>(hsend);
+      const float *all = reinterpret_cast<const float *>(hrecv);
+      for (size_t i = 0; i < counts[k]; ++i) {
+        float sum = all[i];
+        for (int r = 1; r < world; ++r) sum += all[(size_t)r * counts[k] + i];
+        acc[i] = sum;
+      }
+      GSS_HIP(hipMemcpyAsync(bufs[k], hsend, bytes, hipMemcpyHostToDevice, st));
+      GSS_HIP(hipStreamSynchronize(st));
+    }
+    return GSS_OK;
+  }
+  int exchange_rows(const float *send, const int64_t *send_off, float *recv, const int64_t *recv_off, int d, hipStream_t st) override {
+    const size_t row = sizeof(float) * (size_t)d;
+    const size_t ns = (size_t)send_off[world] * row, nr = (size_t)recv_off[world] * row;
+    if (int rc = reserve(ns ? ns : 1, nr ? nr : 1)) return rc;
+    if (ns) GSS_HIP(hipMemcpyAsync(hsend, send, ns, hipMemcpyDeviceToHost, st));
+    GSS_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> sb((size_t)world + 1), rb((size_t)world + 1);
+    for (int q = 0; q <= world; ++q) {
+      sb[(size_t)q] = send_off[q] * (int64_t)row;
+      rb[(size_t)q] = recv_off[q] * (int64_t)row;
+    }
+    if (int rc = call(GSS_HOST_ALLTOALLV, sb.data(), rb.data(), 0)) return rc;
+    if (nr) GSS_HIP(hipMemcpyAsync(recv, hrecv, nr, hipMemcpyHostToDevice, st));
+    GSS_HIP(hipStreamSynchronize(st));
+    return GSS_OK;
+  }
+};
+
 }  // namespace gss
 
 using namespace gss;
 
 extern "C" {
+
+int gss_comm_create_host(gss_comm **out, int32_t world, int32_t rank, gss_host_xfer_fn fn, void *user) {
+  GSS_REQUIRE(out && fn && world >= 1 && rank >= 0 && rank < world, "comm_create_host: bad argument (world=%d rank=%d)", world, rank);
+  HostComm *c = new HostComm();
+  c->world = world;
+  c->rank = rank;
+  c->fn = fn;
+  c->user = user;
+  *out = c;
+  return GSS_OK;
+}
 
 int gss_comm_unique_id(void *id_out) {
   GSS_REQUIRE(id_out, "comm_unique_id: null pointer");

@@ -134,6 +134,83 @@ def rccl_comm(world=None, rank=None):
     return Comm(h, world, rank)
 
 
+# gss_host_xfer_fn (include/gssgcn.h): int fn(void *user, int kind, const void *send, const int64_t *send_off, void *recv,
+#                                             const int64_t *recv_off, int64_t count)
+_HOST_XFER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.c_int64)
+
+
+def _host_bytes(ptr, n):
+    """a uint8 tensor over n bytes of (pinned) host memory the library owns"""
+    return torch.frombuffer((C.c_uint8 * max(int(n), 1)).from_address(ptr), dtype=torch.uint8)[:int(n)]
+
+
+def host_comm(world=None, rank=None, group=None):
+    """Host-staged communicator (gss_comm_create_host) inside a torch.distributed job whose process group is gloo: the library
+    stages every collective through pinned host buffers and this module moves those bytes between the processes.  For boxes
+    where RCCL cannot run the job -- several ranks sharing ONE GPU, which RCCL refuses -- so that the real multi-process job
+    (torch.distributed.run, one plan per process) can be exercised there.  Select with GSS_COMM_BACKEND=host (job_comm)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if world is None else int(world)
+    rank = dist.get_rank(group) if rank is None else int(rank)
+
+    def xfer(_user, kind, send, send_off, recv, recv_off, count):
+        try:
+            if kind == 0:                                                   # GSS_HOST_ALLGATHER
+                out = _host_bytes(recv, count * world)
+                if world == 1:
+                    out.copy_(_host_bytes(send, count))
+                elif count > 0:
+                    dist.all_gather(list(out.view(world, count).unbind(0)), _host_bytes(send, count), group=group)
+            elif kind == 1:                                                 # GSS_HOST_ALLTOALLV
+                src, dst = _host_bytes(send, send_off[world]), _host_bytes(recv, recv_off[world])
+                reqs = []
+                for q in range(world):
+                    s0, s1, r0, r1 = send_off[q], send_off[q + 1], recv_off[q], recv_off[q + 1]
+                    if q == rank:                                            # own range: empty by contract, like the other backends
+                        continue
+                    if s1 > s0:
+                        reqs.append(dist.isend(src[s0:s1], q, group=group))
+                    if r1 > r0:
+                        reqs.append(dist.irecv(dst[r0:r1], q, group=group))
+                for r in reqs:
+                    r.wait()
+            else:
+                return 22
+            return 0
+        except Exception as e:                                              # never unwind through the C frame
+            import sys
+            print(f"[gss host comm rank {rank}] transport failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            return 5
+
+    cb = _HOST_XFER(xfer)
+    h = C.c_void_p()
+    _lib.check(_lib.load().gss_comm_create_host(C.byref(h), world, rank, C.cast(cb, C.c_void_p), None), "gss_comm_create_host")
+    comm = Comm(h, world, rank)
+    comm._keep = cb                                                         # the C side holds the function pointer
+    return comm
+
+
+def job_comm(world=None, rank=None):
+    """the communicator of this process in a torch.distributed job: RCCL (one GPU per rank) unless GSS_COMM_BACKEND=host asks for
+    the host-staged backend (ranks may share a GPU; the process group must be gloo)"""
+    import os
+    backend = os.environ.get("GSS_COMM_BACKEND", "rccl").lower()
+    if backend == "rccl":
+        return rccl_comm(world, rank)
+    if backend == "host":
+        return host_comm(world, rank)
+    raise ValueError(f"GSS_COMM_BACKEND={backend!r}: expected 'rccl' or 'host'")
+
+
+def job_device(local_rank):
+    """the device index of this process: its local rank, or -- host-staged backend on a box with fewer GPUs than ranks -- that
+    modulo the number of GPUs"""
+    import os
+    if os.environ.get("GSS_COMM_BACKEND", "rccl").lower() == "host":
+        return int(local_rank) % max(torch.cuda.device_count(), 1)
+    return int(local_rank)
+
+
 def local_comms(world):
     """`world` communicators for ranks that are threads of this process (gss_comm_create_local)"""
     arr = (C.c_void_p * world)()

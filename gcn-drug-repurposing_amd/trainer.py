@@ -111,6 +111,12 @@ def main(argv=None):
                         f"--nproc-per-node {args.ngpus} --master-addr 127.0.0.1 train.py ...")
     sharded = world > 1 or os.environ.get("GSS_FORCE_SHARDED") == "1"
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # GSS_COMM_BACKEND=host: collectives staged through host memory over gloo, ranks may share a GPU (dist.job_comm) -- how a
+    # one-GPU box runs the multi-process job; the default is RCCL with one GPU per rank
+    host_backend = os.environ.get("GSS_COMM_BACKEND", "rccl").lower() == "host"
+    if host_backend:
+        from .dist import job_device
+        local = job_device(local)
     dev = torch.device('cuda', args.gpu_id if (args.gpu_id is not None and world == 1) else local)
     torch.cuda.set_device(dev)
     if sharded:
@@ -123,7 +129,10 @@ def main(argv=None):
                     s_.bind(("127.0.0.1", 0))
                     os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
             import datetime
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=2 * COLLECTIVE_TIMEOUT_S))
+            if host_backend:
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=2 * COLLECTIVE_TIMEOUT_S))
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=2 * COLLECTIVE_TIMEOUT_S))
 
     if args.seed:                       # seed 0 / None leaves the RNGs unseeded, like train.py:74-76
         torch.manual_seed(args.seed)
@@ -170,8 +179,8 @@ def main(argv=None):
     if shard_path:
         # one process per GPU, node-range shards: a native gss_plan per rank that owns the RCCL communicator and enqueues
         # kernels and collectives from C++ (dist.sharded_plan_engine); same step semantics
-        from .dist import local_comms, rccl_comm, sharded_plan_engine
-        comm = rccl_comm(world, rank) if sharded else local_comms(1)[0]
+        from .dist import job_comm, local_comms, sharded_plan_engine
+        comm = job_comm(world, rank) if sharded else local_comms(1)[0]
         engine = sharded_plan_engine(adj, X32, host_params, comm, num_layers=args.num_layers, layer_decay=args.layer_decay,
                                      alpha=args.alpha, lr=args.lr, max_batch=min(bsz, n), device=dev, cache_layer1=args.cache_layer1)
         if rank == 0:
@@ -252,7 +261,12 @@ def main(argv=None):
         idx32 = torch.cat(batches).to(torch.int32).to(dev)
         if sharded and world > 1:
             import torch.distributed as dist
-            dist.broadcast(idx32, src=0)     # every rank trains on rank 0's batches even when no --seed is given
+            if host_backend:                 # a gloo group carries host tensors
+                host_idx = idx32.cpu()
+                dist.broadcast(host_idx, src=0)
+                idx32 = host_idx.to(dev)
+            else:
+                dist.broadcast(idx32, src=0)     # every rank trains on rank 0's batches even when no --seed is given
         off = 0
         for batch_id, b in enumerate(sizes):
             if itr == 0 and batch_id == 0:

@@ -153,6 +153,17 @@ int gss_scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32
 int gss_comm_unique_id(void *id_out);
 int gss_comm_create_rccl(gss_comm **out, int32_t world, int32_t rank, const void *id);
 int gss_comm_create_local(gss_comm **out /* [world] */, int32_t world);
+/* A third backend for boxes where RCCL cannot run the job: one PROCESS per rank as with RCCL, but every collective is staged through
+ * pinned host memory and handed to a transport callback of the host language (the Python package passes torch.distributed's gloo;
+ * GSS_COMM_BACKEND=host).  RCCL refuses two ranks on one device, so this is how `train.py --ngpus N` / `bench.py --gpus N` run as N
+ * real processes on a ONE-GPU test box (all ranks on that GPU).  The callback receives pinned host buffers:
+ *   GSS_HOST_ALLGATHER: `count` bytes at send from every rank, rank r's at recv + r * count;
+ *   GSS_HOST_ALLTOALLV: bytes [send_off[q], send_off[q+1]) of send go to rank q, the bytes rank q sends land at [recv_off[q], recv_off[q+1])
+ *   of recv (byte offsets, world + 1 entries each).
+ * (the own range is empty, as in gss_exchange_rows).  It returns 0 on success.  Sums (gss_allreduce_sum) are taken on the host in rank order: the same bits on every rank. */
+enum { GSS_HOST_ALLGATHER = 0, GSS_HOST_ALLTOALLV = 1 };
+typedef int (*gss_host_xfer_fn)(void *user, int kind, const void *send, const int64_t *send_off, void *recv, const int64_t *recv_off, int64_t count);
+int gss_comm_create_host(gss_comm **out, int32_t world, int32_t rank, gss_host_xfer_fn fn, void *user);
 void gss_comm_destroy(gss_comm *c);
 /* Make every rank that is (or will be) blocked in a collective of this group return an error -- call it from a rank that failed.
  * In-process backend: releases the host barrier (the peers do not wait for its 120 s timeout).  RCCL: ncclCommAbort -- kernels

@@ -341,6 +341,90 @@ def test_two_rccl_ranks_bench_line_is_complete():
     assert np.isfinite(line["config"]["final_loss"])
 
 
+def _host_env():
+    import os
+    return dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GSS_COMM_BACKEND="host")
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_multi_process_trainer_on_one_gpu_host_staged_backend(tmp_path, ranks):
+    """The multi-PROCESS job on a one-GPU box: `train.py --ngpus N` under torch.distributed.run, every rank its own process with its own
+    native sharded plan, collectives through the host-staged backend (gss_comm_create_host, gloo underneath) because RCCL refuses
+    two ranks on one device.  Same assertions as the two-RCCL-rank test: the single-GPU trainer's embeddings and the
+    reference-generated fixture."""
+    import os
+    import subprocess
+    import sys
+    g = load_golden("train_py_n200_d16")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    emb_path = tmp_path / "in.embs.txt"
+    emb_path.write_bytes(bytes(g["in_embs_txt"]))
+    common = ["--emb-file", str(emb_path), "--num-layers", "2", "--hidden-units", "16", "--k", "5", "--epochs", "3", "--lr", "0.0003",
+              "--beta-percentile", "98", "--batch-size", "64", "--seed", "7"]
+    multi = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                            "--master-port", str(_free_port()), os.path.join(root, "train.py")] + common
+                           + ["--ngpus", str(ranks), "--out", str(tmp_path / "multi.txt")], capture_output=True, text=True, env=_host_env(), timeout=900)
+    assert multi.returncode == 0, multi.stderr[-3000:]
+    one = subprocess.run([sys.executable, os.path.join(root, "train.py")] + common + ["--out", str(tmp_path / "one.txt")],
+                         capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    a, b = np.loadtxt(str(tmp_path / "multi.txt")), np.loadtxt(str(tmp_path / "one.txt"))
+    assert np.abs(a - b).max() < 1e-5          # weight gradients summed over the ranks instead of over the single GPU's slices
+    ref = np.loadtxt(bytes(g["graph_embs_txt"]).decode().splitlines())
+    assert np.abs(a - ref).max() < T.TRAJ_CLI_EMB_ABS
+
+
+def test_multi_process_bench_on_one_gpu_host_staged_backend():
+    """`bench.py --gpus 2` as two processes sharing the GPU (rehearsal of the driver's multi-GPU launch: rendezvous, sharding by rank,
+    barrier, max-over-ranks, the N>1 keys) -- the line is marked a rehearsal, its loss must equal the single-GPU run's"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--spinup-time", "0",
+                        "--min-time", "0"], capture_output=True, text=True, env=_host_env(), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["rehearsal"] is True
+    assert "REHEARSAL" in line["config"]["parallelism"]
+    for key in ("roofline", "xgmi", "per_rank", "comm_share", "kernel_ms_per_step", "value_executed"):
+        assert key in line, key
+    assert len(line["per_rank"]["ms_per_step"]) == 2 and sum(line["per_rank"]["rows"]) == 29960
+    ref = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--spinup-time", "0", "--min-time", "0",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert ref.returncode == 0, ref.stderr[-3000:]
+    one = json.loads([l for l in ref.stdout.splitlines() if l.startswith("{")][-1])
+    assert abs(line["config"]["final_loss"] - one["config"]["final_loss"]) <= T.SPREAD_LOSS_REL * 10 * abs(one["config"]["final_loss"])
+
+
+def test_host_staged_backend_collectives_single_rank():
+    """gss_comm_create_host with one rank in this process: the three collectives are copies through the pinned staging buffers"""
+    import torch.distributed as dist
+    from gcn_drug_repurposing_amd.dist import host_comm
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    started = not dist.is_initialized()
+    if started:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        comm = host_comm(1, 0)
+        assert comm.count() == 1
+        t = torch.randn(1000, device="cuda")
+        ref = t.clone()
+        comm.all_reduce_sum_(t)
+        g = comm.allgather_bytes(ref)
+        send = torch.randn(7, 16, device="cuda")
+        recv = torch.zeros(7, 16, device="cuda")
+        comm.exchange_rows(16, send, np.array([0, 0]), recv, np.array([0, 0]))      # the own range is empty by contract
+        comm.sync(10)
+        assert torch.equal(t, ref) and torch.equal(g, ref) and not bool(recv.any())
+    finally:
+        if started:
+            dist.destroy_process_group()
+
+
 def test_bench_sharded_path_over_rccl_single_rank(tmp_path):
     """bench.py's multi-GPU branch (the native sharded plan over an RCCL communicator) with one rank, launched the way the driver
     launches it; must agree with the single-GPU plan's loss after the same steps and carry the keys a scaling run is graded on."""
