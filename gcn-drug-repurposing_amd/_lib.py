@@ -118,6 +118,7 @@ SIGNATURES = {
     "gss_plan_activation": (_P, [_P, C.c_int, C.c_int]),
     "gss_plan_device_bytes": (_SZ, [_P]),
     "gss_plan_check_guards": (C.c_int, [_P]),
+    "gss_plan_lazy_halo_rows": (C.c_int, [_P, C.POINTER(_I64)]),
     "gss_plan_set_step": (None, [_P, _I32]),
     "gss_plan_adam_buffer": (_P, [_P, _I32, _I32]),
     "gss_plan_get_step": (_I32, [_P]),

@@ -38,6 +38,7 @@ struct Knobs {
   // places as many workgroups on a CU as fit, not one per CU -- a grid of 256 "one per CU" workgroups may double up on some CUs and
   // leave others idle.  > 80 KB admits one workgroup per CU, 54-80 KB two.
   int gemm_lds_kb = 0, wgrad_lds_kb = 0, loss_lds_kb = 0;
+  int lazy_halo = -1;        // sharded lazy step: fetch only the boundary rows of the top layer's M that the batch rows read (-1 = graphs of >= 262,144 nodes, 0 = never, 1 = always)
   int ppr_fused = 1;         // diffusion profiles: the update and the column errors in the SpMM's epilogue (0 = separate update pass)
 };
 template <typename F>

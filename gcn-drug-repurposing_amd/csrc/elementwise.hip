@@ -144,6 +144,122 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n, int d4, const
   st4(out + i * 4, ld4(src + ((size_t)rows[r] * d4 + f4) * 4));
 }
 
+// halo exchange, receiver side of a compacted exchange: dst[rows[k]] = src[k]
+__global__ __launch_bounds__(256) void unpack_rows_kernel(int64_t n, int d4, const float *__restrict__ src, const int32_t *__restrict__ rows,
+                                                          float *__restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)n * d4) return;
+  const size_t r = i / d4, f4 = i % d4;
+  st4(dst + ((size_t)rows[r] * d4 + f4) * 4, ld4(src + i * 4));
+}
+
+// Lazy halo (plan.hip plan_halo_needed): which boundary rows do the listed rows of this shard read?  One wave per listed row; an entry
+// whose column is halo slot h of owner q sets bit (h - recv_off[q]) of q's word range [wrecv_off[q], wrecv_off[q + 1]).
+__global__ __launch_bounds__(256) void halo_need_mark_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                             const int32_t *__restrict__ rows, int b, int n, int P,
+                                                             const int64_t *__restrict__ recv_off, const int64_t *__restrict__ wrecv_off,
+                                                             uint32_t *__restrict__ needw) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= b) return;
+  const int r = rows[i];
+  if (r < 0) return;   // a member another shard owns
+  for (int e = rowptr[r] + lane; e < rowptr[r + 1]; e += 64) {
+    const int c = col[e];
+    if (c < n) continue;
+    const int64_t h = c - n;
+    int q = 0;
+    while (q + 1 < P && recv_off[q + 1] <= h) ++q;
+    const int64_t bit = wrecv_off[q] * 32 + (h - recv_off[q]);
+    atomicOr(&needw[bit >> 5], 1u << (bit & 31));
+  }
+}
+
+// Sender-driven form: word w of peer q's range [wsend_off[q], wsend_off[q + 1]) collects bits[send_rows[s]] of its 32 send slots
+__global__ __launch_bounds__(256) void send_slot_bits_kernel(const uint32_t *__restrict__ bits, const int32_t *__restrict__ send_rows, int P,
+                                                             const int64_t *__restrict__ send_off, const int64_t *__restrict__ wsend_off,
+                                                             int64_t n_words, uint32_t *__restrict__ out) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  int q = 0;
+  while (q + 1 < P && wsend_off[q + 1] <= w) ++q;
+  const int64_t s0 = send_off[q] + (w - wsend_off[q]) * 32, s1 = send_off[q + 1];
+  uint32_t word = 0;
+  for (int j = 0; j < 32 && s0 + j < s1; ++j) {
+    const int r = send_rows[s0 + j];
+    word |= ((bits[(unsigned)r >> 5] >> (r & 31)) & 1u) << j;
+  }
+  out[w] = word;
+}
+
+// bits [first, last) := 0, other bits untouched (atomics: the edge words may be shared with concurrent writers of other bits)
+__global__ __launch_bounds__(256) void bits_clear_kernel(uint32_t *__restrict__ bits, long long first, long long last) {
+  const long long w = first / 32 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w > (last - 1) / 32) return;
+  const long long b0 = w * 32;
+  const int lo = (int)(first > b0 ? first - b0 : 0), hi = (int)(last < b0 + 32 ? last - b0 : 32);
+  const uint32_t mask = (hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+  if (mask == 0xffffffffu)
+    bits[w] = 0u;
+  else
+    atomicAnd(&bits[w], ~mask);
+}
+
+__global__ __launch_bounds__(256) void bits_set_list_kernel(uint32_t *__restrict__ bits, const int32_t *__restrict__ list, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int r = list[i];
+  atomicOr(&bits[(unsigned)r >> 5], 1u << (r & 31));
+}
+
+// The set bits of P word ranges, in ascending order, as a list: bit j of range q is slot slot_off[q] + j; the list holds map[slot]
+// (map != NULL) or slot + add.  out_off[q + 1] = entries up to and including range q.  One workgroup (the bitmaps are a few thousand
+// words; both sides of an exchange run it over the same bits, so their counts and orders agree by construction).
+__global__ __launch_bounds__(1024) void bits_compact_kernel(const uint32_t *__restrict__ words, int P, const int64_t *__restrict__ woff,
+                                                            const int64_t *__restrict__ slot_off, const int32_t *__restrict__ map, int32_t add,
+                                                            int32_t *__restrict__ out, int64_t *__restrict__ out_off) {
+  __shared__ int wave_tot[16];
+  __shared__ long long run;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) {
+    run = 0;
+    out_off[0] = 0;
+  }
+  __syncthreads();
+  for (int q = 0; q < P; ++q) {
+    const int64_t w0 = woff[q], w1 = woff[q + 1], s0 = slot_off[q];
+    for (int64_t wb = w0; wb < w1; wb += 1024) {
+      const int64_t w = wb + tid;
+      uint32_t bits = w < w1 ? words[w] : 0u;
+      const int c = __popc(bits);
+      int incl = c;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63) wave_tot[wv] = incl;
+      __syncthreads();
+      long long pos = run + incl - c;
+      for (int k = 0; k < wv; ++k) pos += wave_tot[k];
+      const int64_t slot_base = s0 + (w - w0) * 32;
+      while (bits) {
+        const int bpos = __ffs(bits) - 1;
+        bits &= bits - 1;
+        const int64_t slot = slot_base + bpos;
+        out[pos++] = map ? map[slot] : (int32_t)(slot + add);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int t = 0;
+        for (int k = 0; k < 16; ++k) t += wave_tot[k];
+        run += t;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) out_off[q + 1] = run;
+  }
+}
+
 // ---- K10  torch.optim.Adam (single-tensor form of torch/optim/adam.py; train.py:139-141,184) -------
 __global__ __launch_bounds__(256) void adam_kernel(int64_t count, float *__restrict__ param, const float *__restrict__ grad,
                                                    float *__restrict__ m, float *__restrict__ v, float lr_over_bc1,
@@ -322,6 +438,60 @@ int pack_rows(int32_t d, const float *src, const int32_t *rows, int64_t n, float
   if (n == 0) return GSS_OK;
   hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(n * (d / 4), 256)), dim3(256), 0, as_stream(stream), n, d / 4, src, rows, out);
   GSS_LAUNCH_CHECK("pack_rows_kernel");
+  return GSS_OK;
+}
+
+int unpack_rows(int32_t d, const float *src, const int32_t *rows, int64_t n, float *dst, void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(n >= 0 && (n == 0 || (src && rows && dst)), "unpack_rows: null operand");
+  if (n == 0) return GSS_OK;
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3(ceil_div(n * (d / 4), 256)), dim3(256), 0, as_stream(stream), n, d / 4, src, rows, dst);
+  GSS_LAUNCH_CHECK("unpack_rows_kernel");
+  return GSS_OK;
+}
+
+int halo_need_mark(const gss_csr *a, const int32_t *rows, int32_t b, int32_t n, int P, const int64_t *d_recv_off, const int64_t *d_wrecv_off,
+                   uint32_t *needw, void *stream) {
+  GSS_REQUIRE(a && rows && d_recv_off && d_wrecv_off && needw && b >= 0 && P >= 1, "halo_need_mark: bad argument");
+  if (b == 0 || a->n_rows == 0) return GSS_OK;
+  hipLaunchKernelGGL(halo_need_mark_kernel, dim3(ceil_div(b, 4)), dim3(256), 0, as_stream(stream), a->rowptr, a->col, rows, b, n, P, d_recv_off,
+                     d_wrecv_off, needw);
+  GSS_LAUNCH_CHECK("halo_need_mark_kernel");
+  return GSS_OK;
+}
+
+int send_slot_bits(const uint32_t *bits, const int32_t *send_rows, int P, const int64_t *d_send_off, const int64_t *d_wsend_off, int64_t n_words,
+                   uint32_t *out, void *stream) {
+  GSS_REQUIRE(bits && d_send_off && d_wsend_off && out && n_words >= 0 && (n_words == 0 || send_rows), "send_slot_bits: bad argument");
+  if (n_words == 0) return GSS_OK;
+  hipLaunchKernelGGL(send_slot_bits_kernel, dim3(ceil_div(n_words, 256)), dim3(256), 0, as_stream(stream), bits, send_rows, P, d_send_off, d_wsend_off,
+                     n_words, out);
+  GSS_LAUNCH_CHECK("send_slot_bits_kernel");
+  return GSS_OK;
+}
+
+int bits_clear(uint32_t *bits, int64_t first, int64_t last, void *stream) {
+  GSS_REQUIRE(bits && first >= 0, "bits_clear: bad argument");
+  if (last <= first) return GSS_OK;
+  const int64_t words = (last - 1) / 32 - first / 32 + 1;
+  hipLaunchKernelGGL(bits_clear_kernel, dim3(ceil_div(words, 256)), dim3(256), 0, as_stream(stream), bits, (long long)first, (long long)last);
+  GSS_LAUNCH_CHECK("bits_clear_kernel");
+  return GSS_OK;
+}
+
+int bits_set_list(uint32_t *bits, const int32_t *list, int64_t n, void *stream) {
+  GSS_REQUIRE(bits && n >= 0 && (n == 0 || list), "bits_set_list: bad argument");
+  if (n == 0) return GSS_OK;
+  hipLaunchKernelGGL(bits_set_list_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), bits, list, n);
+  GSS_LAUNCH_CHECK("bits_set_list_kernel");
+  return GSS_OK;
+}
+
+int bits_compact(const uint32_t *words, int P, const int64_t *d_woff, const int64_t *d_slot_off, const int32_t *map, int32_t add, int32_t *out,
+                 int64_t *d_out_off, void *stream) {
+  GSS_REQUIRE(words && d_woff && d_slot_off && out && d_out_off && P >= 1, "bits_compact: bad argument");
+  hipLaunchKernelGGL(bits_compact_kernel, dim3(1), dim3(1024), 0, as_stream(stream), words, P, d_woff, d_slot_off, map, add, out, d_out_off);
+  GSS_LAUNCH_CHECK("bits_compact_kernel");
   return GSS_OK;
 }
 

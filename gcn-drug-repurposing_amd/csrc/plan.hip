@@ -84,6 +84,24 @@ struct gss_plan {
   const gss_csr *a_own, *a_halo, *at_own, *at_halo;
   hipStream_t xs;
   hipEvent_t ev_ready, ev_halo;
+  // lazy halo (knob lazy_halo; gss_plan_step_lazy on shards): of the top layer's M only the boundary rows that the batch rows this
+  // shard owns reference are fetched.  Requests travel as bitmaps over the (static) halo slots -- word-aligned per owner, so their
+  // sizes are host constants --; both sides list the set bits in the same order; the per-peer counts come back to the host once per
+  // step (ncclSend / ncclRecv take host-side counts).
+  struct LazyHalo {
+    bool on = false;
+    std::vector<int64_t> w_recv_off, w_send_off;   // word offsets per owner / per requester
+    int64_t *d_meta = nullptr;                     // device copies: recv_off | w_recv_off | send_off | w_send_off, P + 1 entries each
+    uint32_t *needw = nullptr, *reqw = nullptr;    // what I need of each owner / what each requester needs of me
+    int32_t *recv_list = nullptr, *send_list = nullptr;   // operand rows the fetched rows land on / own rows to pack, in exchange order
+    int64_t *d_cnt = nullptr;                      // send offsets (P + 1) | recv offsets (P + 1) of this step's exchange
+    int64_t *h_cnt = nullptr;                      // pinned host copy
+    float *recvbuf = nullptr;                      // [n_halo][d] staging of the fetched rows
+    int64_t last_recv = -1, last_send = -1;        // rows moved by the last exchange (gss_plan_lazy_halo_rows)
+  } lz, lzt;
+  // lzt: the same machinery for A_hat^T's halo, driven by the SENDER: of u -- the operand of the top layer's second backward hop, non-zero
+  // only in the batch's neighbourhood (nzbits) -- the owners send the rows that can be non-zero and the bitmap that says which; the receiver
+  // sets exactly those bits behind its own rows' in nzbits, so the hop never reads a row that was not sent.  Full and lazy steps alike.
 };
 
 // debug knob "sparse_bits_rows": operand rows from which a plan keeps the two bitmaps of the sparsity-aware backward hops (the
@@ -153,6 +171,19 @@ void carve(gss_plan *p, Carver &c) {
   const bool sharded = p->P > 1;
   const size_t n_send = (size_t)std::max(p->halo_a.n_send, p->halo_t.n_send);
   p->sendbuf = sharded ? c.take<float>((n_send ? n_send : 1) * D.d) : nullptr;
+  auto carve_lazy = [&](gss_plan::LazyHalo &z, const gss_plan::Halo &h) {
+    if (!z.on) return;
+    const size_t P1 = (size_t)p->P + 1;
+    z.d_meta = c.take<int64_t>(4 * P1);
+    z.d_cnt = c.take<int64_t>(2 * P1);
+    z.needw = c.take<uint32_t>((size_t)z.w_recv_off.back() + 1);
+    z.reqw = c.take<uint32_t>((size_t)z.w_send_off.back() + 1);
+    z.recv_list = c.take<int32_t>((size_t)h.n_halo + 1);
+    z.send_list = c.take<int32_t>((size_t)h.n_send + 1);
+    z.recvbuf = c.take<float>(((size_t)h.n_halo + 1) * D.d);
+  };
+  carve_lazy(p->lz, p->halo_a);
+  carve_lazy(p->lzt, p->halo_t);
   p->x0op = sharded ? c.take<float>(nd_a) : const_cast<float *>(p->x);
   const bool maps = sharded || D.node_map != nullptr;   // per-batch index maps are needed
   p->pid = maps ? c.take<int32_t>(D.max_batch) : nullptr;
@@ -198,7 +229,9 @@ void carve(gss_plan *p, Carver &c) {
   p->pos = L > 1 ? c.take<int32_t>(p->rows_t ? p->rows_t : 1) : nullptr;
   // from sparse_bits_rows operand rows on: the sparse SpMM tests a bitmap before the 4-byte-per-node map (zero-initialised slab)
   // (the sizing pass carves from a null base: conditions must not look at the pointers it hands out)
-  const bool bitmaps = L > 1 && p->rows_t >= (size_t)K().sparse_bits_rows;
+  // (with the lazy halo the bitmaps are kept whatever the size of THIS shard: whether a hop's exchange is a subset is a decision all
+  // ranks must share, and the sender-driven subset of u's halo is read off nzbits)
+  const bool bitmaps = L > 1 && (p->rows_t >= (size_t)K().sparse_bits_rows || p->lzt.on);
   p->posbits = bitmaps ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;
   p->nzbits = bitmaps ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;
   p->needbits = (bitmaps && !sharded) ? c.take<uint32_t>(n1 / 32 + 1) : nullptr;
@@ -336,6 +369,23 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
     p->prof_ms[k] = 0.0;
     p->prof_cnt[k] = 0;
   }
+  {
+    // every rank takes the same decision: it depends on the knob and the size of the whole graph only
+    const int knob = K().lazy_halo;
+    p->lz.on = P > 1 && desc->num_layers > 1 && (knob == 1 || (knob < 0 && n_global >= 262144));
+    p->lzt.on = p->lz.on && spmm_sparse_available();      // (the sparse first backward hop writes nzbits; knob spmm_variant is process-wide)
+    auto word_offsets = [&](gss_plan::LazyHalo &z, const gss_plan::Halo &h) {
+      if (!z.on) return;
+      z.w_recv_off.assign((size_t)P + 1, 0);
+      z.w_send_off.assign((size_t)P + 1, 0);
+      for (int q = 0; q < P; ++q) {
+        z.w_recv_off[(size_t)q + 1] = z.w_recv_off[(size_t)q] + (h.recv_off[(size_t)q + 1] - h.recv_off[(size_t)q] + 31) / 32;
+        z.w_send_off[(size_t)q + 1] = z.w_send_off[(size_t)q] + (h.send_off[(size_t)q + 1] - h.send_off[(size_t)q] + 31) / 32;
+      }
+    };
+    word_offsets(p->lz, p->halo_a);
+    word_offsets(p->lzt, p->halo_t);
+  }
   Carver sizing;
   carve(p, sizing);
   p->slab_bytes = sizing.off + 256;
@@ -405,6 +455,25 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
       return fail(GSS_EHIP, "plan_create: hipMemset(guard) -> %s", hipGetErrorString(e));
     }
   }
+  for (int m = 0; m < 2; ++m) {
+    gss_plan::LazyHalo &z = m ? p->lzt : p->lz;
+    const gss_plan::Halo &h = m ? p->halo_t : p->halo_a;
+    if (!z.on) continue;
+    const size_t P1 = (size_t)P + 1;
+    std::vector<int64_t> meta;
+    meta.insert(meta.end(), h.recv_off.begin(), h.recv_off.end());
+    meta.insert(meta.end(), z.w_recv_off.begin(), z.w_recv_off.end());
+    meta.insert(meta.end(), h.send_off.begin(), h.send_off.end());
+    meta.insert(meta.end(), z.w_send_off.begin(), z.w_send_off.end());
+    e = hipMemcpy(z.d_meta, meta.data(), sizeof(int64_t) * 4 * P1, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&z.h_cnt, sizeof(int64_t) * 2 * P1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      if (p->lz.h_cnt) (void)hipHostFree(p->lz.h_cnt);
+      (void)hipFree(p->slab);
+      delete p;
+      return fail(GSS_EHIP, "plan_create: lazy-halo tables -> %s", hipGetErrorString(e));
+    }
+  }
   if (p->nzbits && p->rows_t > (size_t)desc->n) {
     // rows a peer owns: this shard cannot know whether they are zero
     if (int rc = bits_fill(p->nzbits, desc->n, (int64_t)p->rows_t, nullptr)) {
@@ -436,20 +505,78 @@ int plan_halo(gss_plan *p, const gss_plan::Halo &h, float *op, void *stream) {
   return p->comm->exchange_rows(p->sendbuf, h.send_off.data(), op + (size_t)p->desc.n * d, h.recv_off.data(), d, as_stream(stream));
 }
 
+// A hop that reads a SUBSET of its operand's boundary rows (knob lazy_halo).  Which rows is known on one side only:
+//   need_rows != NULL  (the top layer's M in a lazy step): the receiver knows -- the columns of the rows `need_rows[0..b)` of A_hat it
+//                      evaluates (-1: a peer's member); it marks them over its halo slots and sends the bitmaps to the owners;
+//   src_bits  != NULL  (u, the operand of the top layer's second backward hop): the sender knows -- its rows that can be non-zero
+//                      (nzbits); it sends the bitmaps over its send slots to the receivers, which then set exactly those bits behind their
+//                      own rows' in the same bitmap, so the hop's non-zero-row filter never lets it read a row that was not sent.
+// The bitmaps are word-aligned per peer, their sizes host constants; both sides list the set bits in the same order; the per-peer row counts
+// of the step come back to the host once (ncclSend / ncclRecv take host-side counts).  Boundary rows that are not fetched keep whatever
+// they held: nothing reads them.
+int plan_halo_subset(gss_plan *p, gss_plan::LazyHalo &z, const gss_plan::Halo &h, const gss_csr *a, float *op, const int32_t *need_rows, int32_t b,
+                     uint32_t *src_bits, void *stream) {
+  PROF(GSS_PROF_COMM);
+  const int P = p->P, d = p->desc.d, n = p->desc.n;
+  const size_t P1 = (size_t)P + 1;
+  hipStream_t st = as_stream(stream);
+  const int64_t *d_recv_off = z.d_meta, *d_wrecv_off = z.d_meta + P1, *d_send_off = z.d_meta + 2 * P1, *d_wsend_off = z.d_meta + 3 * P1;
+  if (need_rows) {
+    GSS_HIP(hipMemsetAsync(z.needw, 0, sizeof(uint32_t) * ((size_t)z.w_recv_off.back() + 1), st));
+    if (h.n_halo > 0)
+      if (int rc = halo_need_mark(a, need_rows, b, n, P, d_recv_off, d_wrecv_off, z.needw, stream)) return rc;
+    // my requests are grouped by owner (the layout I receive rows in); what arrives is grouped by requester (the layout I send rows in)
+    if (int rc = p->comm->exchange_rows(reinterpret_cast<const float *>(z.needw), z.w_recv_off.data(), reinterpret_cast<float *>(z.reqw),
+                                        z.w_send_off.data(), 1, st))
+      return rc;
+  } else {
+    if (int rc = send_slot_bits(src_bits, h.d_send_rows, P, d_send_off, d_wsend_off, z.w_send_off.back(), z.reqw, stream)) return rc;
+    if (int rc = p->comm->exchange_rows(reinterpret_cast<const float *>(z.reqw), z.w_send_off.data(), reinterpret_cast<float *>(z.needw),
+                                        z.w_recv_off.data(), 1, st))
+      return rc;
+  }
+  if (int rc = bits_compact(z.reqw, P, d_wsend_off, d_send_off, h.d_send_rows, 0, z.send_list, z.d_cnt, stream)) return rc;
+  if (int rc = bits_compact(z.needw, P, d_wrecv_off, d_recv_off, nullptr, n, z.recv_list, z.d_cnt + P1, stream)) return rc;
+  GSS_HIP(hipMemcpyAsync(z.h_cnt, z.d_cnt, sizeof(int64_t) * 2 * P1, hipMemcpyDeviceToHost, st));
+  if (int rc = p->comm->sync(st, 300.0)) return rc;          // the counts of this step; with the communicator's watchdog
+  const int64_t *send_off = z.h_cnt, *recv_off = z.h_cnt + P1;
+  GSS_REQUIRE(send_off[P] >= 0 && send_off[P] <= h.n_send && recv_off[P] >= 0 && recv_off[P] <= h.n_halo,
+              "lazy halo: %lld rows to send of %lld, %lld to fetch of %lld", (long long)send_off[P], (long long)h.n_send, (long long)recv_off[P],
+              (long long)h.n_halo);
+  z.last_send = send_off[P];
+  z.last_recv = recv_off[P];
+  if (int rc = pack_rows(d, op, z.send_list, send_off[P], p->sendbuf, stream)) return rc;
+  if (int rc = p->comm->exchange_rows(p->sendbuf, send_off, z.recvbuf, recv_off, d, st)) return rc;
+  if (src_bits) {
+    // the boundary rows' bits: exactly the rows that arrive (atomics: the word that straddles the own rows is shared with them)
+    if (int rc = bits_clear(src_bits, n, n + h.n_halo, stream)) return rc;
+    if (int rc = bits_set_list(src_bits, z.recv_list, recv_off[P], stream)) return rc;
+  }
+  return unpack_rows(d, z.recvbuf, z.recv_list, recv_off[P], op, stream);
+}
+
 // One hop over an operand whose boundary rows come from the peers.  Plain form: exchange, then `full` (the product over the shard's
 // whole CSR).  Overlapped form (the matrix was given split, gss_shard_desc): the exchange runs on p->xs while `own` multiplies the
 // entries that reference the shard's own rows -- complete as soon as the producing kernel is --, then `rest` adds the boundary-column
 // entries and runs the epilogue.  Both streams are re-joined before `rest`, so everything after the hop is ordered as before.
 template <typename Full, typename Own, typename Rest>
-int plan_hop(gss_plan *p, const gss_plan::Halo &h, bool overlapped, float *op, void *stream, Full full, Own own, Rest rest) {
+int plan_hop(gss_plan *p, const gss_plan::Halo &h, bool overlapped, float *op, void *stream, Full full, Own own, Rest rest,
+             const int32_t *need_rows = nullptr, int32_t need_b = 0, uint32_t *src_bits = nullptr) {
+  // need_rows / src_bits: a subset of the boundary rows (plan_halo_subset); h is halo_a with need_rows, halo_t with src_bits
+  auto exchange = [&](void *st) {
+    if (need_rows) return plan_halo_subset(p, p->lz, h, p->a, op, need_rows, need_b, nullptr, st);
+    if (src_bits) return plan_halo_subset(p, p->lzt, h, p->at, op, nullptr, 0, src_bits, st);
+    return plan_halo(p, h, op, st);
+  };
   if (p->P == 1 || !overlapped) {
-    if (int rc = plan_halo(p, h, op, stream)) return rc;
+    if (p->P > 1)
+      if (int rc = exchange(stream)) return rc;
     return full();
   }
   GSS_HIP(hipEventRecord(p->ev_ready, as_stream(stream)));     // the operand's own rows are complete here
   GSS_HIP(hipStreamWaitEvent(p->xs, p->ev_ready, 0));
   if (int rc = own()) return rc;                               // enqueued first: the in-process backend blocks the host in the exchange
-  if (int rc = plan_halo(p, h, op, p->xs)) return rc;
+  if (int rc = exchange(p->xs)) return rc;
   GSS_HIP(hipEventRecord(p->ev_halo, p->xs));
   GSS_HIP(hipStreamWaitEvent(as_stream(stream), p->ev_halo, 0));
   return rest();
@@ -574,7 +701,8 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
             PROF(GSS_PROF_SPMM_FWD);
             return spmm_fwd(p->a_halo, D.d, m, p->am[l], nullptr, nullptr, stream, rpos, nullptr, p->am[l]);
           };
-          if (int rc = plan_hop(p, p->halo_a, split_a, m, stream, full, own, rest)) return rc;
+          const bool needed_only = lazy_l && p->lz.on;      // the batch rows' columns are all of M's boundary rows this hop reads
+          if (int rc = plan_hop(p, p->halo_a, split_a, m, stream, full, own, rest, needed_only ? lazy_rows : nullptr, lazy_b)) return rc;
           if (l == 0) p->m0_ready = true;
         }
       }
@@ -766,7 +894,9 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
             return spmm_bwd2_sparse_res(p->at_halo, D.d, p->u, p->t, p->p[lp], c, p->dx_b, pos_row, p->dp, gx_out, stream, p->nzbits, p->dp);
           return spmm_bwd2(p->at_halo, D.d, p->u, p->t, p->p[lp], c, res, p->dp, gx_out, stream, p->dp);
         };
-        if (int rc = plan_hop(p, p->halo_t, split_t, p->u, stream, full, own, rest)) return rc;
+        // fold_res with the non-zero-row bitmap: u is zero outside the batch's neighbourhood -- the owners send the rows that are not
+        const bool subset = fold_res && p->lzt.on && p->nzbits;
+        if (int rc = plan_hop(p, p->halo_t, split_t, p->u, stream, full, own, rest, nullptr, 0, subset ? p->nzbits : nullptr)) return rc;
       }
       if (lp + 2 == L && !fold_res) {
         PROF(GSS_PROF_ELEMENTWISE);
@@ -862,6 +992,8 @@ void gss_plan_destroy(gss_plan *p) {
   if (p->ev_halo) (void)hipEventDestroy(p->ev_halo);
   if (p->ev_main_ready) (void)hipEventDestroy(p->ev_main_ready);
   if (p->ev_side_done) (void)hipEventDestroy(p->ev_side_done);
+  if (p->lz.h_cnt) (void)hipHostFree(p->lz.h_cnt);
+  if (p->lzt.h_cnt) (void)hipHostFree(p->lzt.h_cnt);
   if (p->slab) (void)hipFree(p->slab);
   delete p;
 }
@@ -997,6 +1129,17 @@ const float *gss_plan_activation(const gss_plan *p, int layer, int which) {
   return which == 0 ? p->ax[layer] : which == 1 ? p->am[layer] : which == 2 ? p->p[layer] : nullptr;
 }
 size_t gss_plan_device_bytes(const gss_plan *p) { return p ? p->slab_bytes : 0; }
+
+int gss_plan_lazy_halo_rows(const gss_plan *p, int64_t *out6) {
+  GSS_REQUIRE(p && out6, "plan_lazy_halo_rows: null argument");
+  out6[0] = p->lz.on ? p->lz.last_recv : -1;
+  out6[1] = p->lz.on ? p->lz.last_send : -1;
+  out6[2] = p->halo_a.n_halo;
+  out6[3] = p->lzt.on ? p->lzt.last_recv : -1;
+  out6[4] = p->lzt.on ? p->lzt.last_send : -1;
+  out6[5] = p->halo_t.n_halo;
+  return GSS_OK;
+}
 
 int gss_plan_check_guards(gss_plan *p) {
   GSS_REQUIRE(p, "plan_check_guards: null plan");

@@ -175,5 +175,13 @@ class GssEngine:
         """raises if a kernel wrote behind one of the plan's buffers (gss_plan_check_guards; tests call it)"""
         _lib.check(self.lib.gss_plan_check_guards(self.handle), "gss_plan_check_guards")
 
+    def lazy_halo_rows(self):
+        """what the last subset exchanges of a sharded plan moved (gss_plan_lazy_halo_rows): (fetched, sent, whole halo) of the top
+        layer's M in a lazy step, then the same of u in the second backward hop; fetched / sent are -1 when the plan exchanges whole halos"""
+        import ctypes as C
+        out = (C.c_int64 * 6)()
+        _lib.check(self.lib.gss_plan_lazy_halo_rows(self.handle, out), "gss_plan_lazy_halo_rows")
+        return tuple(int(v) for v in out)
+
     def device_bytes(self) -> int:
         return int(self.lib.gss_plan_device_bytes(self.handle))

@@ -390,6 +390,14 @@ int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *
  * step 0, the embeddings that are written out).  On a sharded plan every shard evaluates the top layer on the batch rows it owns.
  * One-layer plans run the full step. */
 int gss_plan_step_lazy(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream);
+/* Sharded plans, knob lazy_halo (default: graphs of >= 262,144 nodes): two hops fetch a SUBSET of their operand's boundary rows.
+ * (1) Lazy steps, the top layer's M: only the boundary rows that the batch rows of this shard reference (the receiver marks them over
+ * its halo slots and sends the bitmaps to the owners).  (2) Every step, u -- the operand of the top layer's second backward hop, zero
+ * outside the batch's neighbourhood --: only the rows that can be non-zero (the owners send them and the bitmap that says which).
+ * One device -> host round trip per such hop for the row counts.  Same bits as the full exchanges.  out6 reports what the LAST such
+ * exchanges moved: {rows fetched, rows sent, rows of the whole halo} for (1) and then for (2); fetched / sent are -1 when the plan
+ * exchanges whole halos. */
+int gss_plan_lazy_halo_rows(const gss_plan *p, int64_t *out6);
 /* layer activations for parity tests: which 0 AX, 1 AM, 2 P of layer `layer` (0-based) */
 const float *gss_plan_activation(const gss_plan *p, int layer, int which);
 size_t gss_plan_device_bytes(const gss_plan *p);
@@ -436,7 +444,8 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
  * (default 100000); round-3 experiments, all off by default: "gemm_prio", "wgrad_prio" (static wave priorities), "gemm_stagger" (late
  * start of the second generation of projection workgroups), "gemm_lds_kb" / "wgrad_lds_kb" / "loss_lds_kb" (occupancy by LDS
  * footprint), "wgrad_variant" = 1 (default) / 2 (operands through an LDS-DMA ring), "ppr_fused" = 1 (default) / 0 (separate update
- * pass of the diffusion profiles).  Every setting computes the same results (some in a different summation order); the defaults are
+ * pass of the diffusion profiles); "lazy_halo" = -1 (default: graphs of >= 262,144 nodes) / 0 / 1: sharded plans fetch subsets of the
+ * boundary rows where a hop reads a subset (gss_plan_lazy_halo_rows; every rank of a job must use the same value).  Every setting computes the same results (some in a different summation order); the defaults are
  * the measured optima recorded in DESIGN.md section 4.  The values are process-wide DEFAULTS: a plan (and a gss_ppr handle) takes a
  * snapshot when it is created and runs under it from then on, so changing a knob never re-shapes a live plan -- in particular not
  * the plans of other rank threads of the same process; per-op entry points read the current defaults. */

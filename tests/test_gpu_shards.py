@@ -449,3 +449,75 @@ def test_lazy_step_on_shards_equals_the_full_sharded_step(world, relabel):
         np.testing.assert_array_equal(a["emb"], b["emb"])
         for x, y in zip(a["params"], b["params"]):
             np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("world,case,relabel,split", [(2, "edge_n600_d128_L2", False, False), (3, "knn_n2000_d64_L3", True, True),
+                                                       (8, "knn_n200_d16_L2", False, False), (4, "knn_n2000_d64_L3", False, True)])
+def test_lazy_halo_fetches_only_what_the_batch_rows_read(world, case, relabel, split):
+    """Knob lazy_halo (automatic from 262,144 nodes; forced here): in a lazy step the top layer's `A_hat M` is evaluated on the batch
+    rows a shard owns, so of M's boundary rows only the columns of THOSE rows are fetched -- requests as bitmaps over the halo slots,
+    both sides listing the set bits in the same order, counts through one device -> host copy.  The unfetched boundary rows keep stale
+    values from earlier steps (the weights change every step, so a row wrongly left out would show).  Losses, parameters and
+    embeddings equal the plan that exchanges the whole halo bit for bit (same split, so the same summation order); the number of
+    rows fetched is exactly the number of distinct boundary columns of the owned batch rows, and what the ranks fetch in total is
+    what they send in total."""
+    import gcn_drug_repurposing_amd as pkg
+    from gcn_drug_repurposing_amd.dist import local_comms
+    from gcn_drug_repurposing_amd.shards import ScipySource, build_shard, shard_engine, shard_rows
+    from conftest import golden_params
+    lib = pkg.load()
+    g = load_golden(case)
+    n, d, L = (int(v) for v in g["meta"])
+    adj, X, p0 = golden_csr(g, "A"), g["X"], golden_params(g, "init")
+    rng = np.random.RandomState(11)
+    batches = [rng.choice(n, size=s, replace=False).astype(np.int32) for s in (min(n, 100), 3, 1, 48, min(n, 128), 17)]
+    kw = dict(num_layers=L, layer_decay=float(g["decay"]), alpha=float(g["alpha"]), lr=float(g["lr"]), max_batch=128)
+
+    def run(knob):
+        assert lib.gss_debug_set_option(b"lazy_halo", knob) == 0
+        try:
+            comms = local_comms(world)
+
+            def fn(rank):
+                shard = build_shard(ScipySource(adj), comms[rank], need_transpose=True, device="cuda:0", relabel=relabel, split=split)
+                eng = shard_engine(shard, shard_rows(shard, X), p0, comms[rank], **kw)
+                lo, hi = shard.part.rows(rank)
+                indptr, col = shard.a.h_indptr, shard.a.col.cpu().numpy()[:shard.a.nnz]
+                losses, moved, moved_u = [], [], []
+                for k, idx in enumerate(batches):
+                    (eng.step if k == 3 else eng.step_lazy)(torch.from_numpy(idx).cuda(), float(g["beta"]))   # one full step in between
+                    losses.append(eng.loss.item())
+                    fetched, sent, halo, u_fetched, u_sent, u_halo = eng.lazy_halo_rows()
+                    if knob == 0:
+                        assert (fetched, sent, u_fetched, u_sent) == (-1, -1, -1, -1)
+                    else:
+                        assert 0 <= u_fetched <= u_halo == shard.layout.halo_at.n_halo
+                        moved_u.append((u_fetched, u_sent))
+                    if knob == 1 and k != 3:
+                        rows = idx.astype(np.int64) if shard.node_map is None else shard.node_map.cpu().numpy().astype(np.int64)[idx]
+                        own = rows[(rows >= lo) & (rows < hi)] - lo
+                        cols = np.concatenate([col[indptr[r]:indptr[r + 1]] for r in own]) if len(own) else np.zeros(0, np.int64)
+                        assert fetched == len(np.unique(cols[cols >= hi - lo])) and fetched <= halo == shard.layout.halo_a.n_halo
+                        moved.append((fetched, sent))
+                eng.forward()
+                eng.check_guards()
+                return dict(losses=losses, moved=moved, moved_u=moved_u, emb=eng.gather_embeddings().cpu().numpy(),
+                            params=[t.cpu().numpy().copy() for t in eng.params], halo=shard.layout.halo_a.n_halo, halo_t=shard.layout.halo_at.n_halo)
+
+            return _threaded(world, fn, comms)
+        finally:
+            lib.gss_debug_set_option(b"lazy_halo", -1)
+
+    whole, needed = run(0), run(1)
+    for a, b in zip(whole, needed):
+        assert a["losses"] == b["losses"]
+        np.testing.assert_array_equal(a["emb"], b["emb"])
+        for x, y in zip(a["params"], b["params"]):
+            np.testing.assert_array_equal(x, y)
+    for k in range(len(needed[0]["moved"])):
+        assert sum(r["moved"][k][0] for r in needed) == sum(r["moved"][k][1] for r in needed)
+    for k in range(len(batches)):
+        assert sum(r["moved_u"][k][0] for r in needed) == sum(r["moved_u"][k][1] for r in needed)
+    # a batch of one or three rows reads a small part of the halo, and few rows of u are non-zero
+    assert sum(r["moved"][1][0] for r in needed) < sum(r["halo"] for r in needed)
+    assert sum(r["moved_u"][2][0] for r in needed) < sum(r["halo_t"] for r in needed)

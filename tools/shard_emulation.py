@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """A sharded job on a ONE-GPU box: `world` ranks as threads of this process (gss_comm_create_local), each building only its
 own rows of an RMAT graph (shards.RmatSource / build_shard) and running the native sharded plan.
-usage: shard_emulation.py <nodes> <edges> <world> [steps] [d] [split: auto | 0 | 1]
+usage: shard_emulation.py <nodes> <edges> <world> [steps] [d] [split: auto | 0 | 1] [lazy_halo: -1 | 0 | 1]
 Reports per rank: rows, stored entries, boundary rows per hop (halo) and their fraction of the other shards' rows, plan
 bytes; for the job: host peak RSS, setup time, ms/step (NOT a performance figure: the ranks share one GPU and the exchanges
-are host-synchronised copies), and the loss after the steps -- compare it with the world = 1 run of the same command."""
+are host-synchronised copies), and the loss after the steps -- compare it with the world = 1 run of the same command.  After the
+full steps the same number of LAZY steps (what train.py runs): their time and the boundary rows of the top layer's M each rank fetched in the
+last one, against the whole halo (knob lazy_halo, argument 7: 0 = always the whole halo)."""
 import json
 import os
 import resource
@@ -25,13 +27,15 @@ n, m, world = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 d = int(sys.argv[5]) if len(sys.argv) > 5 else 128
 split = {"auto": "auto", "0": False, "1": True}[sys.argv[6] if len(sys.argv) > 6 else "auto"]
+lazy_halo = int(sys.argv[7]) if len(sys.argv) > 7 else -1
+assert pkg.load().gss_debug_set_option(b"lazy_halo", lazy_halo) == 0
 L, B = 2, 2048
 np.random.seed(7)
 w = np.random.randn(d, d) * 1e-5
 np.fill_diagonal(w, 1.0)
 params = {"W1": w.astype(np.float32), "b1": np.zeros(d, np.float32), "W2": w.astype(np.float32).copy(), "b2": np.zeros(d, np.float32)}
 rng = np.random.RandomState(1234)
-batches = [rng.permutation(n)[:B].astype(np.int32) for _ in range(steps + 1)]
+batches = [rng.permutation(n)[:B].astype(np.int32) for _ in range(2 * steps + 1)]
 comms = local_comms(world)
 out, errors = [None] * world, []
 rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
@@ -54,6 +58,14 @@ def worker(rank):
             for k in range(1, steps + 1):
                 eng.step(idx[k], 0.25)
             torch.cuda.current_stream().synchronize()
+            t_full = (time.perf_counter() - t1) / steps * 1e3
+            loss_full = eng.loss.item()
+            t2 = time.perf_counter()
+            for k in range(steps + 1, 2 * steps + 1):
+                eng.step_lazy(idx[k], 0.25)
+            torch.cuda.current_stream().synchronize()
+            t_lazy = (time.perf_counter() - t2) / steps * 1e3
+            fetched, sent, _, u_fetched, u_sent, u_halo = eng.lazy_halo_rows()
             fa, ft = shard.layout.halo_fraction()
             out[rank] = dict(rank=rank, rows=hi - lo, nnz=shard.a.nnz, halo_rows_a=shard.layout.halo_a.n_halo, halo_rows_at=shard.layout.halo_at.n_halo,
                              halo_fraction_a=round(fa, 4), halo_fraction_at=round(ft, 4), send_rows_a=int(shard.layout.halo_a.send_off[-1]),
@@ -62,7 +74,13 @@ def worker(rank):
                              own_column_entries_at=(shard.split_at[0].nnz if shard.split_at else None),
                              exchanged_mb_per_hop_a=round(shard.layout.halo_a.n_halo * d * 4 / 2 ** 20, 1),
                              exchanged_mb_per_hop_at=round(shard.layout.halo_at.n_halo * d * 4 / 2 ** 20, 1),
-                             ms_per_step=round((time.perf_counter() - t1) / steps * 1e3, 2), loss=eng.loss.item(), relabelled=shard.relabel is not None)
+                             ms_per_step=round(t_full, 2), loss=loss_full, relabelled=shard.relabel is not None,
+                             lazy_ms_per_step=round(t_lazy, 2), lazy_loss=eng.loss.item(),
+                             lazy_top_m_rows_fetched=(fetched if fetched >= 0 else shard.layout.halo_a.n_halo),
+                             lazy_top_m_rows_sent=(sent if sent >= 0 else int(shard.layout.halo_a.send_off[-1])),
+                             lazy_top_m_mb_fetched=round((fetched if fetched >= 0 else shard.layout.halo_a.n_halo) * d * 4 / 2 ** 20, 2),
+                             u_rows_fetched=(u_fetched if u_fetched >= 0 else u_halo), u_rows_sent=(u_sent if u_sent >= 0 else int(shard.layout.halo_at.send_off[-1])),
+                             u_mb_fetched=round((u_fetched if u_fetched >= 0 else u_halo) * d * 4 / 2 ** 20, 2), lazy_halo=fetched >= 0)
     except Exception as e:  # noqa: BLE001
         import traceback
         errors.append((rank, repr(e), traceback.format_exc()))
@@ -78,5 +96,5 @@ if errors:
 peak = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
 res = dict(nodes=n, edges=m, world=world, d=d, steps=steps, host_peak_rss_gb=round(peak / 2 ** 20, 2), host_rss_before_gb=round(rss0 / 2 ** 20, 2),
            host_rss_per_rank_gb=round((peak - rss0) / 2 ** 20 / world, 2), gpu_peak_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), ranks=out)
-assert len({o["loss"] for o in out}) == 1, "the replicas disagree on the loss"
+assert len({o["loss"] for o in out}) == 1 and len({o["lazy_loss"] for o in out}) == 1, "the replicas disagree on the loss"
 print(json.dumps(res, indent=1))
