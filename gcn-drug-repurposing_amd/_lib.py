@@ -170,6 +170,16 @@ def load():
         fn.argtypes = args
     if lib.gss_abi_version() != ABI_VERSION:
         raise GssError(f"libgssgcn.so ABI {lib.gss_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+    # GSS_OPTIONS="name=value,name=value": tuning knobs (gss_debug_set_option) for entry points without a flag for them -- every rank of
+    # a torch.distributed job inherits the same environment, which is what the job-wide knobs (lazy_halo) need
+    for kv in filter(None, (t.strip() for t in os.environ.get("GSS_OPTIONS", "").split(","))):
+        name, _, val = kv.partition("=")
+        try:
+            rc = lib.gss_debug_set_option(name.strip().encode(), int(val))
+        except ValueError:
+            raise GssError(f"GSS_OPTIONS: {kv!r} is not name=integer") from None
+        if rc != 0:
+            raise GssError(f"GSS_OPTIONS: {kv!r}: {lib.gss_last_error().decode(errors='replace')}")
     _lib = lib
     return lib
 

@@ -361,9 +361,12 @@ def test_multi_process_trainer_on_one_gpu_host_staged_backend(tmp_path, ranks):
     emb_path.write_bytes(bytes(g["in_embs_txt"]))
     common = ["--emb-file", str(emb_path), "--num-layers", "2", "--hidden-units", "16", "--k", "5", "--epochs", "3", "--lr", "0.0003",
               "--beta-percentile", "98", "--batch-size", "64", "--seed", "7"]
+    env = _host_env()
+    if ranks == 3:      # the subset exchanges of knob lazy_halo (bitmap requests, per-step counts) across processes as well
+        env["GSS_OPTIONS"] = "lazy_halo=1"
     multi = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
                             "--master-port", str(_free_port()), os.path.join(root, "train.py")] + common
-                           + ["--ngpus", str(ranks), "--out", str(tmp_path / "multi.txt")], capture_output=True, text=True, env=_host_env(), timeout=900)
+                           + ["--ngpus", str(ranks), "--out", str(tmp_path / "multi.txt")], capture_output=True, text=True, env=env, timeout=900)
     assert multi.returncode == 0, multi.stderr[-3000:]
     one = subprocess.run([sys.executable, os.path.join(root, "train.py")] + common + ["--out", str(tmp_path / "one.txt")],
                          capture_output=True, text=True, timeout=900)

@@ -255,3 +255,17 @@ def test_native_embs_reader_rejects_non_finite_and_glued_tokens(tmp_path):
         assert (rc == 0) == ok, body
         if rc == 0:
             lib.gss_embs_close(h)
+
+
+def test_gss_options_environment_is_checked(tmp_path):
+    """GSS_OPTIONS=name=value,... is applied when the library is loaded; a bad entry is an error, not ignored"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import gcn_drug_repurposing_amd as p; p.load(); print('ok')"
+    ok = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, GSS_OPTIONS="lazy_halo=1, spmm_slices=2"), capture_output=True, text=True)
+    assert ok.returncode == 0 and "ok" in ok.stdout, ok.stderr[-2000:]
+    for bad in ("lazy_halo=7", "no_such_knob=1", "lazy_halo"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, GSS_OPTIONS=bad), capture_output=True, text=True)
+        assert r.returncode != 0 and "GSS_OPTIONS" in r.stderr, (bad, r.stderr[-500:])
