@@ -599,6 +599,13 @@ def main():
                        "note": "comm class = pack kernels + the grouped ncclSend/ncclRecv of every halo hop + the three all-reduces of a step "
                                "(batch rows, their input gradients, the four weight gradients), event-bracketed on each rank's stream: it "
                                "includes the wait for the slowest peer"}
+        lh = engine.lazy_halo_rows()
+        if lh[3] >= 0:
+            # knob lazy_halo (automatic from 262,144 nodes): the backward hop A_hat^T u fetched only the rows of u that can be non-zero
+            rows = all_ranks([lh[3], lh[5]])
+            out["xgmi"]["subset_exchange_u"] = {"rows_fetched_last_step_by_rank": rows[:, 0].astype(int).tolist(),
+                                                "rows_of_the_whole_halo_by_rank": rows[:, 1].astype(int).tolist(),
+                                                "note": "ideal_exchange_us_per_step above is priced on whole halos"}
         fa, ft = shard.layout.halo_fraction()
         halo_info.update({"halo_fraction_a": fa, "halo_fraction_at": ft})
     if halo_info is not None:

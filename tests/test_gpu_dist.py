@@ -386,10 +386,12 @@ def test_multi_process_bench_on_one_gpu_host_staged_backend():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--spinup-time", "0",
-                        "--min-time", "0"], capture_output=True, text=True, env=_host_env(), timeout=900)
+                        "--min-time", "0"], capture_output=True, text=True, env=dict(_host_env(), GSS_OPTIONS="lazy_halo=1"), timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["rehearsal"] is True
+    sub = line["xgmi"]["subset_exchange_u"]        # the knob reached both processes: the backward hop fetched a subset of u's halo
+    assert all(0 < f <= h for f, h in zip(sub["rows_fetched_last_step_by_rank"], sub["rows_of_the_whole_halo_by_rank"]))
     assert "REHEARSAL" in line["config"]["parallelism"]
     for key in ("roofline", "xgmi", "per_rank", "comm_share", "kernel_ms_per_step", "value_executed"):
         assert key in line, key
@@ -399,6 +401,25 @@ def test_multi_process_bench_on_one_gpu_host_staged_backend():
     assert ref.returncode == 0, ref.stderr[-3000:]
     one = json.loads([l for l in ref.stdout.splitlines() if l.startswith("{")][-1])
     assert abs(line["config"]["final_loss"] - one["config"]["final_loss"]) <= T.SPREAD_LOSS_REL * 10 * abs(one["config"]["final_loss"])
+
+
+def test_multi_process_job_with_a_dying_rank_ends_instead_of_hanging():
+    """Three ranks as processes (host-staged backend); rank 1 disappears in the middle of training (tests/mp_fail_job.py).  The survivors'
+    next collective must fail -- the transport reports the dead peer, the communicator turns it into GSS_ECOMM, the caller exits -- and
+    the job ends with a non-zero code well inside the deadline instead of hanging."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "tests", "mp_fail_job.py")],
+                       capture_output=True, text=True, env=_host_env(), timeout=600)
+    took = time.time() - t0
+    assert r.returncode != 0, "a job that lost a rank reported success"
+    assert "step 2" in r.stdout and "step 5" not in r.stdout, r.stdout[-2000:]
+    assert took < 300, f"the job took {took:.0f} s to notice a dead rank"
 
 
 def test_host_staged_backend_collectives_single_rank():
