@@ -234,7 +234,8 @@ void carve(gss_plan *p, Carver &c) {
   const bool bitmaps = L > 1 && (p->rows_t >= (size_t)K().sparse_bits_rows || p->lzt.on);
   p->posbits = bitmaps ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;
   p->nzbits = bitmaps ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;
-  p->needbits = (bitmaps && !sharded) ? c.take<uint32_t>(n1 / 32 + 1) : nullptr;
+  // (a shard needs the peers' requests to know which of its rows anything reads: with the lazy halo only)
+  p->needbits = (bitmaps && (!sharded || p->lz.on)) ? c.take<uint32_t>((p->rows_a ? p->rows_a : 1) / 32 + 1) : nullptr;
   p->w1t = c.take<float>((size_t)D.d * D.d);
   p->w2t = c.take<float>((size_t)D.d * D.d);
   const size_t cnt[4] = {(size_t)D.d * D.d, (size_t)D.d, (size_t)D.d * D.d, (size_t)D.d};
@@ -514,10 +515,11 @@ int plan_halo(gss_plan *p, const gss_plan::Halo &h, float *op, void *stream) {
 // The bitmaps are word-aligned per peer, their sizes host constants; both sides list the set bits in the same order; the per-peer row counts
 // of the step come back to the host once (ncclSend / ncclRecv take host-side counts).  Boundary rows that are not fetched keep whatever
 // they held: nothing reads them.
-int plan_halo_subset(gss_plan *p, gss_plan::LazyHalo &z, const gss_plan::Halo &h, const gss_csr *a, float *op, const int32_t *need_rows, int32_t b,
-                     uint32_t *src_bits, void *stream) {
+// Request phase: who needs what.  Afterwards z.send_list / z.recv_list and the host-side counts z.h_cnt describe the transfer.
+int plan_halo_requests(gss_plan *p, gss_plan::LazyHalo &z, const gss_plan::Halo &h, const gss_csr *a, const int32_t *need_rows, int32_t b,
+                       const uint32_t *src_bits, void *stream) {
   PROF(GSS_PROF_COMM);
-  const int P = p->P, d = p->desc.d, n = p->desc.n;
+  const int P = p->P, n = p->desc.n;
   const size_t P1 = (size_t)P + 1;
   hipStream_t st = as_stream(stream);
   const int64_t *d_recv_off = z.d_meta, *d_wrecv_off = z.d_meta + P1, *d_send_off = z.d_meta + 2 * P1, *d_wsend_off = z.d_meta + 3 * P1;
@@ -545,12 +547,21 @@ int plan_halo_subset(gss_plan *p, gss_plan::LazyHalo &z, const gss_plan::Halo &h
               (long long)h.n_halo);
   z.last_send = send_off[P];
   z.last_recv = recv_off[P];
+  return GSS_OK;
+}
+
+// Transfer phase: the listed rows of `op` to the peers, theirs into the listed boundary rows.  set_bits (sender-driven form): the
+// boundary rows' bits become exactly the rows that arrive.
+int plan_halo_transfer(gss_plan *p, gss_plan::LazyHalo &z, const gss_plan::Halo &h, float *op, uint32_t *set_bits, void *stream) {
+  PROF(GSS_PROF_COMM);
+  const int P = p->P, d = p->desc.d, n = p->desc.n;
+  const int64_t *send_off = z.h_cnt, *recv_off = z.h_cnt + (size_t)P + 1;
   if (int rc = pack_rows(d, op, z.send_list, send_off[P], p->sendbuf, stream)) return rc;
-  if (int rc = p->comm->exchange_rows(p->sendbuf, send_off, z.recvbuf, recv_off, d, st)) return rc;
-  if (src_bits) {
-    // the boundary rows' bits: exactly the rows that arrive (atomics: the word that straddles the own rows is shared with them)
-    if (int rc = bits_clear(src_bits, n, n + h.n_halo, stream)) return rc;
-    if (int rc = bits_set_list(src_bits, z.recv_list, recv_off[P], stream)) return rc;
+  if (int rc = p->comm->exchange_rows(p->sendbuf, send_off, z.recvbuf, recv_off, d, as_stream(stream))) return rc;
+  if (set_bits) {
+    // (atomics: the word that straddles the own rows is shared with them)
+    if (int rc = bits_clear(set_bits, n, n + h.n_halo, stream)) return rc;
+    if (int rc = bits_set_list(set_bits, z.recv_list, recv_off[P], stream)) return rc;
   }
   return unpack_rows(d, z.recvbuf, z.recv_list, recv_off[P], op, stream);
 }
@@ -562,10 +573,15 @@ int plan_halo_subset(gss_plan *p, gss_plan::LazyHalo &z, const gss_plan::Halo &h
 template <typename Full, typename Own, typename Rest>
 int plan_hop(gss_plan *p, const gss_plan::Halo &h, bool overlapped, float *op, void *stream, Full full, Own own, Rest rest,
              const int32_t *need_rows = nullptr, int32_t need_b = 0, uint32_t *src_bits = nullptr) {
-  // need_rows / src_bits: a subset of the boundary rows (plan_halo_subset); h is halo_a with need_rows, halo_t with src_bits
+  // need_rows / src_bits: a subset of the boundary rows; h is halo_a with need_rows (whose request phase the caller has run: the
+  // top layer's needed-row bitmap comes out of it), halo_t with src_bits
+  (void)need_b;
   auto exchange = [&](void *st) {
-    if (need_rows) return plan_halo_subset(p, p->lz, h, p->a, op, need_rows, need_b, nullptr, st);
-    if (src_bits) return plan_halo_subset(p, p->lzt, h, p->at, op, nullptr, 0, src_bits, st);
+    if (need_rows) return plan_halo_transfer(p, p->lz, h, op, nullptr, st);
+    if (src_bits) {
+      if (int rc = plan_halo_requests(p, p->lzt, h, p->at, nullptr, 0, src_bits, st)) return rc;
+      return plan_halo_transfer(p, p->lzt, h, op, src_bits, st);
+    }
     return plan_halo(p, h, op, st);
   };
   if (p->P == 1 || !overlapped) {
@@ -656,15 +672,20 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
       // (the SpMM is executed), the boundary rows are exchanged once
       float *m = l == 0 ? p->m0op : p->m_tmp;
       const bool lazy_l = lazy_rows && l == L - 1;
+      const bool needed_only = lazy_l && p->P > 1 && p->lz.on;   // sharded: A_hat M fetches only the boundary rows of M its rows read
+      if (needed_only)   // who reads which of M's rows: the peers' requests also say which of THIS shard's rows anything reads
+        if (int rc = plan_halo_requests(p, p->lz, p->halo_a, p->a, lazy_rows, lazy_b, nullptr, stream)) return rc;
       if (lazy_l && p->needbits) {
         // huge graphs: AX and M of the top layer on the batch rows and their neighbours only (what A_hat M on the batch rows, the
-        // batch-row weight gradient and the backward hop's epilogue read)
+        // batch-row weight gradient and the backward hop's epilogue read); a shard adds the rows its peers' batch rows reference
         PROF(GSS_PROF_ELEMENTWISE);
-        GSS_HIP(hipMemsetAsync(p->needbits, 0, sizeof(uint32_t) * (((size_t)D.n + 31) / 32), as_stream(stream)));
+        GSS_HIP(hipMemsetAsync(p->needbits, 0, sizeof(uint32_t) * (p->rows_a / 32 + 1), as_stream(stream)));
         if (int rc = mark_rows_and_neighbours(p->a, lazy_rows, lazy_b, p->needbits, stream)) return rc;
+        if (needed_only)
+          if (int rc = bits_set_list(p->needbits, p->lz.send_list, p->lz.h_cnt[p->P], stream)) return rc;
       }
       {
-        const uint32_t *rbits = (lazy_l && p->needbits) ? p->needbits : nullptr;   // (single-shard plans only: never with a split matrix)
+        const uint32_t *rbits = (lazy_l && p->needbits) ? p->needbits : nullptr;
         auto full = [&]() {
           PROF(GSS_PROF_SPMM_FWD_HAD);
           return spmm_fwd(p->a, D.d, xl, p->ax[l], xl, m, stream, nullptr, rbits);
@@ -674,11 +695,11 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
         } else {
           auto own = [&]() {
             PROF(GSS_PROF_SPMM_FWD_HAD);
-            return spmm_fwd(p->a_own, D.d, xl, p->ax[l], nullptr, nullptr, stream);
+            return spmm_fwd(p->a_own, D.d, xl, p->ax[l], nullptr, nullptr, stream, nullptr, rbits);
           };
           auto rest = [&]() {
             PROF(GSS_PROF_SPMM_FWD_HAD);
-            return spmm_fwd(p->a_halo, D.d, xl, p->ax[l], xl, m, stream, nullptr, nullptr, p->ax[l]);
+            return spmm_fwd(p->a_halo, D.d, xl, p->ax[l], xl, m, stream, nullptr, rbits, p->ax[l]);
           };
           if (int rc = plan_hop(p, p->halo_a, split_a, xl, stream, full, own, rest)) return rc;
         }
@@ -701,7 +722,6 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
             PROF(GSS_PROF_SPMM_FWD);
             return spmm_fwd(p->a_halo, D.d, m, p->am[l], nullptr, nullptr, stream, rpos, nullptr, p->am[l]);
           };
-          const bool needed_only = lazy_l && p->lz.on;      // the batch rows' columns are all of M's boundary rows this hop reads
           if (int rc = plan_hop(p, p->halo_a, split_a, m, stream, full, own, rest, needed_only ? lazy_rows : nullptr, lazy_b)) return rc;
           if (l == 0) p->m0_ready = true;
         }

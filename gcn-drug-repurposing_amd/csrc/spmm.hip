@@ -47,6 +47,8 @@ struct SpmmEpi {
                            // May alias an output (every element is read, then written, by the same lane)
   const uint32_t *gather_bits;  // SPMM_PLAIN, optional: bit c clear => row c of the operand is all zeros, the neighbour is skipped (the
                                 // first pass of a two-pass SPMM_BWD2S, whose second pass carries the same bitmap as posbits)
+  const uint32_t *rowbits;      // SPMM_PLAIN, optional: only rows whose bit is set are computed (the first pass of a two-pass SPMM_FWD1
+                                // under a row bitmap, whose second pass carries the same bitmap as posbits)
 };
 
 struct CsrView {
@@ -297,6 +299,10 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   // SPMM_FWD1 with a row bitmap (ep.posbits): the same for AX / M -- gss_plan_step_lazy on huge graphs needs them on the batch rows
   // and their neighbours only
   if (MODE == SPMM_FWD1 && ep.posbits && row >= 0 && !((ep.posbits[(unsigned)row >> 5] >> (row & 31)) & 1u)) {
+    row = -1;
+    e1 = e0;
+  }
+  if (MODE == SPMM_PLAIN && ep.rowbits && row >= 0 && !((ep.rowbits[(unsigned)row >> 5] >> (row & 31)) & 1u)) {
     row = -1;
     e1 = e0;
   }
@@ -637,7 +643,7 @@ int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float 
              const uint32_t *row_bits, const float *y_in, const uint32_t *gather_bits) {
   GSS_REQUIRE(y, "spmm: y is null");
   GSS_REQUIRE(!row_pos || (!m && K().spmm_variant == 2), "spmm: a row map goes with the plain product of the balanced SpMM only");
-  GSS_REQUIRE(!row_bits || (m && K().spmm_variant == 2), "spmm: a row bitmap goes with the Hadamard-fused product of the balanced SpMM only");
+  GSS_REQUIRE(!row_bits || K().spmm_variant == 2, "spmm: a row bitmap needs the balanced SpMM (spmm_variant 2)");
   GSS_REQUIRE((!y_in && !gather_bits) || K().spmm_variant == 2, "spmm: a two-pass product needs the balanced SpMM (spmm_variant 2)");
   GSS_REQUIRE(!gather_bits || !m, "spmm: a gather filter goes with the plain product only");
   if (m) {
@@ -649,6 +655,7 @@ int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float 
   SpmmEpi ep{nullptr, nullptr, nullptr, y, nullptr, 0.f, row_pos, nullptr, nullptr};
   ep.y_in = y_in;
   ep.gather_bits = gather_bits;
+  ep.rowbits = row_bits;
   return launch_spmm<SPMM_PLAIN>(a, d, x, ep, stream);
 }
 

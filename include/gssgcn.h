@@ -435,8 +435,7 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
  * 2 (nnz-balanced segments, default); "spmm_slices" = 0 (automatic, default) or 1..8 time-separated feature
  * slices in the balanced SpMM; "spmm_seg_edges" = entries per SpMM segment (default 32; applies to gss_csr handles
  * created afterwards); "gemm_variant" = 1 (operand fragments from L1/L2), 2 (LDS-DMA staged, node tile
- * chosen by width; default), 3 / 4 (LDS-DMA staged, 128- / 64-node tiles forced); "spmm_pin" = 0 / 1 (default): feature slices
- * pinned to XCDs; "spmm_fly" = 4 (default) / 8 row gathers in flight per lane group; "spmm_hot_rows" = -1 (default: what
+ * chosen by width; default), 3 / 4 (LDS-DMA staged, 128- / 64-node tiles forced); "spmm_pin" = with a manual "spmm_slices": slices time-separated (0, default) or pinned to XCDs (1); the automatic policy pins operands of <= 64 MB; "spmm_fly" = 4 (default) / 8 row gathers in flight per lane group; "spmm_hot_rows" = -1 (default: what
  * gss_csr_set_hot declared) or a row count; "gemm_small_nt", "gemm_nt_cap" = narrowest / widest feature tile of the projections in
  * 16-feature units (0 = automatic); "xcd_remap" = 0 / 1 (default): workgroups that read the same rows share an XCD (dense kernels);
  * "wgrad_wgs", "loss_wgs" = workgroups of a full-size weight-gradient launch / the loss sweep (default 256 = one per CU; set
