@@ -166,3 +166,56 @@ def test_halo_layout_reproduces_the_global_product():
     # the hub's shard reads every node; shards that share no edge exchange nothing
     hub_rank = int(part.owner(np.array([5]))[0])
     assert halos[hub_rank].n_halo == n - halos[hub_rank].nl
+
+
+def _host_transport_worker(rank, world, port):
+    """the transport callback dist.host_comm hands to gss_comm_create_host, called directly on host buffers (no GPU: the C side only
+    stages device memory through such buffers)"""
+    import ctypes as C
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gcn_drug_repurposing_amd.dist import host_comm
+        comm = host_comm()
+        assert (comm.world, comm.rank) == (world, rank)
+        cb = comm._keep
+        i64 = C.POINTER(C.c_int64)
+        # kind 0: all-gather of `count` bytes
+        count = 37
+        send = (C.c_uint8 * count)(*[(rank * 50 + k) % 251 for k in range(count)])
+        recv = (C.c_uint8 * (count * world))()
+        assert cb(None, 0, C.addressof(send), i64(), C.addressof(recv), i64(), count) == 0
+        got = np.frombuffer(recv, dtype=np.uint8).reshape(world, count)
+        for r in range(world):
+            np.testing.assert_array_equal(got[r], [(r * 50 + k) % 251 for k in range(count)])
+        assert cb(None, 0, C.addressof(send), i64(), C.addressof(recv), i64(), 0) == 0          # nothing to move
+        # kind 1: all-to-all-v with byte offsets; rank r sends 3 * (r + q + 1) bytes to q != r, nothing to itself; an empty pair as well
+        def n_bytes(src, dst):
+            return 0 if src == dst or (src, dst) == (0, world - 1) else 3 * (src + dst + 1)
+        soff = np.zeros(world + 1, np.int64)
+        roff = np.zeros(world + 1, np.int64)
+        for q in range(world):
+            soff[q + 1] = soff[q] + n_bytes(rank, q)
+            roff[q + 1] = roff[q] + n_bytes(q, rank)
+        sbuf = np.zeros(max(int(soff[-1]), 1), np.uint8)
+        for q in range(world):
+            sbuf[soff[q]:soff[q + 1]] = (100 * rank + 10 * q + np.arange(n_bytes(rank, q))) % 256
+        rbuf = np.full(max(int(roff[-1]), 1), 255, np.uint8)
+        assert cb(None, 1, sbuf.ctypes.data, soff.ctypes.data_as(i64), rbuf.ctypes.data, roff.ctypes.data_as(i64), 0) == 0
+        for q in range(world):
+            np.testing.assert_array_equal(rbuf[roff[q]:roff[q + 1]], (100 * q + 10 * rank + np.arange(n_bytes(q, rank))) % 256)
+        assert cb(None, 9, sbuf.ctypes.data, soff.ctypes.data_as(i64), rbuf.ctypes.data, roff.ctypes.data_as(i64), 0) != 0   # unknown kind
+        assert comm.count() == world
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_host_staged_transport_callback_over_gloo(world):
+    """GSS_COMM_BACKEND=host (include/gssgcn.h gss_comm_create_host): the byte transport underneath the host-staged communicator, as
+    separate processes on CPU -- all-gather and all-to-all-v land every rank's bytes where the C side expects them"""
+    import torch.multiprocessing as mp
+    mp.spawn(_host_transport_worker, args=(world, _free_port()), nprocs=world, join=True)
