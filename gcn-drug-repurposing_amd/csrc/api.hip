@@ -110,6 +110,10 @@ int gss_debug_set_option(const char *name, int value) {
     g_knobs.gemm_stagger = value;
     return GSS_OK;
   }
+  if (strcmp(name, "gemm_rows_split") == 0) {
+    g_knobs.gemm_rows_split = value ? 1 : 0;
+    return GSS_OK;
+  }
   if (strcmp(name, "lazy_halo") == 0) {
     GSS_REQUIRE(value >= -1 && value <= 1, "lazy_halo must be -1 (by graph size), 0 or 1");
     g_knobs.lazy_halo = value;   // sharded plans created afterwards; every rank of a job must use the same value

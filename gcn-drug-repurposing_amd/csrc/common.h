@@ -26,6 +26,7 @@ struct Knobs {
   int gemm_variant = 2;      // 1 = L1/L2-fed GEMM, 2 = LDS-DMA staged (default), 3 / 4 = forced 128- / 64-node tiles
   int gemm_nt_cap = 0;       // cap of the feature tile width (16-feature units), 0 = none
   int gemm_small_nt = 2;     // narrowest feature tile for small problems, 0 = never narrow
+  int gemm_rows_split = 1;   // forward projection over a short row list: 4 waves per 16 listed rows that split the features (0 = one wave per tile)
   int gemm_prio = 0;         // static wave priority experiment of the projection (0 = off; see dense.hip)
   int gemm_stagger = 0;      // second-generation projection workgroups start this many x 512 cycles late (0 = off)
   int wgrad_prio = 0;        // the same for the weight gradient

@@ -397,6 +397,94 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
   }
 }
 
+// Forward projection over a SHORT ROW LIST (gss_plan_step_lazy: the top layer on the batch rows, 2048 of them): 16 listed rows per
+// workgroup, whose 4 waves split the FEATURES (16 NTW each) instead of the nodes.  The one-wave form of gemm_nt_lds_kernel gives such a
+// tile to a single wave -- 512 dependent-latency MFMAs, 16 us for 134 MFLOP at B = 2048, d = 128 --; here every wave issues a quarter
+// of them on its own SIMD.  Every output element accumulates its K steps in the same order as in gemm_nt_lds_kernel (chunk by chunk,
+// e = 0..3 inside), and the epilogue is the SAME code run by wave 0 on all 4 NTW accumulator blocks of a row (handed over through LDS
+// in the register layout the whole-row kernel has): results are bit-identical to the full pass, which the lazy step's contract needs.
+template <int NTW, int EPI>
+__global__ __launch_bounds__(256) void gemm_rows_split_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = 4 * NTW;              // feature blocks of a whole row (J = 16 NT)
+  constexpr int XT = 16 * 16;              // floats of the X chunk tile (16 nodes x 16 k)
+  constexpr int BUF = XT + NT * 256;       // floats per ring buffer
+  constexpr int G = 1 + NTW;               // DMA instructions per wave and chunk: the X block (every wave, same bytes) + its W blocks
+  constexpr int NBUF = 4, PF = 3;
+  float *lds = reinterpret_cast<float *>(smem);
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int node_base = (int)blockIdx.x * 16;
+  const float *xsrc[2];
+  const float *wsrc[2][NTW];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    const float *in = kh ? g.in1 : g.in0;
+    const int ld = kh ? g.ld_in1 : g.ld_in0;
+    int node = min(g.n - 1, node_base + r);
+    node = max(g.rows[node], 0);            // a skipped entry (< 0) stages row 0; fwd_epilogue drops the result
+    xsrc[kh] = in + (size_t)node * ld + 4 * q;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) wsrc[kh][i] = g.w[0][kh] + (size_t)(16 * (NTW * w + i) + r) * g.ld_w + 4 * q;
+  }
+  const int nchunk = g.K / 16;
+  const int csplit = g.ksplit / 16;
+  auto stage = [&](int ci) {
+    const int kh = ci >= csplit ? 1 : 0;
+    const int off = (ci - (kh ? csplit : 0)) * 16;
+    const unsigned buf = lds_base + (unsigned)((ci % NBUF) * BUF) * 4u;
+    glds16(xsrc[kh] + off, buf);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) glds16(wsrc[kh][i] + off, buf + (unsigned)(XT * 4 + (NTW * w + i) * 1024));
+  };
+  f32x4 acc[NTW];
+#pragma unroll
+  for (int u = 0; u < NTW; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < PF && c < nchunk; ++c) stage(c);
+  for (int ci = 0; ci < nchunk; ++ci) {
+    const int younger = min(PF - 1, nchunk - 1 - ci);
+    if (younger >= 2)
+      wait_vmcnt<2 * G>();
+    else if (younger == 1)
+      wait_vmcnt<G>();
+    else
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    const float *cur = lds + (ci % NBUF) * BUF;
+    const float4 b = *reinterpret_cast<const float4 *>(cur + lane * 4);
+    float4 a[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) a[u] = *reinterpret_cast<const float4 *>(cur + XT + (NTW * w + u) * 256 + lane * 4);
+    if (ci + PF < nchunk) stage(ci + PF);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float bv = e == 0 ? b.x : e == 1 ? b.y : e == 2 ? b.z : b.w;
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) {
+        const float av = e == 0 ? a[u].x : e == 1 ? a[u].y : e == 2 ? a[u].z : a[u].w;
+        acc[u] = mfma16(av, bv, acc[u]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // hand the accumulator blocks to wave 0 in the whole-row kernel's layout: block u of the row, lane (r, q)
+  __builtin_amdgcn_s_barrier();            // every wave is done with the ring: reuse its first bytes
+  float4 *dump = reinterpret_cast<float4 *>(smem);
+#pragma unroll
+  for (int u = 0; u < NTW; ++u) dump[(NTW * w + u) * 64 + lane] = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+  __syncthreads();
+  if (w != 0) return;
+  f32x4 row[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const float4 v = dump[u * 64 + lane];
+    row[u] = (f32x4){v.x, v.y, v.z, v.w};
+  }
+  fwd_epilogue<NT, EPI>(g, row, node_base + r, 0, q);
+}
+
 // Measured dead end, for the record: a weights-resident variant for d <= 128 ([W1|W2] = 128 KB DMA'd into LDS once per
 // workgroup, 8 independent waves per CU, each holding its 16-node [AX|AM] block in registers, fragment reads one chunk
 // ahead, no barrier in the loop): 32.9 us vs 31.4 us at N = 29,960, 202 vs 210 us at N = 240k.  Per-wave timestamps
@@ -439,7 +527,20 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
     // the grid is many waves of workgroups deep (d = 128: N = 1M 791 -> 753 us, N = 4M 3061 -> 2913 us with 128-node tiles)
     const int mt = K().gemm_variant == 3 ? 2 : K().gemm_variant == 4 ? 1 : ((d >= 256 || g.n >= 262144) ? 2 : 1);
     if (EPI != EPI_SPLIT && g.rows && (int64_t)ceil_div(g.n, 64) * (g.J / (16 * nt)) < 256) {
-      // forward over a short row list: 16-node workgroups of one wave (see the kernel)
+      // forward over a short row list: 16 listed rows per workgroup.  Whole rows of 64 / 128 / 256 features: 4 waves that split the
+      // features (gemm_rows_split_kernel, same bits); other widths: one wave per 16 x 16 nt tile
+      if (EPI != EPI_SPLIT && g.J == d && g.jsplit == d && (d == 64 || d == 128 || d == 256) && K().gemm_rows_split) {
+        dim3 gridr(ceil_div(g.n, 16));
+        const size_t ldsr = 4 * (size_t)(16 * 16 + d * 16) * sizeof(float);
+        if (d == 64)
+          hipLaunchKernelGGL((gemm_rows_split_kernel<1, EPI == EPI_SPLIT ? EPI_FWD : EPI>), gridr, dim3(256), ldsr, st, g);
+        else if (d == 128)
+          hipLaunchKernelGGL((gemm_rows_split_kernel<2, EPI == EPI_SPLIT ? EPI_FWD : EPI>), gridr, dim3(256), ldsr, st, g);
+        else
+          hipLaunchKernelGGL((gemm_rows_split_kernel<4, EPI == EPI_SPLIT ? EPI_FWD : EPI>), gridr, dim3(256), ldsr, st, g);
+        GSS_LAUNCH_CHECK("gemm_rows_split_kernel");
+        return GSS_OK;
+      }
       dim3 grid1(ceil_div(g.n, 16), g.J / (16 * nt));
       const size_t lds1 = 4 * (size_t)(16 * 16 + 16 * nt * 16) * sizeof(float);
       switch (nt) {

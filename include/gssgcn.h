@@ -443,7 +443,8 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
  * (default 100000); round-3 experiments, all off by default: "gemm_prio", "wgrad_prio" (static wave priorities), "gemm_stagger" (late
  * start of the second generation of projection workgroups), "gemm_lds_kb" / "wgrad_lds_kb" / "loss_lds_kb" (occupancy by LDS
  * footprint), "wgrad_variant" = 1 (default) / 2 (operands through an LDS-DMA ring), "ppr_fused" = 1 (default) / 0 (separate update
- * pass of the diffusion profiles); "lazy_halo" = -1 (default: graphs of >= 262,144 nodes) / 0 / 1: sharded plans fetch subsets of the
+ * pass of the diffusion profiles); "gemm_rows_split" = 1 (default) / 0: the forward projection over a short row list (lazy step)
+ * by four waves per 16 rows that split the features / by one wave; "lazy_halo" = -1 (default: graphs of >= 262,144 nodes) / 0 / 1: sharded plans fetch subsets of the
  * boundary rows where a hop reads a subset (gss_plan_lazy_halo_rows; every rank of a job must use the same value).  Every setting computes the same results (some in a different summation order); the defaults are
  * the measured optima recorded in DESIGN.md section 4.  The values are process-wide DEFAULTS: a plan (and a gss_ppr handle) takes a
  * snapshot when it is created and runs under it from then on, so changing a knob never re-shapes a live plan -- in particular not
