@@ -521,3 +521,53 @@ def test_lazy_halo_fetches_only_what_the_batch_rows_read(world, case, relabel, s
     # a batch of one or three rows reads a small part of the halo, and few rows of u are non-zero
     assert sum(r["moved"][1][0] for r in needed) < sum(r["halo"] for r in needed)
     assert sum(r["moved_u"][2][0] for r in needed) < sum(r["halo_t"] for r in needed)
+
+
+def test_subset_exchanges_at_a_halo_of_several_compaction_trips():
+    """RMAT 600k nodes / 6M edges on two ranks: the request bitmaps are several thousand words long, so the workgroup that lists their set
+    bits (bits_compact_kernel) makes several trips of 1024 words with its running total carried across them and across the peers' ranges.
+    Lazy and full steps with the subset exchanges forced on equal the whole-halo plan's bit for bit."""
+    import gcn_drug_repurposing_amd as pkg
+    from gcn_drug_repurposing_amd.dist import local_comms
+    from gcn_drug_repurposing_amd.shards import RmatSource, build_shard, gaussian_rows, shard_engine
+    lib = pkg.load()
+    n, m, d, L, B, world = 600000, 6000000, 32, 2, 1024, 2
+    np.random.seed(3)
+    p = O.init_layer_weights(d, 1e-2)
+    rng = np.random.RandomState(2)
+    batches = [rng.permutation(n)[:B].astype(np.int32) for _ in range(3)]
+
+    def run(knob):
+        assert lib.gss_debug_set_option(b"lazy_halo", knob) == 0
+        try:
+            comms = local_comms(world)
+
+            def fn(rank):
+                shard = build_shard(RmatSource(n, m, seed=4, device="cuda:0"), comms[rank], need_transpose=True, device="cuda:0", split=False)
+                lo, hi = shard.part.rows(rank)
+                eng = shard_engine(shard, gaussian_rows(lo, hi, d, 5), p, comms[rank], num_layers=L, layer_decay=0.3, alpha=1.0, lr=1e-3, max_batch=B)
+                losses, moved = [], []
+                for k, idx in enumerate(batches):
+                    (eng.step if k == 1 else eng.step_lazy)(torch.from_numpy(idx).cuda(), 0.25)
+                    losses.append(eng.loss.item())
+                    moved.append(eng.lazy_halo_rows())
+                eng.check_guards()
+                sel = torch.from_numpy(np.arange(0, hi - lo, max(1, (hi - lo) // 5000))).cuda()
+                return dict(losses=losses, moved=moved, emb=eng.emb.index_select(0, sel).cpu().numpy(), params=[t.cpu().numpy().copy() for t in eng.params],
+                            slots=(int(shard.layout.halo_a.send_off[-1]), shard.layout.halo_a.n_halo))
+
+            return _threaded(world, fn, comms)
+        finally:
+            lib.gss_debug_set_option(b"lazy_halo", -1)
+
+    whole, needed = run(0), run(1)
+    assert max(max(r["slots"]) for r in needed) > 32 * 4096, "the halo is too small for several compaction trips"
+    for a, b in zip(whole, needed):
+        assert a["losses"] == b["losses"]
+        np.testing.assert_array_equal(a["emb"], b["emb"])
+        for x, y in zip(a["params"], b["params"]):
+            np.testing.assert_array_equal(x, y)
+    for k in range(3):
+        assert sum(r["moved"][k][3] for r in needed) == sum(r["moved"][k][4] for r in needed) > 0
+        if k != 1:
+            assert sum(r["moved"][k][0] for r in needed) == sum(r["moved"][k][1] for r in needed) > 0
