@@ -35,8 +35,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_FILE = "r03_spmm_pmc.json"
-PMC_FALLBACK = "r02_spmm_pmc.json"
+PMC_FILE = "r04_spmm_pmc.json"
+PMC_FALLBACK = "r03_spmm_pmc.json"
+PMC_FILE_RMAT10M = "r04_spmm_pmc_rmat10m.json"
 MFMA_F32_PEAK_TFLOPS = 157.3
 XGMI_LINK_GBS = 153.0        # one xGMI link, one direction (7 links per GPU, one per peer in an 8-GPU node)
 COLLECTIVE_TIMEOUT_S = 300.0 # a stream that does not drain for this long = a peer stopped taking part: abort and exit non-zero
@@ -500,13 +501,21 @@ def main():
     ev_over_us = max(0.0, (raw_ms_per_step - own_ms_per_step) * 1e3 / max(launches / args.steps, 1))
 
     def class_us(cls):
+        """average launch time of a class on the headline's timer, or None when the class is too short for the correction to mean
+        anything: the overhead is an AVERAGE over all launches of a step (a bracket around a 5 us launch does not open the same gap as
+        one around a 15 ms launch), so a class whose raw bracket is below 3 x the overhead is reported as null instead of a difference
+        of two comparable numbers (the RMAT line carried negative class times and an MFMA fraction of 0.94)"""
         ms, cnt = prof[cls]
-        return (ms / cnt * 1e3 - ev_over_us) if cnt else None
+        if not cnt:
+            return None
+        raw = ms / cnt * 1e3
+        return (raw - ev_over_us) if raw >= 3.0 * ev_over_us else None
 
     out["kernel_us"] = {k: class_us(k) for k, v in prof.items() if v[1]}
     out["kernel_us_raw_event_bracket"] = {k: v[0] / v[1] * 1e3 for k, v in prof.items() if v[1]}
-    out["kernel_ms_per_step"] = {k: class_us(k) * v[1] / args.steps * 1e-3 for k, v in prof.items() if v[1]}
+    out["kernel_ms_per_step"] = {k: (class_us(k) * v[1] / args.steps * 1e-3 if class_us(k) is not None else None) for k, v in prof.items() if v[1]}
     out["event_overhead_us_per_launch"] = ev_over_us
+    out["kernel_us_null_below_us"] = 3.0 * ev_over_us
     out["launches_per_step"] = launches / args.steps
 
     # the shard this rank computes on (the whole graph at world 1): rows, stored entries, operand rows incl. the boundary rows
@@ -535,6 +544,14 @@ def main():
     single = world == 1 and not sharded
     if world == 1:
         pmc = next((os.path.join(ROOT, "profiles", f) for f in (PMC_FILE, PMC_FALLBACK) if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
+        pmc_rmat = os.path.join(ROOT, "profiles", PMC_FILE_RMAT10M)
+        if args.workload == "rmat:10000000:200000000" and d == 128 and os.path.exists(pmc_rmat):
+            # BASELINE config 5 on one GPU: the counters of the same two kernels at this size (tools/profile_r04.sh)
+            z = json.load(open(pmc_rmat))
+            for key, name in (("roofline", "fwd1"), ("roofline_plain", "plain")):
+                if out[key] and name in z.get("hbm_traffic", {}):
+                    out[key]["traffic"] = z["hbm_traffic"][name]["traffic_bytes_per_launch"]
+                    out[key]["traffic_source"] = f"offline rocprofv3 --pmc profile of the same kernels on this workload: profiles/{PMC_FILE_RMAT10M}"
         if args.workload == "whole_graph" and d == 128 and pmc:
             # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel on this workload, corrected as MI355X_MICROARCH.md
             # prescribes.  Counters cannot be read from inside bench.py: the figure comes from an OFFLINE profile of the
@@ -549,15 +566,17 @@ def main():
         # nnz / t_SpMM per launch, forward and backward kinds separately.  spmm_bwd1 at L = 2 is the sparsity-aware
         # top-layer hop (it visits only entries whose neighbour is a batch row), counted at nnz like the rest
         out["spmm_kernel_edges_per_s_by_kind"] = {k: nnz / (class_us(k) * 1e-6)
-                                                  for k in ("spmm_fwd_hadamard", "spmm_fwd", "spmm_bwd1", "spmm_bwd2") if prof.get(k, (0, 0))[1]}
+                                                  for k in ("spmm_fwd_hadamard", "spmm_fwd", "spmm_bwd1", "spmm_bwd2")
+                                                  if prof.get(k, (0, 0))[1] and class_us(k)}
         # fp32-MFMA kernels: achieved TFLOP/s against the 157.3 TF dense fp32-matrix peak
         mf = {}
         for cls, name, fl in (("dense_fwd", "projection (gemm_nt)", 2.0 * n * (2 * d) * d),
                               ("wgrad", "weight gradients (wgrad_tn: L - 1 launches over N rows, the top layer's B rows merged into the first)",
                                2.0 * (n * (L - 1) + B) * d * (2 * d)),
-                              ("loss", "loss gather + sweep + finish, 4 B^2 d", 4.0 * B * B * d)):
+                              ("loss", "loss: sweep with the gather in its prologue and finish + batch-row input gradient in its tail, 4 B^2 d + 4 B d^2",
+                               4.0 * B * B * d + 4.0 * B * d * d)):
             cnt = prof[cls][1]
-            if not cnt:
+            if not cnt or class_us(cls) is None:
                 continue
             per_step = cnt / args.steps
             # several launches of a class per step (L projections; L - 1 full weight gradients; the loss's three launches): flops of all
@@ -575,7 +594,7 @@ def main():
         halo_bytes_t = (int(shard.layout.halo_at.n_halo) * d * 4) if shard.layout.halo_at is not None else 0
         pair_a = int(np.diff(shard.layout.halo_a.recv_off).max()) * d * 4 if world > 1 else 0
         pair_t = (int(np.diff(shard.layout.halo_at.recv_off).max()) * d * 4) if (world > 1 and shard.layout.halo_at is not None) else 0
-        comm_ms = out["kernel_ms_per_step"].get("comm", 0.0)
+        comm_ms = out["kernel_ms_per_step"].get("comm") or 0.0
         mine = [own_ms_per_step, comm_ms, halo_bytes_a, halo_bytes_t, pair_a, pair_t, out["roofline"]["frac"] if out["roofline"] else 0.0,
                 out["roofline"]["avg_launch_us"] if out["roofline"] else 0.0, n_loc, nnz_loc]
         allv = all_ranks(mine)

@@ -123,6 +123,19 @@ int gss_debug_set_option(const char *name, int value) {
     g_knobs.ppr_fused = value ? 1 : 0;   // handles created afterwards
     return GSS_OK;
   }
+  if (strcmp(name, "loss_idx") == 0) {
+    g_knobs.loss_idx = value ? 1 : 0;
+    return GSS_OK;
+  }
+  if (strcmp(name, "loss_tail") == 0) {
+    g_knobs.loss_tail = value ? 1 : 0;
+    return GSS_OK;
+  }
+  if (strcmp(name, "halo_recompute") == 0) {
+    GSS_REQUIRE(value >= -1 && value <= 1, "halo_recompute must be -1 (by graph size), 0 or 1");
+    g_knobs.halo_recompute = value;   // sharded plans created afterwards; every rank of a job must use the same value
+    return GSS_OK;
+  }
   if (strcmp(name, "gemm_variant") == 0) {
     GSS_REQUIRE(value >= 1 && value <= 4, "gemm_variant must be 1..4");
     g_knobs.gemm_variant = value;

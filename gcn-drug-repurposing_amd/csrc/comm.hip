@@ -32,6 +32,22 @@ namespace gss {
     if (r_ != ncclSuccess) return ::gss::fail(GSS_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r_)); \
   } while (0)
 
+// wait for `st` with a deadline (timeout_s <= 0: none): the stream is polled, never blocked on
+static int stream_wait(hipStream_t st, double timeout_s, const char *who) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int spins = 0;; ++spins) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return GSS_OK;
+    if (q != hipErrorNotReady) return fail(GSS_EHIP, "%s: hipStreamQuery -> %s", who, hipGetErrorString(q));
+    if ((spins & 63) == 63 && timeout_s > 0) {
+      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (el > timeout_s) return fail(GSS_ETIMEOUT, "%s: waited %.0f s for the stream", who, el);
+    }
+    if (spins < 2000) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 20 : 500));
+  }
+}
+
 // ---- RCCL ------------------------------------------------------------------------------------------------
 // Error handling: RCCL reports a failed peer / transport asynchronously.  Every enqueue below ends with a poll of
 // ncclCommGetAsyncError; a failure aborts the communicator (ncclCommAbort: kernels already enqueued on the stream stop waiting for
@@ -39,31 +55,52 @@ namespace gss {
 // collective that hangs without an error (a rank that stopped calling: mismatched order, a crashed peer whose socket stays open)
 // is caught at the caller's synchronisation points by gss_comm_sync, which waits for the stream with a deadline and aborts.
 struct RcclComm final : gss_comm {
+  // `comm` is read by every enqueue and freed by abort(), which the host may call from another thread (Python's Comm.abort, a
+  // watchdog): `mu` serialises the two.  Enqueues hold it only while they hand work to RCCL (never while waiting for the device).
   ncclComm_t comm = nullptr;
+  std::mutex mu;
   std::atomic<bool> aborted{false};
+  std::atomic<bool> failed{false};   // check_async has reported an error: ncclCommDestroy could wait for the dead peer
   ~RcclComm() override {
-    if (comm) (void)ncclCommDestroy(comm);
+    std::lock_guard<std::mutex> lk(mu);
+    if (!comm) return;
+    if (failed.load() || aborted.load())
+      (void)ncclCommAbort(comm);
+    else
+      (void)ncclCommDestroy(comm);
+    comm = nullptr;
   }
-  void abort() override {
+  bool device_transport() const override { return true; }
+  void abort_locked() {
     if (aborted.exchange(true)) return;
     if (comm) (void)ncclCommAbort(comm);   // frees the communicator
     comm = nullptr;
   }
-  int alive() const {
+  void abort() override {
+    std::lock_guard<std::mutex> lk(mu);
+    abort_locked();
+  }
+  int alive_locked() const {
     if (aborted.load() || !comm) return fail(GSS_ECOMM, "RCCL communicator of rank %d was aborted after an earlier failure", rank);
     return GSS_OK;
   }
-  int check_async() override {
-    if (int rc = alive()) return rc;
+  int check_locked() {
+    if (int rc = alive_locked()) return rc;
     ncclResult_t st = ncclSuccess;
     const ncclResult_t r = ncclCommGetAsyncError(comm, &st);
     if (r == ncclSuccess && (st == ncclSuccess || st == ncclInProgress)) return GSS_OK;
     const ncclResult_t bad = r != ncclSuccess ? r : st;
-    abort();
+    failed.store(true);
+    abort_locked();
     return fail(GSS_ECOMM, "RCCL asynchronous error on rank %d of %d: %s (communicator aborted)", rank, world, ncclGetErrorString(bad));
   }
+  int check_async() override {
+    std::lock_guard<std::mutex> lk(mu);
+    return check_locked();
+  }
   int count(int32_t *out) override {
-    if (int rc = alive()) return rc;
+    std::lock_guard<std::mutex> lk(mu);
+    if (int rc = alive_locked()) return rc;
     int c = 0;
     GSS_NCCL(ncclCommCount(comm, &c));
     *out = c;
@@ -80,6 +117,7 @@ struct RcclComm final : gss_comm {
         if (int rc = check_async()) return rc;
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (timeout_s > 0 && el > timeout_s) {
+          failed.store(true);
           abort();
           return fail(GSS_ETIMEOUT, "comm_sync: rank %d of %d waited %.0f s for its stream (a peer stopped taking part in a collective?); "
                       "communicator aborted", rank, world, el);
@@ -90,13 +128,15 @@ struct RcclComm final : gss_comm {
     }
   }
   int all_gather(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) override {
-    if (int rc = alive()) return rc;
+    std::lock_guard<std::mutex> lk(mu);
+    if (int rc = alive_locked()) return rc;
     // in place when send == recv + rank * bytes_per_rank (RCCL detects it)
     GSS_NCCL(ncclAllGather(send, recv, bytes_per_rank, ncclInt8, comm, st));
-    return check_async();
+    return check_locked();
   }
   int all_reduce_sum(float *const *bufs, const size_t *counts, int nbuf, hipStream_t st) override {
-    if (int rc = alive()) return rc;
+    std::lock_guard<std::mutex> lk(mu);
+    if (int rc = alive_locked()) return rc;
     // several tensors = one fused RCCL operation (one launch)
     if (nbuf > 1) GSS_NCCL(ncclGroupStart());
     for (int k = 0; k < nbuf; ++k) {
@@ -107,10 +147,11 @@ struct RcclComm final : gss_comm {
       }
     }
     if (nbuf > 1) GSS_NCCL(ncclGroupEnd());
-    return check_async();
+    return check_locked();
   }
   int exchange_rows(const float *send, const int64_t *send_off, float *recv, const int64_t *recv_off, int d, hipStream_t st) override {
-    if (int rc = alive()) return rc;
+    std::lock_guard<std::mutex> lk(mu);
+    if (int rc = alive_locked()) return rc;
     // halo exchange: one fused group of point-to-point transfers, each over the xGMI link of its pair; pairs with an empty
     // list are skipped
     GSS_NCCL(ncclGroupStart());
@@ -123,7 +164,7 @@ struct RcclComm final : gss_comm {
     }
     const ncclResult_t e = ncclGroupEnd();
     if (r != ncclSuccess || e != ncclSuccess) return fail(GSS_ECOMM, "halo exchange (ncclSend/ncclRecv group) -> %s", ncclGetErrorString(r != ncclSuccess ? r : e));
-    return check_async();
+    return check_locked();
   }
 };
 
@@ -183,8 +224,11 @@ struct LocalComm final : gss_comm {
     *out = world;
     return GSS_OK;
   }
-  int sync(hipStream_t st, double) override {   // every collective of this backend already waited behind a timed barrier
-    GSS_HIP(hipStreamSynchronize(st));
+  int sync(hipStream_t st, double timeout_s) override {   // (every collective of this backend already waited behind a timed barrier)
+    if (int rc = stream_wait(st, timeout_s, "local comm")) {
+      if (rc == GSS_ETIMEOUT) sh->abort();
+      return rc;
+    }
     return check_async();
   }
   float *tmp = nullptr;
@@ -267,8 +311,11 @@ struct HostComm final : gss_comm {
     *out = world;
     return GSS_OK;
   }
-  int sync(hipStream_t st, double) override {
-    GSS_HIP(hipStreamSynchronize(st));
+  int sync(hipStream_t st, double timeout_s) override {
+    if (int rc = stream_wait(st, timeout_s, "host-staged comm")) {
+      if (rc == GSS_ETIMEOUT) broken = true;
+      return rc;
+    }
     return check_async();
   }
   int reserve(size_t ns, size_t nr) {

@@ -25,12 +25,35 @@ __device__ __forceinline__ f32x4 mfma16l(float a, float b, f32x4 c) {
 
 constexpr int kLossWaves = 4;
 
+// What follows the sweep, folded into it (round 4): the last of an i tile's js workgroups to finish sums the tile's partial dE in
+// slab order, runs the backward of F.normalize / F.elu on the tile's 16 batch rows and their input gradient [g_ax | g_am] = dP [W1 ; W2]
+// -- loss_finish_bwd_kernel and the batch-row launch of gemm_nt_lds_kernel<.., EPI_SPLIT>, which were two launches of ~5 us for < 1 us
+// of work each (a kernel boundary costs more than either).  Same lanes, same order, same MFMA sequence as the stand-alone kernels: same bits.
+struct LossTail {
+  unsigned *tile_cnt;        // [ni] arrival counters + [1] finished tiles; zero between launches (the last arriver resets what it used)
+  const int32_t *rows;       // row of inv_den / p per member (NULL: the sweep's own row table, IDX mode)
+  const int32_t *pos_ids;    // key of the batch-position map per member (NULL: as rows)
+  int32_t *pos_set;          // nullable
+  const float *keep;         // nullable: 0 where another shard owns the member (its dx_b / dp_b rows are written as zeros)
+  const float *inv_den, *p;
+  float c;
+  float *dx_b, *dp_b, *loss_out;
+  const float *w1t, *w2t;    // NULL: no input gradient
+  float *gax_b, *gam_b;
+  int dgrad_all;             // the input gradient of EVERY member (a shard that holds p / inv_den of the whole batch), else of the kept ones
+};
+
 struct LossArgs {
   int d, b, js;  // js = grid.y
-  const float *e;  // contiguous E_B [b][d] (gathered by gather_rows_kernel)
+  const float *e;  // contiguous E_B [b][d] (gathered by gather_rows_kernel); IDX: the embedding matrix, rows through the table
   float beta, alpha;
   float *de_part;     // [js][b][d]
   double *loss_part;  // [grid.x * grid.y]
+  // IDX: the batch-row gather and id translation folded into the sweep's prologue (every workgroup builds the row table in LDS;
+  // workgroup 0 also stores the translated ids for the kernels after it)
+  const int32_t *idx, *node_map;
+  int32_t *rloc_out, *pid_out;   // nullable (already prepared)
+  LossTail t;
 };
 
 // E_B = e[idx] (modules/model.py:216-217) into a contiguous buffer, so the MFMA loop has no index indirection
@@ -78,11 +101,81 @@ __global__ __launch_bounds__(256) void gather_rows_mapped_kernel(int b, int d4, 
 // the second product's operand loads removed altogether (wrong results, timing only) 30.6 us -- the sweep is bound by neither its
 // loads nor their waits; 1024 MFMAs per SIMD are 13.7 us at 2.4 GHz and ~16.5 us at the ~2.0 GHz an MFMA-saturated loop sustains
 // (tools/micro/mfma_lds.hip: 126-131 of 157 TFLOP/s), the rest is the fixed start (i-tile fragments) and end (wave tree, partial store).
-template <int NG, bool EXACT, bool PF = (NG <= 2), int OCC = (NG >= 4 ? 1 : 2)>
+// One batch row of the finish (shared by loss_finish_bwd_kernel and the sweep's tail -- the same lanes in the same order, so the two
+// forms give the same bits): lane li of the row's lane group (lpr lanes) holds float4s li + 64 k.
+//   de = 2 sum_js de_part; dot = e . de; dx = (de - e dot) * inv; dp = c * dx (.) elu'(p)
+// dp_lds (nullable): the row of dP the input-gradient MFMAs of the tail read (unmasked when dgrad_all)
+template <int VPL>
+__device__ __forceinline__ void finish_row(bool ok, int r, int li, int lpr, int d4, int js, int b, const float *__restrict__ de_part,
+                                           const float *__restrict__ erow, float inv_u, float keepv, const float *__restrict__ prow, float c,
+                                           float *__restrict__ dx_b, float *__restrict__ dp_b, float *dp_lds, bool dgrad_all) {
+  float4 g[VPL], ev[VPL];
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int f4 = li + k * 64;
+    const bool in = ok && f4 < d4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in) {
+      const size_t off = ((size_t)r * d4 + f4) * 4;
+      s = ld4(de_part + off);
+      for (int t = 1; t < js; ++t) s = add4(s, ld4(de_part + (size_t)t * b * d4 * 4 + off));
+      s = scale4(2.f, s);
+    }
+    g[k] = s;
+    ev[k] = in ? ld4(erow + (size_t)f4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    dot += g[k].x * ev[k].x + g[k].y * ev[k].y + g[k].z * ev[k].z + g[k].w * ev[k].w;
+  }
+  for (int o = 1; o < lpr; o <<= 1) dot += __shfl_xor(dot, o, 64);
+  if (!ok) return;
+  const float inv = keepv != 0.f ? inv_u : 0.f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int f4 = li + k * 64;
+    if (f4 >= d4) continue;
+    float4 dx;
+    dx.x = (g[k].x - ev[k].x * dot) * inv;
+    dx.y = (g[k].y - ev[k].y * dot) * inv;
+    dx.z = (g[k].z - ev[k].z * dot) * inv;
+    dx.w = (g[k].w - ev[k].w * dot) * inv;
+    st4(dx_b + ((size_t)r * d4 + f4) * 4, dx);
+    const float4 pg = elu_grad4(ld4(prow + (size_t)f4 * 4));
+    const float4 dp = scale4(c, mul4(dx, pg));
+    st4(dp_b + ((size_t)r * d4 + f4) * 4, dp);
+    if (dp_lds) {
+      float4 dl = dp;
+      if (dgrad_all && keepv == 0.f) {   // a member another shard owns: its gradient row all the same (this shard holds its p / inv_den)
+        float4 du;
+        du.x = (g[k].x - ev[k].x * dot) * inv_u;
+        du.y = (g[k].y - ev[k].y * dot) * inv_u;
+        du.z = (g[k].z - ev[k].z * dot) * inv_u;
+        du.w = (g[k].w - ev[k].w * dot) * inv_u;
+        dl = scale4(c, mul4(du, pg));
+      }
+      *reinterpret_cast<float4 *>(dp_lds + (size_t)f4 * 4) = dl;
+    }
+  }
+}
+
+// EXACT: d == 64 NG, no feature masking anywhere.  From d = 256 on the operand fragments + accumulators need more than the 256
+// registers two workgroups per CU leave a lane (372 B/lane of scratch at NG = 4): one workgroup per CU with the full 512
+// (accumulators in AGPRs), and at NG = 4 no register prefetch of the next j tile, measured at B = 2048, d = 256:
+// 123 us -> 55 us for gather + sweep + finish (tools/loss_prof.py 256).
+// Measured dead ends at d = 128, B = 2048 (gather + sweep + finish 31.6 us, tools/loss_prof.py): 8 waves per workgroup 33.2 us; two j
+// tiles per trip with two operand register sets that swap roles (no copies, every wait a full tile behind its load in the ISA) 34.7 us;
+// the second product's operand loads removed altogether (wrong results, timing only) 30.6 us -- the sweep is bound by neither its
+// loads nor their waits; 1024 MFMAs per SIMD are 13.7 us at 2.4 GHz and ~16.5 us at the ~2.0 GHz an MFMA-saturated loop sustains
+// (tools/micro/mfma_lds.hip: 126-131 of 157 TFLOP/s), the rest is the fixed start (i-tile fragments) and end (wave tree, partial store).
+// IDX (round 4): E_B is never gathered -- the prologue builds the table member -> embedding row in LDS (the id translation of a
+// relabelled graph included) and every operand row is fetched through it (the same values in the same order: same bits).
+// TAIL (round 4, EXACT only): see LossTail.
+template <int NG, bool EXACT, bool IDX = false, bool TAIL = false, bool PF = (NG <= 2), int OCC = (NG >= 4 ? 1 : 2)>
 __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *red = reinterpret_cast<float4 *>(smem);  // [2 slots][NG*4 tiles][64 lanes]
+  int32_t *rtab = reinterpret_cast<int32_t *>(smem + (size_t)2 * NG * 4 * 64 * sizeof(float4));   // IDX: [b] embedding row of every member
   __shared__ double lsum[kLossWaves];
+  __shared__ int s_last;
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
@@ -95,7 +188,21 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
   const float coef = -g.alpha / ((float)B * (float)B);
   const float beta = g.beta;
 
-  const float *ei = g.e + (size_t)min(B - 1, i0 + c) * d + 4 * q;
+  if (IDX) {
+    const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    for (int t = threadIdx.x; t < B; t += 64 * kLossWaves) {
+      int id = g.idx[t];
+      if (g.node_map) id = g.node_map[id];
+      rtab[t] = id;
+      if (writer && g.rloc_out) g.rloc_out[t] = id;
+      if (writer && g.pid_out) g.pid_out[t] = id;
+    }
+    __syncthreads();
+  }
+  // row of E_B behind member j (j already clamped to [0, B))
+  auto erow = [&](int j) -> const float * { return g.e + (size_t)(IDX ? rtab[j] : j) * d; };
+
+  const float *ei = erow(min(B - 1, i0 + c)) + 4 * q;
   const bool i_ok = (i0 + c) < B;
   // the i-tile's operand fragments stay in registers for the whole j sweep when d <= 256
   constexpr bool HOLD_I = NG <= 4;
@@ -115,21 +222,29 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
 
   float4 aj[HOLD_I ? NCH : 1];
   if (HOLD_I && PF && slot < nj) {
-    const float *ej0 = g.e + (size_t)min(B - 1, slot * 16 + c) * d + 4 * q;
+    const float *ej0 = erow(min(B - 1, slot * 16 + c)) + 4 * q;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) aj[k] = (EXACT || 16 * k < d) ? ld4(ej0 + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // IDX: the table entries of a tile are read one trip ahead of the loads that need them (no LDS round trip in front of a fetch)
+  int rid_p2[4] = {0, 0, 0, 0}, rid_an = 0;
+  if (IDX && slot < nj) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rid_p2[r] = rtab[min(B - 1, slot * 16 + 4 * q + r)];
+    const int jn = slot + nslots;
+    rid_an = rtab[min(B - 1, (jn < nj ? jn : slot) * 16 + c)];
   }
   for (int jt = slot; jt < nj; jt += nslots) {
     const int j0 = jt * 16;
     // ---- S'[j][i] = E_j . E_i  (A = E_j rows, B = E_i rows), k order kc + 4 q + e; two accumulators
     // break the dependent MFMA chain; the next j-tile's operands are requested before this tile's MFMAs
-    const float *ej = g.e + (size_t)min(B - 1, j0 + c) * d + 4 * q;
+    const float *ej = (IDX && HOLD_I && PF) ? nullptr : erow(min(B - 1, j0 + c)) + 4 * q;
     // operands of the second product (rows j0 + 4 q + r of E_B, features fbase + 64 G + 4 c ..): requested now,
     // branch-free, so their latency hides under the 4 NCH MFMAs of the first product
     float4 p2[4][NG];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float *er = g.e + (size_t)min(B - 1, j0 + 4 * q + r) * d;
+      const float *er = IDX ? g.e + (size_t)rid_p2[r] * d : g.e + (size_t)min(B - 1, j0 + 4 * q + r) * d;
 #pragma unroll
       for (int G = 0; G < NG; ++G) {
         const int f = fbase + 64 * G + 4 * c;
@@ -146,6 +261,11 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
     if (HOLD_I && !PF) {
 #pragma unroll
       for (int k = 0; k < NCH; ++k) aj[k] = (EXACT || 16 * k < d) ? ld4(ej + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (IDX) {
+        const int jn = jt + nslots;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rid_p2[r] = rtab[min(B - 1, (jn < nj ? jn : jt) * 16 + 4 * q + r)];
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
@@ -157,9 +277,15 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
     } else if (HOLD_I) {
       float4 an[NCH];
       const int jn = jt + nslots;
-      const float *ejn = g.e + (size_t)min(B - 1, (jn < nj ? jn : jt) * 16 + c) * d + 4 * q;
+      const float *ejn = IDX ? g.e + (size_t)rid_an * d + 4 * q : g.e + (size_t)min(B - 1, (jn < nj ? jn : jt) * 16 + c) * d + 4 * q;
 #pragma unroll
       for (int k = 0; k < NCH; ++k) an[k] = (EXACT || 16 * k < d) ? ld4(ejn + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (IDX) {   // the table entries of the NEXT trip's fetches
+        const int j1 = jn < nj ? jn : jt, j2 = (jn + nslots) < nj ? jn + nslots : j1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rid_p2[r] = rtab[min(B - 1, j1 * 16 + 4 * q + r)];
+        rid_an = rtab[min(B - 1, j2 * 16 + c)];
+      }
       __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks every load next to its first use (one exposed
                                           // round trip per 4 MFMAs); issue them all here, consume them later
 #pragma unroll
@@ -172,6 +298,11 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
 #pragma unroll
       for (int k = 0; k < NCH; ++k) aj[k] = an[k];
     } else {
+      if (IDX) {
+        const int jn = jt + nslots;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rid_p2[r] = rtab[min(B - 1, (jn < nj ? jn : jt) * 16 + 4 * q + r)];
+      }
       for (int kc = 0; kc < d; kc += 16) {
         const float4 a4 = ld4(ej + kc);
         const float4 b4 = ld4(ei + kc);
@@ -231,25 +362,118 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
     }
     __syncthreads();
   }
-  // tile (G, e), lane (c, q), reg r: node i0 + c, feature fbase + 64 G + 4 (4 q + r) + e
-  if (w == 0 && i_ok) {
-    float *out = g.de_part + ((size_t)blockIdx.y * B + (i0 + c)) * d;
-#pragma unroll
-    for (int G = 0; G < NG; ++G)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int f = fbase + 64 * G + 16 * q + 4 * r;
-        if (EXACT || f < d) st4(out + f, make_float4(acc[G][0][r], acc[G][1][r], acc[G][2][r], acc[G][3][r]));
-      }
-  }
   // ---- loss partial (only the z == 0 slab counts it)
   const double ws = wave_sum_d((double)lacc);
   if (lane == 0) lsum[w] = ws;
   __syncthreads();
-  if (threadIdx.x == 0 && blockIdx.z == 0) {
-    double t = 0.0;
-    for (int k = 0; k < kLossWaves; ++k) t += lsum[k];
-    g.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = t;
+  // tile (G, e), lane (c, q), reg r: node i0 + c, feature fbase + 64 G + 4 (4 q + r) + e
+  if (w == 0) {
+    if (i_ok) {
+      float *out = g.de_part + ((size_t)blockIdx.y * B + (i0 + c)) * d;
+#pragma unroll
+      for (int G = 0; G < NG; ++G)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = fbase + 64 * G + 16 * q + 4 * r;
+          if (EXACT || f < d) st4(out + f, make_float4(acc[G][0][r], acc[G][1][r], acc[G][2][r], acc[G][3][r]));
+        }
+    }
+    if (lane == 0 && blockIdx.z == 0) {
+      double t = 0.0;
+      for (int k = 0; k < kLossWaves; ++k) t += lsum[k];
+      g.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+    if (TAIL) __threadfence();   // this workgroup's partials (all stored by wave 0) are visible device-wide before it counts itself in
+  }
+  if (!TAIL) return;
+
+  // ---- tail: the last of the tile's js workgroups finishes the tile (every workgroup passes here exactly once: no waiting)
+  const LossTail &T = g.t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = atomicAdd(&T.tile_cnt[blockIdx.x], 1u);
+    s_last = (old == (unsigned)g.js - 1u) ? 1 : 0;
+    if (s_last) (void)atomicExch(&T.tile_cnt[blockIdx.x], 0u);   // nobody else touches it any more; zero again for the next launch
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();   // the other slabs' partials, written before their arrival, are read from memory below
+  {
+    const int d4 = d / 4;
+    int lg = 2;
+    while ((1 << lg) < d4 && lg < 6) ++lg;
+    const int lpr = 1 << lg, rpw = 64 >> lg;
+    const int li = lane & (lpr - 1);
+    float *dp_tile = reinterpret_cast<float *>(red);   // [16][d + 4]: the B operand of the input-gradient MFMAs (the tree is done with `red`;
+    const int ds = d + 4;                              // rows 16 B apart in the banks: the 16 rows of a fragment read do not collide)
+    constexpr int VPL = NG <= 4 ? 1 : 2;  // float4s of a row per lane: d4 / 64 rounded up
+    for (int rr = w * rpw + (lane >> lg); rr < 16; rr += kLossWaves * rpw) {
+      const int r = i0 + rr;
+      const bool ok = r < B;
+      const int rc = ok ? r : B - 1;
+      const int node = T.rows ? T.rows[rc] : (IDX ? rtab[rc] : rc);
+      const float keepv = T.keep ? T.keep[rc] : 1.f;
+      if (ok && T.pos_set && li == 0) {
+        const int key = T.pos_ids ? T.pos_ids[r] : node;
+        if (key >= 0) T.pos_set[key] = r;
+      }
+      finish_row<VPL>(ok, r, li, lpr, d4, g.js, B, g.de_part, erow(rc), T.inv_den[node], keepv, T.p + (size_t)node * d, T.c, T.dx_b, T.dp_b,
+                      T.w1t ? dp_tile + (size_t)rr * ds : nullptr, T.dgrad_all != 0);
+      if (!ok && T.w1t)
+        for (int f4 = li; f4 < d4; f4 += lpr) *reinterpret_cast<float4 *>(dp_tile + (size_t)rr * ds + f4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (T.w1t) {
+      // [g_ax | g_am][i0 .. i0 + 16) = dP_tile . [W1 ; W2]: wave w takes output features [w d / 2, (w + 1) d / 2) of the 2 d; the k order
+      // (chunk by chunk, e = 0..3 inside) is gemm_nt_lds_kernel's, so the rows keep the bits of the stand-alone launch
+      __syncthreads();
+      constexpr int NTW = 2 * NG;                   // 16-feature blocks per wave: (2 d / 4) / 16 with d = 64 NG
+      const int jw0 = w * 32 * NG;
+      const bool hi = jw0 >= d;
+      const float *wt = (hi ? T.w2t : T.w1t) + (size_t)((hi ? jw0 - d : jw0) + c) * d + 4 * q;
+      const float *brow = dp_tile + (size_t)c * ds + 4 * q;
+      f32x4 o[NTW];
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) o[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kc = 0; kc < d; kc += 16) {
+        const float4 bv = *reinterpret_cast<const float4 *>(brow + kc);
+        float4 av[NTW];
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) av[u] = ld4(wt + (size_t)(16 * u) * d + kc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float bs = e == 0 ? bv.x : e == 1 ? bv.y : e == 2 ? bv.z : bv.w;
+#pragma unroll
+          for (int u = 0; u < NTW; ++u) {
+            const float as = e == 0 ? av[u].x : e == 1 ? av[u].y : e == 2 ? av[u].z : av[u].w;
+            o[u] = mfma16l(as, bs, o[u]);
+          }
+        }
+      }
+      if (i_ok) {
+        float *out = (hi ? T.gam_b : T.gax_b) + (size_t)(i0 + c) * d + (hi ? jw0 - d : jw0) + 4 * q;
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) st4(out + 16 * u, make_float4(o[u][0], o[u][1], o[u][2], o[u][3]));
+      }
+    }
+  }
+  // ---- the loss itself: by the workgroup that finishes the last tile (loss_finish_bwd_kernel's sum, same order)
+  if (w == 0) {
+    __threadfence();
+    int last_all = 0;
+    if (lane == 0) {
+      const unsigned old = atomicAdd(&T.tile_cnt[gridDim.x], 1u);
+      last_all = old == gridDim.x - 1u;
+      if (last_all) (void)atomicExch(&T.tile_cnt[gridDim.x], 0u);
+    }
+    last_all = __shfl(last_all, 0, 64);
+    if (last_all) {
+      __threadfence();
+      const int nloss = (int)(gridDim.x * gridDim.y);
+      double t = 0.0;
+      for (int k = lane; k < nloss; k += 64) t += g.loss_part[k];
+      t = wave_sum_d(t);
+      if (lane == 0) T.loss_out[0] = (float)(-0.5 * (double)g.alpha * t / ((double)B * (double)B));
+    }
   }
 }
 
@@ -272,13 +496,16 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(int b, int d, int js, 
   }
 }
 
-// plan path: loss_finish + the backward of F.normalize and F.elu on the batch rows in one launch.
+// plan path: loss_finish + the backward of F.normalize and F.elu on the batch rows in one launch (the stand-alone form of the sweep's
+// tail, for the shapes the tail does not cover).
 // One lane group per batch row: de = 2 sum_js de_part (the row of dLoss/dE_B), then
-// dx = (de - e (e . de)) * inv_den[node], dp = c * dx (.) elu'(p[node]); e rows come from the gathered E_B.
+// dx = (de - e (e . de)) * inv_den[node], dp = c * dx (.) elu'(p[node]); e rows come from the gathered E_B, or (erows != NULL) from
+// the embedding matrix through the row list.
 template <int VPL>
 __global__ __launch_bounds__(256) void loss_finish_bwd_kernel(int b, int d4, int lpr_log2, int js, int nloss,
                                                               const float *__restrict__ de_part, const double *__restrict__ loss_part,
-                                                              float alpha, const float *__restrict__ e_b, const int32_t *__restrict__ idx,
+                                                              float alpha, const float *__restrict__ e_b, const int32_t *__restrict__ erows,
+                                                              const int32_t *__restrict__ idx,
                                                               const int32_t *__restrict__ pos_ids, const float *__restrict__ keep,
                                                               const float *__restrict__ inv_den, const float *__restrict__ p, float c,
                                                               float *__restrict__ dx_b, float *__restrict__ dp_b,
@@ -289,49 +516,20 @@ __global__ __launch_bounds__(256) void loss_finish_bwd_kernel(int b, int d4, int
   const int li = lane & (lpr - 1);
   const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + (lane >> lpr_log2);
   const bool ok = r < b;
-  const int node = ok ? idx[r] : 0;
-  float4 g[VPL], ev[VPL];
-  float dot = 0.f;
-#pragma unroll
-  for (int k = 0; k < VPL; ++k) {
-    const int f4 = li + k * 64;
-    const bool in = ok && f4 < d4;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (in) {
-      const size_t off = ((size_t)r * d4 + f4) * 4;
-      s = ld4(de_part + off);
-      for (int t = 1; t < js; ++t) s = add4(s, ld4(de_part + (size_t)t * b * d4 * 4 + off));
-      s = scale4(2.f, s);
-    }
-    g[k] = s;
-    ev[k] = in ? ld4(e_b + ((size_t)r * d4 + f4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    dot += g[k].x * ev[k].x + g[k].y * ev[k].y + g[k].z * ev[k].z + g[k].w * ev[k].w;
-  }
-  for (int o = 1; o < lpr; o <<= 1) dot += __shfl_xor(dot, o, 64);
+  const int rc = ok ? r : 0;
+  const int node = idx[rc];
   if (blockIdx.x == 0 && threadIdx.x < 64) {
     double t = 0.0;
     for (int k = threadIdx.x; k < nloss; k += 64) t += loss_part[k];
     t = wave_sum_d(t);
     if (threadIdx.x == 0) loss_out[0] = (float)(-0.5 * (double)alpha * t / ((double)b * (double)b));
   }
-  if (!ok) return;
   // idx: row of inv_den / p (this shard's local row); pos_ids: the id the batch-position map is keyed by (the same array on
   // one GPU, the padded global id on a shard); keep[r] == 0: another shard owns the row -> zero gradient here
-  if (pos_set && li == 0 && pos_ids[r] >= 0) pos_set[pos_ids[r]] = r;
-  const float inv = (!keep || keep[r] != 0.f) ? inv_den[node] : 0.f;
-#pragma unroll
-  for (int k = 0; k < VPL; ++k) {
-    const int f4 = li + k * 64;
-    if (f4 >= d4) continue;
-    float4 dx;
-    dx.x = (g[k].x - ev[k].x * dot) * inv;
-    dx.y = (g[k].y - ev[k].y * dot) * inv;
-    dx.z = (g[k].z - ev[k].z * dot) * inv;
-    dx.w = (g[k].w - ev[k].w * dot) * inv;
-    st4(dx_b + ((size_t)r * d4 + f4) * 4, dx);
-    const float4 pg = elu_grad4(ld4(p + ((size_t)node * d4 + f4) * 4));
-    st4(dp_b + ((size_t)r * d4 + f4) * 4, scale4(c, mul4(dx, pg)));
-  }
+  if (ok && pos_set && li == 0 && pos_ids[r] >= 0) pos_set[pos_ids[r]] = r;
+  const float *erow = e_b + (size_t)(erows ? erows[rc] : rc) * d4 * 4;
+  finish_row<VPL>(ok, r, li, lpr, d4, js, b, de_part, erow, inv_den[node], keep ? keep[rc] : 1.f, p + (size_t)node * d4 * 4, c, dx_b, dp_b, nullptr,
+                  false);
 }
 
 // debug knob "loss_wgs": workgroups the (i-tile x j-split) grid aims at.  One workgroup per CU wins at B = 2048 (gather + sweep + finish,
@@ -350,12 +548,17 @@ static void loss_geometry(int32_t b, int32_t d, int &ni, int &js, int &nz, int &
   nz = ceil_div(groups, ng);
 }
 
+// workspace: [4 KB header: the tail's arrival counters, at a place that does not move with b] [de_part] [loss_part] [E_B]
+constexpr size_t kLossHeader = 4096;
+constexpr int kLossTailMaxTiles = (int)(kLossHeader / sizeof(unsigned)) - 1;
+constexpr int kLossIdxMaxBatch = 8192;   // rows of the LDS table (32 KB)
+
 size_t loss_workspace_bytes(int32_t b, int32_t d) {
   int ni, js, nz, ng;
   loss_geometry(b, d, ni, js, nz, ng);
   size_t de = sizeof(float) * (size_t)js * b * d;
   de = (de + 15) / 16 * 16;
-  return de + (sizeof(double) * (size_t)ni * js + 15) / 16 * 16 + sizeof(float) * (size_t)b * d;
+  return kLossHeader + de + (sizeof(double) * (size_t)ni * js + 15) / 16 * 16 + sizeof(float) * (size_t)b * d;
 }
 
 // The workspace is NOT monotone in b: the number of j slabs grows as the i tiles get fewer (B = 2048 -> 128 tiles x 2 slabs, 3 B d floats;
@@ -372,6 +575,7 @@ size_t loss_workspace_bytes_max(int32_t b_max, int32_t d) {
 
 struct LossLaunch {
   int ni, js, nz, ng;
+  unsigned *cnt;
   float *de_part;
   double *loss_part;
   float *e_b;
@@ -382,9 +586,11 @@ static void loss_layout(int32_t d, int32_t b, void *ws, LossLaunch &L) {
   size_t de_bytes = sizeof(float) * (size_t)L.js * b * d;
   de_bytes = (de_bytes + 15) / 16 * 16;
   const size_t lp_bytes = (sizeof(double) * (size_t)L.ni * L.js + 15) / 16 * 16;
-  L.de_part = (float *)ws;
-  L.loss_part = (double *)((char *)ws + de_bytes);
-  L.e_b = (float *)((char *)ws + de_bytes + lp_bytes);
+  char *base = (char *)ws + kLossHeader;
+  L.cnt = (unsigned *)ws;
+  L.de_part = (float *)base;
+  L.loss_part = (double *)(base + de_bytes);
+  L.e_b = (float *)(base + de_bytes + lp_bytes);
 }
 
 // stage 1: E_B = e[idx] (zero where keep == 0) into the workspace; returns where it is
@@ -395,27 +601,60 @@ static int loss_gather(int32_t d, const float *e, const int32_t *idx, const floa
   return GSS_OK;
 }
 
-// stage 2: the fused S / G / dE sweep over the gathered rows
-static int loss_sweep(int32_t d, int32_t b, float beta, float alpha, hipStream_t st, LossLaunch &L) {
-  LossArgs g{d, b, L.js, L.e_b, beta, alpha, L.de_part, L.loss_part};
+// debug knobs "loss_idx" / "loss_tail": 0 = the gather launch / the finish and batch-row input-gradient launches stay separate kernels
+bool loss_tail_available(int32_t d, int32_t b) {
+  int ni, js, nz, ng;
+  loss_geometry(b, d, ni, js, nz, ng);
+  return K().loss_tail != 0 && d == 64 * ng && nz == 1 && ng <= 4 && ni <= kLossTailMaxTiles;
+}
+bool loss_idx_available(int32_t b) { return K().loss_idx != 0 && b <= kLossIdxMaxBatch; }
+
+// stage 2: the fused S / G / dE sweep.  idx mode (g.idx != NULL): operand rows through the LDS table; tail: see LossTail
+static int loss_sweep(hipStream_t st, LossLaunch &L, LossArgs g, bool tail) {
+  const int d = g.d;
   dim3 grid(L.ni, L.js, L.nz), block(64 * kLossWaves);
-  const size_t lds = (size_t)2 * L.ng * 4 * 64 * sizeof(float4);
+  const bool idx = g.idx != nullptr;
+  const size_t lds = (size_t)2 * L.ng * 4 * 64 * sizeof(float4) + (idx ? sizeof(int32_t) * (size_t)g.b : 0);
   const bool exact = (d == 64 * L.ng) && L.nz == 1;
-#define GSS_LOSS_CASE(NGV)                                                              \
-  case NGV:                                                                             \
-    if (exact)                                                                          \
-      hipLaunchKernelGGL((loss_fused_kernel<NGV, true>), grid, block, lds_request(loss_fused_kernel<NGV, true>, lds, K().loss_lds_kb), st, g);      \
-    else                                                                                \
-      hipLaunchKernelGGL((loss_fused_kernel<NGV, false>), grid, block, lds_request(loss_fused_kernel<NGV, false>, lds, K().loss_lds_kb), st, g);     \
+  if (tail && !(exact && L.ng <= 4 && L.ni <= kLossTailMaxTiles)) return fail(GSS_EINVAL, "loss_sweep: the fused tail is not available at d=%d, b=%d", d, g.b);
+  if (idx && g.b > kLossIdxMaxBatch) return fail(GSS_EINVAL, "loss_sweep: the row table does not fit b=%d", g.b);
+  g.js = L.js;
+  g.de_part = L.de_part;
+  g.loss_part = L.loss_part;
+  g.t.tile_cnt = L.cnt;
+#define GSS_LOSS_LAUNCH(NGV, EX, IX, TL) \
+  hipLaunchKernelGGL((loss_fused_kernel<NGV, EX, IX, TL>), grid, block, lds_request(loss_fused_kernel<NGV, EX, IX, TL>, lds, K().loss_lds_kb), st, g)
+#define GSS_LOSS_CASE(NGV)                            \
+  case NGV:                                           \
+    if (exact && tail && idx)                         \
+      GSS_LOSS_LAUNCH(NGV, true, true, true);         \
+    else if (exact && tail)                           \
+      GSS_LOSS_LAUNCH(NGV, true, false, true);        \
+    else if (exact && idx)                            \
+      GSS_LOSS_LAUNCH(NGV, true, true, false);        \
+    else if (exact)                                   \
+      GSS_LOSS_LAUNCH(NGV, true, false, false);       \
+    else if (idx)                                     \
+      GSS_LOSS_LAUNCH(NGV, false, true, false);       \
+    else                                              \
+      GSS_LOSS_LAUNCH(NGV, false, false, false);      \
     break;
   switch (L.ng) {
     GSS_LOSS_CASE(1)
     GSS_LOSS_CASE(2)
     GSS_LOSS_CASE(4)
     default:
-      GSS_LOSS_CASE(8)
+      if (exact && idx)
+        GSS_LOSS_LAUNCH(8, true, true, false);
+      else if (exact)
+        GSS_LOSS_LAUNCH(8, true, false, false);
+      else if (idx)
+        GSS_LOSS_LAUNCH(8, false, true, false);
+      else
+        GSS_LOSS_LAUNCH(8, false, false, false);
   }
 #undef GSS_LOSS_CASE
+#undef GSS_LOSS_LAUNCH
   GSS_LAUNCH_CHECK("loss_fused_kernel");
   return GSS_OK;
 }
@@ -427,7 +666,13 @@ int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32
   hipStream_t st = as_stream(stream);
   LossLaunch L;
   if (int rc = loss_gather(d, e, idx, nullptr, b, ws, st, L)) return rc;
-  if (int rc = loss_sweep(d, b, beta, alpha, st, L)) return rc;
+  LossArgs g{};
+  g.d = d;
+  g.b = b;
+  g.e = L.e_b;
+  g.beta = beta;
+  g.alpha = alpha;
+  if (int rc = loss_sweep(st, L, g, false)) return rc;
   const int nb = ceil_div((int64_t)b * d / 4, 256);
   hipLaunchKernelGGL(loss_finish_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, b, d, L.js, L.ni * L.js, L.de_part, L.loss_part,
                      alpha, de_b, loss_out);
@@ -471,20 +716,81 @@ int loss_gather_rows_mapped(int32_t d, const float *e, const int32_t *idx, const
 int loss_fused_gathered(int32_t d, int32_t b, float beta, float alpha, float *loss_out, const int32_t *idx, const int32_t *pos_ids,
                         const float *keep, const float *inv_den, const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set,
                         void *ws, void *stream) {
-  if (int rc = check_d(d)) return rc;
-  GSS_REQUIRE(b > 0 && idx && pos_ids && loss_out && inv_den && p && dx_b && dp_b && ws, "loss_fused_gathered: null operand");
+  LossStep s{};
+  s.d = d;
+  s.b = b;
+  s.beta = beta;
+  s.alpha = alpha;
+  s.loss_out = loss_out;
+  s.rows = idx;
+  s.pos_ids = pos_ids;
+  s.keep = keep;
+  s.inv_den = inv_den;
+  s.p = p;
+  s.c = c;
+  s.dx_b = dx_b;
+  s.dp_b = dp_b;
+  s.pos_set = pos_set;
+  s.no_tail = true;
+  bool dgrad_done = false;
+  return loss_step(s, ws, stream, &dgrad_done);
+}
+
+// The loss of one step on the plan's path: sweep (+ gather in its prologue when s.idx is given) + finish (+ the batch rows' input
+// gradient when s.w1t is given), in as few launches as the shapes allow.  *dgrad_done says whether gax_b / gam_b were written.
+int loss_step(const LossStep &s, void *ws, void *stream, bool *dgrad_done) {
+  if (int rc = check_d(s.d)) return rc;
+  GSS_REQUIRE(s.b > 0 && s.loss_out && s.inv_den && s.p && s.dx_b && s.dp_b && ws && dgrad_done, "loss_step: null operand");
+  GSS_REQUIRE(s.idx || s.rows, "loss_step: neither a batch to translate nor translated rows");
+  GSS_REQUIRE(!s.idx || (s.emb && loss_idx_available(s.b)), "loss_step: the row-table form needs the embeddings and b <= %d", kLossIdxMaxBatch);
   hipStream_t st = as_stream(stream);
+  const int d = s.d, b = s.b;
   LossLaunch L;
   loss_layout(d, b, ws, L);
-  if (int rc = loss_sweep(d, b, beta, alpha, st, L)) return rc;
+  const bool tail = !s.no_tail && loss_tail_available(d, b);
+  LossArgs g{};
+  g.d = d;
+  g.b = b;
+  g.e = s.idx ? s.emb : (s.e_b ? s.e_b : L.e_b);
+  g.beta = s.beta;
+  g.alpha = s.alpha;
+  g.idx = s.idx;
+  g.node_map = s.node_map;
+  g.rloc_out = s.rloc_out;
+  g.pid_out = s.pid_out;
+  LossTail &T = g.t;
+  T.rows = s.rows;
+  T.pos_ids = s.pos_ids;
+  T.pos_set = s.pos_set;
+  T.keep = s.keep;
+  T.inv_den = s.inv_den;
+  T.p = s.p;
+  T.c = s.c;
+  T.dx_b = s.dx_b;
+  T.dp_b = s.dp_b;
+  T.loss_out = s.loss_out;
+  T.w1t = s.w1t;
+  T.w2t = s.w2t;
+  T.gax_b = s.gax_b;
+  T.gam_b = s.gam_b;
+  T.dgrad_all = s.dgrad_all ? 1 : 0;
+  GSS_REQUIRE(!s.w1t || (s.w2t && s.gax_b && s.gam_b), "loss_step: incomplete input-gradient operands");
+  if (int rc = loss_sweep(st, L, g, tail)) return rc;
+  *dgrad_done = tail && s.w1t != nullptr;
+  if (tail) return GSS_OK;
+  // separate finish launch (shapes the tail does not cover, or knob loss_tail = 0).  In idx mode the stand-alone kernel reads the
+  // rows the sweep's workgroup 0 stored (rloc_out), or the caller's prepared rows
+  const int32_t *rows = s.rows ? s.rows : s.rloc_out;
+  GSS_REQUIRE(rows, "loss_step: the separate finish needs translated rows (rloc_out)");
+  const int32_t *pos_ids = s.pos_ids ? s.pos_ids : rows;
   const int d4 = d / 4;
   int lg = 2;
   while ((1 << lg) < d4 && lg < 6) ++lg;
   const int vpl = d4 <= 64 ? 1 : d4 <= 128 ? 2 : 4;
   dim3 grid(ceil_div(b, 4 * (64 >> lg))), block(256);
 #define GSS_FIN(V)                                                                                                              \
-  hipLaunchKernelGGL((loss_finish_bwd_kernel<V>), grid, block, 0, st, b, d4, lg, L.js, L.ni * L.js, L.de_part, L.loss_part, alpha, \
-                     L.e_b, idx, pos_ids, keep, inv_den, p, c, dx_b, dp_b, pos_set, loss_out)
+  hipLaunchKernelGGL((loss_finish_bwd_kernel<V>), grid, block, 0, st, b, d4, lg, L.js, L.ni * L.js, L.de_part, L.loss_part, s.alpha, \
+                     g.e, s.idx ? rows : nullptr, rows, pos_ids, s.keep, s.inv_den, s.p, s.c, s.dx_b, s.dp_b, s.pos_set, s.loss_out)
   if (vpl == 1)
     GSS_FIN(1);
   else if (vpl == 2)

@@ -372,8 +372,12 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
   }
   {
     // every rank takes the same decision: it depends on the knob and the size of the whole graph only
+    // (automatic: large graphs, and not over RCCL -- a subset hop costs a host round trip for the counts (comm->sync: stream drain +
+    // D2H copy), whose price between real devices nobody has measured yet; over RCCL it is opt-in (knob 1) until a multi-GPU run shows
+    // a net gain.  ADVICE round 3.)
     const int knob = K().lazy_halo;
-    p->lz.on = P > 1 && desc->num_layers > 1 && (knob == 1 || (knob < 0 && n_global >= 262144));
+    const bool rccl = comm && comm->device_transport();
+    p->lz.on = P > 1 && desc->num_layers > 1 && (knob == 1 || (knob < 0 && n_global >= 262144 && !rccl));
     p->lzt.on = p->lz.on && spmm_sparse_available();      // (the sparse first backward hop writes nzbits; knob spmm_variant is process-wide)
     auto word_offsets = [&](gss_plan::LazyHalo &z, const gss_plan::Halo &h) {
       if (!z.on) return;
@@ -766,7 +770,7 @@ static BatchView plan_batch_view(gss_plan *p, const int32_t *idx) {
 }
 
 int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float *de_rows, bool top_done, bool wt_ok, void *stream,
-                       int *deferred_slices = nullptr);
+                       int *deferred_slices = nullptr, bool dgrad_done = false);
 
 // prepared (gss_plan_step_lazy): batch_prepare already translated the batch ids and set the batch-position map
 int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta, bool wt_ok, void *stream, BatchView &bv,
@@ -778,33 +782,81 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
   bv = plan_batch_view(p, idx);
   const bool sparse_top = L > 1 && spmm_sparse_available();
   GSS_REQUIRE(p->P == 1 || L == 1 || sparse_top, "a sharded plan needs the balanced SpMM (spmm_variant 2)");
-  float *e_b = nullptr;
-  {
-    // E_B = emb[idx] (model.py:216-217): every shard contributes the rows it owns, one all-reduce assembles them (C3)
-    PROF(GSS_PROF_LOSS);
-    if (plan_batch_mapped(p) && !prepared) {
-      if (int rc = loss_gather_rows_mapped(D.d, p->emb, idx, D.node_map, p->lo, D.n, p->gid2op_t, p->pid, p->rloc, p->keep, b, p->loss_ws, &e_b,
-                                           stream))
-        return rc;
-    } else if (int rc = loss_gather_rows(D.d, p->emb, bv.rows, bv.keep, b, p->loss_ws, &e_b, stream))
-      return rc;
+  const bool mapped = plan_batch_mapped(p);
+  // the batch rows' input gradient rides in the loss kernel's tail where the shapes allow: it needs the transposed weights now
+  const bool want_dgrad = sparse_top && loss_tail_available(D.d, b);
+  if (want_dgrad && !wt_ok) {
+    PROF(GSS_PROF_ELEMENTWISE);
+    if (int rc = transpose2(D.d, p->w1, p->w2, p->w1t, p->w2t, stream)) return rc;
+    wt_ok = true;
   }
-  if (int rc = plan_allreduce(p, e_b, (size_t)b * D.d, stream)) return rc;
+  LossStep s{};
+  s.d = D.d;
+  s.b = b;
+  s.beta = beta;
+  s.alpha = D.alpha;
+  s.loss_out = p->loss;
+  s.inv_den = p->inv_den;
+  s.p = p->p[L - 1];
+  s.c = L > 1 ? D.layer_decay : 1.f;
+  s.dx_b = p->dx_b;
+  s.dp_b = p->dp_b;
+  s.pos_set = (sparse_top && !prepared) ? p->pos : nullptr;
+  s.keep = bv.keep;
+  if (want_dgrad) {
+    s.w1t = p->w1t;
+    s.w2t = p->w2t;
+    s.gax_b = p->gab;
+    s.gam_b = p->gab + (size_t)b * D.d;
+  }
+  if (p->P == 1 && loss_idx_available(b)) {
+    // one GPU: no gather launch -- the sweep fetches the batch rows of the embedding matrix through a row table its prologue builds
+    // (E_B = emb[idx], model.py:216-217), the id translation of a relabelled graph included
+    if (!mapped) {
+      s.idx = idx;
+      s.rows = s.pos_ids = idx;
+    } else if (prepared) {
+      s.idx = p->rloc;
+      s.rows = p->rloc;
+      s.pos_ids = p->pid;
+    } else {
+      s.idx = idx;
+      s.node_map = D.node_map;
+      s.rloc_out = p->rloc;
+      s.pid_out = p->pid;
+    }
+    s.emb = p->emb;
+  } else {
+    float *e_b = nullptr;
+    {
+      // E_B = emb[idx] (model.py:216-217): every shard contributes the rows it owns, one all-reduce assembles them (C3)
+      PROF(GSS_PROF_LOSS);
+      if (mapped && !prepared) {
+        if (int rc = loss_gather_rows_mapped(D.d, p->emb, idx, D.node_map, p->lo, D.n, p->gid2op_t, p->pid, p->rloc, p->keep, b, p->loss_ws, &e_b,
+                                             stream))
+          return rc;
+      } else if (int rc = loss_gather_rows(D.d, p->emb, bv.rows, bv.keep, b, p->loss_ws, &e_b, stream))
+        return rc;
+    }
+    if (int rc = plan_allreduce(p, e_b, (size_t)b * D.d, stream)) return rc;
+    s.e_b = e_b;
+    s.rows = bv.rows;
+    s.pos_ids = bv.ids;
+  }
+  bool dgrad_done = false;
   {
     // loss, dLoss/dE_B and the backward of F.normalize / F.elu on the batch rows (every shard computes the full B x B
     // sweep -- identical bits everywhere, no exchange of the loss -- and keeps the gradient rows it owns)
     PROF(GSS_PROF_LOSS);
-    if (int rc = loss_fused_gathered(D.d, b, beta, D.alpha, p->loss, bv.rows, bv.ids, bv.keep, p->inv_den, p->p[L - 1],
-                                     L > 1 ? D.layer_decay : 1.f, p->dx_b, p->dp_b, (sparse_top && !prepared) ? p->pos : nullptr, p->loss_ws, stream))
-      return rc;
+    if (int rc = loss_step(s, p->loss_ws, stream, &dgrad_done)) return rc;
   }
-  return plan_backward_impl(p, bv, b, nullptr, true, wt_ok, stream, deferred_slices);
+  return plan_backward_impl(p, bv, b, nullptr, true, wt_ok, stream, deferred_slices, dgrad_done);
 }
 
 // deferred_slices != NULL (gss_plan_step): the caller finishes with the fused reduce + Adam kernel, which also resets
 // the batch-position map; the residual of the top layer then rides in the backward SpMM's epilogue
 int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float *de_rows, bool top_done, bool wt_ok, void *stream,
-                       int *deferred_slices) {
+                       int *deferred_slices, bool dgrad_done) {
   GSS_REQUIRE(p && bv.rows, "plan_backward: null argument");
   const gss_plan_desc &D = p->desc;
   GSS_REQUIRE(b >= 1 && b <= D.max_batch, "plan_backward: %d rows out of [1, %d]", b, D.max_batch);
@@ -847,7 +899,7 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
       // sum over the shards (C3) is the batch's gradient
       p->gax_b = p->gab;
       p->gam_b = p->gab + (size_t)b * D.d;
-      {
+      if (!dgrad_done) {   // (else the loss kernel's tail already wrote them)
         PROF(GSS_PROF_DGRAD);
         if (int rc = dense_bwd_input(b, D.d, p->dp_b, p->w1t, p->w2t, nullptr, p->gax_b, p->gam_b, stream)) return rc;
       }

@@ -647,7 +647,11 @@ int gss_ppr_run(gss_ppr *p, double alpha, double tol, int32_t max_iter, double *
     GSS_HIP(hipMemcpyAsync(&active, p->n_active, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GSS_HIP(hipStreamSynchronize(st));
   }
-  if (cur != x) GSS_HIP(hipMemcpyAsync(x, cur, (size_t)D.n * D.kpad * sizeof(double), hipMemcpyDeviceToDevice, st));   // the last iterate, in the caller's buffer
+  // the last iterate, in the caller's buffer: the k real columns only -- a group made of padding columns alone is skipped from the first
+  // iteration on, so the handle's buffer never wrote them; the caller's padding keeps the zeros ppr_init put there
+  if (cur != x)
+    GSS_HIP(hipMemcpy2DAsync(x, (size_t)D.kpad * sizeof(double), cur, (size_t)D.kpad * sizeof(double), (size_t)D.k * sizeof(double), (size_t)D.n,
+                             hipMemcpyDeviceToDevice, st));
   GSS_HIP(hipMemcpyAsync(iters_out, p->iters, (size_t)D.k * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   GSS_HIP(hipStreamSynchronize(st));
   if (active > 0) return fail(GSS_ENOTCONV, "ppr_run: %d of %d columns did not converge in %d iterations", active, D.k, max_iter);

@@ -21,6 +21,7 @@
 #include <memory>
 #include <string>
 #include <system_error>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -189,16 +190,30 @@ void run_parallel(int count, F &&work) {
     if (count == 1) work(0);
     return;
   }
+  // an exception of any item -- thrown on a pool thread or by the inline leftovers -- is parked, every started thread is joined, and the
+  // first one is rethrown on the caller's thread, where GSS_NOTHROW turns it into an error code (the inline loop used
+  // to unwind past joinable threads)
+  std::mutex mu;
+  std::exception_ptr first;
+  auto guarded = [&](int t) {
+    try {
+      work(t);
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!first) first = std::current_exception();
+    }
+  };
   std::vector<std::thread> pool;
   pool.reserve((size_t)count);
   int started = 0;
   try {
-    for (; started < count; ++started) pool.emplace_back(std::ref(work), started);
+    for (; started < count; ++started) pool.emplace_back(guarded, started);
   } catch (const std::system_error &) {
     // started threads keep running; the rest is done here
   }
-  for (int t = started; t < count; ++t) work(t);
+  for (int t = started; t < count; ++t) guarded(t);
   for (auto &th : pool) th.join();
+  if (first) std::rethrow_exception(first);
 }
 
 struct FileCloser {

@@ -51,3 +51,13 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+def record_measured(name, **values):
+    """GSS_RECORD_PARITY=<file>: append what a parity test measured (the figures its tolerances are a stated multiple of) as a JSON line"""
+    path = os.environ.get("GSS_RECORD_PARITY")
+    if not path:
+        return
+    import json
+    with open(path, "a") as f:
+        f.write(json.dumps({"test": name, **{k: float(v) for k, v in values.items()}}) + "\n")

@@ -20,6 +20,7 @@ import threading
 import numpy as np
 import pytest
 
+from conftest import record_measured
 from oracle import gss_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -55,6 +56,7 @@ def _check_grads(got, emb_dev, ref64, tag):
     g_ref = O.backward(cache, O.loss_grad_emb(np.asarray(emb_dev, np.float64), BETA, idx, ALPHA))
     for k in ("W1", "b1", "W2", "b2"):
         scale = np.abs(g64[k]).max()
+        record_measured("configs._check_grads", lin=np.abs(got[k] - g_ref[k]).max() / scale, allfp64=np.abs(got[k] - g64[k]).max() / scale)
         assert np.abs(got[k] - g_ref[k]).max() < 1e-5 * scale + 1e-12, (tag, k, np.abs(got[k] - g_ref[k]).max(), scale)
         assert np.abs(got[k] - g64[k]).max() < 1e-3 * scale + 1e-12, (tag, k, np.abs(got[k] - g64[k]).max(), scale)
 
@@ -348,6 +350,7 @@ def test_config2_downstream_auc_with_the_real_drug_indication_pairs():
         eng.check_guards()
         emb_cpu, loss_cpu = cpu.step(idx.astype(np.int64), beta)
     emb_gpu = eng.emb.cpu().numpy()                                      # the last forward, as train.py:193 writes it
+    record_measured("config2_auc.traj", loss_rel=abs(eng.loss.item() - loss_cpu) / abs(loss_cpu), emb_abs=np.abs(emb_gpu - emb_cpu.numpy()).max())
     assert abs(eng.loss.item() - loss_cpu) < 2e-4 * abs(loss_cpu)
     assert np.abs(emb_gpu - emb_cpu.numpy()).max() < 2e-4
     drugs = [names[i] for i in np.nonzero(ntype == 0)[0]]
@@ -358,6 +361,7 @@ def test_config2_downstream_auc_with_the_real_drug_indication_pairs():
     assert used_g == used_c and len(auc_gpu) == 840
     assert abs(np.median(auc_gpu) - np.median(auc_cpu)) < 1e-4 and abs(auc_gpu.mean() - auc_cpu.mean()) < 1e-4
     delta = np.abs(auc_gpu - auc_cpu)
+    record_measured("config2_auc.auc", max_delta=delta.max(), frac_above_1e4=(delta > 1e-4).mean(), median=abs(np.median(auc_gpu) - np.median(auc_cpu)))
     assert delta.max() < 2e-3 and (delta > 1e-4).mean() < 0.05, (delta.max(), (delta > 1e-4).mean())
     # predict_drug.py:55-73: the drugs ranked for the COVID node
     r_gpu, _ = consumer.rank_by_query(emb_gpu, names, "NodeCovid", drugs)

@@ -1,7 +1,9 @@
 #!/bin/bash
 # usage: pmc_run.sh <tag> "<counters>" <program args...>   (one rocprofv3 --pmc pass with a hard timeout)
 tag=$1; ctrs=$2; shift 2
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc/$tag; rm -rf $O; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+if [ -z "$R" ] || [ ! -f "$R/bench.py" ]; then echo "pmc_run.sh: cannot find the repo root (GRAFT_REPO_ROOT=$GRAFT_REPO_ROOT)"; exit 2; fi
+O=$R/gpurun_out/pmc/$tag; rm -rf "$O"; mkdir -p "$O"
 cd /tmp; export TMPDIR=/tmp
 echo "== $tag [$ctrs]"
 timeout -k 5 ${PMC_TIMEOUT:-300} rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $O -- python3 $R/"$1" "${@:2}" > $O/log.txt 2>&1

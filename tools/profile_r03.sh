@@ -5,6 +5,7 @@
 #   3. memory-side counters of the two forward SpMMs, one counter group per pass (FETCH_SIZE / WRITE_SIZE / TCC hit-miss-req)
 #      -> gpurun_out/pmc/r03_wg_{fwd1,plain}_*  -> tools/pmc_pack_r02.py r03 -> profiles/r03_spmm_pmc.json
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+export GRAFT_REPO_ROOT=$R
 O=$R/gpurun_out/r03; mkdir -p $O
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 cd /tmp; export TMPDIR=/tmp
