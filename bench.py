@@ -490,6 +490,8 @@ def main():
     # more than the un-instrumented step (round 2: 0.340 vs 0.307 ms).  The per-launch overhead is measured -- (sum of the bracketed
     # times - the wall time of the same steps without events) / launches -- and subtracted, so the class times use the SAME timer as
     # the headline and sum to ms_per_step; both the raw and the corrected launch time are reported.
+    if hasattr(engine, "comm_stats"):
+        engine.comm_stats()                  # reset: the counts below are those of the profiled steps
     engine.profile(True)
     run(args.warmup, args.warmup + args.steps)
     prof = engine.profile_read()
@@ -594,11 +596,19 @@ def main():
         halo_bytes_t = (int(shard.layout.halo_at.n_halo) * d * 4) if shard.layout.halo_at is not None else 0
         pair_a = int(np.diff(shard.layout.halo_a.recv_off).max()) * d * 4 if world > 1 else 0
         pair_t = (int(np.diff(shard.layout.halo_at.recv_off).max()) * d * 4) if (world > 1 and shard.layout.halo_at is not None) else 0
-        comm_ms = out["kernel_ms_per_step"].get("comm") or 0.0
+        # the three comm classes use their RAW event brackets: a collective's bracket has no neighbouring kernel gap to correct for
+        comm_cls = {k: prof[k] for k in ("comm", "comm_batch", "comm_grads") if prof.get(k, (0, 0))[1]}
+        comm_ms = sum(v[0] for v in comm_cls.values()) / args.steps
+        stats = engine.comm_stats() if hasattr(engine, "comm_stats") else (0, 0, 0)        # since the last read: the profiled steps
+        out["collectives_per_step"] = {"boundary_row_exchanges": stats[0] / args.steps, "batch_row_allreduces": stats[1] / args.steps,
+                                       "weight_gradient_allreduces": stats[2] / args.steps, "total": sum(stats) / args.steps,
+                                       "us_each": {k: v[0] / v[1] * 1e3 for k, v in comm_cls.items()},
+                                       "note": "gss_plan_comm_stats over the profiled steps; us_each = event bracket around one collective on this "
+                                               "rank's stream (pack kernel + transfer for an exchange), the wait for the slowest peer included"}
         mine = [own_ms_per_step, comm_ms, halo_bytes_a, halo_bytes_t, pair_a, pair_t, out["roofline"]["frac"] if out["roofline"] else 0.0,
                 out["roofline"]["avg_launch_us"] if out["roofline"] else 0.0, n_loc, nnz_loc]
         allv = all_ranks(mine)
-        hops_a, hops_t = 2 * L - 2, max(0, 2 * L - 3)
+        hops_a, hops_t = max(0, 2 * L - 2 - (1 if n < 262144 and L > 1 else 0)), max(0, 2 * L - 3)     # (halo_recompute below 262,144 nodes)
         # a hop is done when its most loaded pair is: every pair has its own xGMI link (8 GPUs fully connected), so the floor per hop
         # is max over pairs of bytes / link rate; the all-reduces (B d, 2 B d and 2 (d^2 + d) floats) are latency-bound and not priced
         ideal_us = (hops_a * allv[:, 4].max() + hops_t * allv[:, 5].max()) / (XGMI_LINK_GBS * 1e9) * 1e6
@@ -615,9 +625,9 @@ def main():
                        "ideal_exchange_us_per_step": ideal_us,
                        "measured_comm_us_per_step_max": float(allv[:, 1].max() * 1e3),
                        "frac_of_link_rate": (ideal_us / (allv[:, 1].max() * 1e3)) if allv[:, 1].max() > 0 else None,
-                       "note": "comm class = pack kernels + the grouped ncclSend/ncclRecv of every halo hop + the three all-reduces of a step "
-                               "(batch rows, their input gradients, the four weight gradients), event-bracketed on each rank's stream: it "
-                               "includes the wait for the slowest peer"}
+                       "note": "comm classes = pack kernels + the grouped ncclSend/ncclRecv of every halo hop + the two all-reduces of a step "
+                               "([E_B | P_B | inv_B] of the batch, the four weight gradients), event-bracketed on each rank's stream: they "
+                               "include the wait for the slowest peer"}
         lh = engine.lazy_halo_rows()
         if lh[3] >= 0:
             # knob lazy_halo (automatic from 262,144 nodes): the backward hop A_hat^T u fetched only the rows of u that can be non-zero

@@ -119,6 +119,7 @@ SIGNATURES = {
     "gss_plan_device_bytes": (_SZ, [_P]),
     "gss_plan_check_guards": (C.c_int, [_P]),
     "gss_plan_lazy_halo_rows": (C.c_int, [_P, C.POINTER(_I64)]),
+    "gss_plan_comm_stats": (C.c_int, [_P, C.POINTER(_I64)]),
     "gss_plan_set_step": (None, [_P, _I32]),
     "gss_plan_adam_buffer": (_P, [_P, _I32, _I32]),
     "gss_plan_get_step": (_I32, [_P]),
@@ -137,7 +138,7 @@ SIGNATURES = {
 
 
 PROF_CLASSES = ("spmm_fwd_hadamard", "spmm_fwd", "spmm_bwd1", "spmm_bwd2", "dense_fwd", "dgrad", "wgrad", "wgrad_batch",
-                "loss", "rownorm", "elementwise", "adam", "comm")
+                "loss", "rownorm", "elementwise", "adam", "comm", "comm_batch", "comm_grads")
 
 
 def build(verbose: bool = False) -> str:

@@ -128,7 +128,8 @@ int gss_debug_set_option(const char *name, int value) {
     return GSS_OK;
   }
   if (strcmp(name, "loss_tail") == 0) {
-    g_knobs.loss_tail = value ? 1 : 0;
+    GSS_REQUIRE(value >= 0 && value <= 2, "loss_tail must be 0, 1 or 2");
+    g_knobs.loss_tail = value;
     return GSS_OK;
   }
   if (strcmp(name, "halo_recompute") == 0) {

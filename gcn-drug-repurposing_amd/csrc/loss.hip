@@ -101,6 +101,39 @@ __global__ __launch_bounds__(256) void gather_rows_mapped_kernel(int b, int d4, 
 // the second product's operand loads removed altogether (wrong results, timing only) 30.6 us -- the sweep is bound by neither its
 // loads nor their waits; 1024 MFMAs per SIMD are 13.7 us at 2.4 GHz and ~16.5 us at the ~2.0 GHz an MFMA-saturated loop sustains
 // (tools/micro/mfma_lds.hip: 126-131 of 157 TFLOP/s), the rest is the fixed start (i-tile fragments) and end (wave tree, partial store).
+// A shard's contribution to the ONE batch collective of a step (round 4): [E_B | P_B | inv_B] -- the embedding row, the top layer's
+// pre-activation row and 1 / ||x|| of every member this shard owns, zeros for the others -- so that after one all-reduce (every element
+// has exactly one non-zero contributor: the sum is the owner's value, bit for bit) every rank holds what the finish needs for EVERY
+// member and computes the batch rows' input gradient locally: the second all-reduce of a step (the [2 B][d] input gradients) is gone.
+// m.idx != NULL: the id translation of gather_rows_mapped_kernel rides along; else rows / keep are the prepared ones.
+__global__ __launch_bounds__(256) void gather_batch_kernel(int b, int d4, const float *__restrict__ e, const float *__restrict__ p,
+                                                           const float *__restrict__ inv_den, BatchMap m, const int32_t *__restrict__ rows,
+                                                           const float *__restrict__ keep, float *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)b * d4) return;
+  const int r = (int)(i / d4), f4 = (int)(i % d4);
+  int rel;
+  bool mine;
+  if (m.idx) {
+    const int id = m.node_map ? m.node_map[m.idx[r]] : m.idx[r];
+    rel = id - m.lo;
+    mine = rel >= 0 && rel < m.nl;
+    if (f4 == 0) {
+      m.rloc[r] = min(max(rel, 0), max(m.nl - 1, 0));
+      if (m.keep) m.keep[r] = mine ? 1.f : 0.f;
+      m.pid[r] = m.gid2op ? m.gid2op[id] : (mine ? rel : -1);
+    }
+  } else {
+    rel = rows[r];
+    mine = !keep || keep[r] != 0.f;
+  }
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t src = ((size_t)rel * d4 + f4) * 4;
+  st4(out + i * 4, mine ? ld4(e + src) : z);
+  st4(out + ((size_t)b * d4 + i) * 4, mine ? ld4(p + src) : z);
+  if (f4 == 0) out[(size_t)2 * b * d4 * 4 + r] = mine ? inv_den[rel] : 0.f;
+}
+
 // One batch row of the finish (shared by loss_finish_bwd_kernel and the sweep's tail -- the same lanes in the same order, so the two
 // forms give the same bits): lane li of the row's lane group (lpr lanes) holds float4s li + 64 k.
 //   de = 2 sum_js de_part; dot = e . de; dx = (de - e dot) * inv; dp = c * dx (.) elu'(p)
@@ -109,7 +142,7 @@ template <int VPL>
 __device__ __forceinline__ void finish_row(bool ok, int r, int li, int lpr, int d4, int js, int b, const float *__restrict__ de_part,
                                            const float *__restrict__ erow, float inv_u, float keepv, const float *__restrict__ prow, float c,
                                            float *__restrict__ dx_b, float *__restrict__ dp_b, float *dp_lds, bool dgrad_all) {
-  float4 g[VPL], ev[VPL];
+  float4 g[VPL], ev[VPL], pv[VPL];
   float dot = 0.f;
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
@@ -124,6 +157,7 @@ __device__ __forceinline__ void finish_row(bool ok, int r, int li, int lpr, int 
     }
     g[k] = s;
     ev[k] = in ? ld4(erow + (size_t)f4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    pv[k] = in ? ld4(prow + (size_t)f4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);   // (with the other operands: one round trip, not two)
     dot += g[k].x * ev[k].x + g[k].y * ev[k].y + g[k].z * ev[k].z + g[k].w * ev[k].w;
   }
   for (int o = 1; o < lpr; o <<= 1) dot += __shfl_xor(dot, o, 64);
@@ -139,7 +173,7 @@ __device__ __forceinline__ void finish_row(bool ok, int r, int li, int lpr, int 
     dx.z = (g[k].z - ev[k].z * dot) * inv;
     dx.w = (g[k].w - ev[k].w * dot) * inv;
     st4(dx_b + ((size_t)r * d4 + f4) * 4, dx);
-    const float4 pg = elu_grad4(ld4(prow + (size_t)f4 * 4));
+    const float4 pg = elu_grad4(pv[k]);
     const float4 dp = scale4(c, mul4(dx, pg));
     st4(dp_b + ((size_t)r * d4 + f4) * 4, dp);
     if (dp_lds) {
@@ -387,8 +421,27 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
   }
   if (!TAIL) return;
 
-  // ---- tail: the last of the tile's js workgroups finishes the tile (every workgroup passes here exactly once: no waiting)
+  // ---- tail: the last of the tile's js workgroups finishes the tile (every workgroup passes here exactly once: no waiting).
+  // A dependent global round trip costs ~1 us on this machine, so the tail is laid out as few of them as possible: [release fence]
+  // [arrival atomic] [one batch of loads: the slabs' partials, E / P rows, 1/||x||, the weight fragments] [compute, stores]; the
+  // job-wide arrival count for the loss travels underneath the compute.
   const LossTail &T = g.t;
+  const int d4 = d / 4;
+  int lg = 2;
+  while ((1 << lg) < d4 && lg < 6) ++lg;
+  const int lpr = 1 << lg, rpw = 64 >> lg;
+  const int li = lane & (lpr - 1);
+  constexpr int RP = 16 / kLossWaves;         // rows of the tile per wave at most (rpw >= 1 rows per pass, kLossWaves * rpw rows per pass and workgroup)
+  // what does not depend on the other slabs is fetched before the arrival is known: the members' rows / keep flags (a few bytes)
+  int nodes[RP];
+  float keeps[RP];
+#pragma unroll
+  for (int k = 0; k < RP; ++k) {
+    const int rr = w * rpw + (lane >> lg) + k * kLossWaves * rpw;
+    const int rc = min(i0 + min(rr, 15), B - 1);
+    nodes[k] = T.rows ? T.rows[rc] : (IDX ? rtab[rc] : rc);
+    keeps[k] = T.keep ? T.keep[rc] : 1.f;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = atomicAdd(&T.tile_cnt[blockIdx.x], 1u);
@@ -398,75 +451,81 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
   __syncthreads();
   if (!s_last) return;
   __threadfence();   // the other slabs' partials, written before their arrival, are read from memory below
-  {
-    const int d4 = d / 4;
-    int lg = 2;
-    while ((1 << lg) < d4 && lg < 6) ++lg;
-    const int lpr = 1 << lg, rpw = 64 >> lg;
-    const int li = lane & (lpr - 1);
-    float *dp_tile = reinterpret_cast<float *>(red);   // [16][d + 4]: the B operand of the input-gradient MFMAs (the tree is done with `red`;
-    const int ds = d + 4;                              // rows 16 B apart in the banks: the 16 rows of a fragment read do not collide)
-    constexpr int VPL = NG <= 4 ? 1 : 2;  // float4s of a row per lane: d4 / 64 rounded up
-    for (int rr = w * rpw + (lane >> lg); rr < 16; rr += kLossWaves * rpw) {
+  // job-wide arrival (the loss is summed by the workgroup that finishes the last tile): the count is requested now and looked at
+  // after the tile is done.  Every slab of this tile fenced its loss partial before it arrived above, and this fence sits between
+  // that observation and this arrival, so whoever sees the last count may read every partial.
+  unsigned all_old = 0;
+  if (threadIdx.x == 0) all_old = atomicAdd(&T.tile_cnt[gridDim.x], 1u);
+  float *dp_tile = reinterpret_cast<float *>(red);   // [16][d + 4]: the B operand of the input-gradient MFMAs (the tree is done with `red`;
+  const int ds = d + 4;                              // rows 16 B apart in the banks: the 16 rows of a fragment read do not collide)
+  constexpr int VPL = NG <= 4 ? 1 : 2;               // float4s of a row per lane: d4 / 64 rounded up
+  constexpr int NTW = 2 * NG;                        // 16-feature blocks per wave: (2 d / 4) / 16 with d = 64 NG
+  constexpr int NCHK = 4 * NG;                       // 16-wide k chunks of the input gradient
+  constexpr bool WREG = NG <= 2;                     // the wave's weight fragments fit the registers the sweep no longer needs
+  const int jw0 = w * 32 * NG;
+  const bool hi = jw0 >= d;
+  const float *wt = T.w1t ? (hi ? T.w2t : T.w1t) + (size_t)((hi ? jw0 - d : jw0) + c) * d + 4 * q : nullptr;
+  float4 wf[WREG ? NCHK : 1][WREG ? NTW : 1];
+  if (WREG && T.w1t) {
+#pragma unroll
+    for (int k = 0; k < NCHK; ++k)
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) wf[k][u] = ld4(wt + (size_t)(16 * u) * d + 16 * k);
+  }
+#pragma unroll
+  for (int k = 0; k < RP; ++k) {
+    const int rr = w * rpw + (lane >> lg) + k * kLossWaves * rpw;   // (the lanes of a row's group share rr: the shuffles inside stay whole)
+    if (rr < 16) {
       const int r = i0 + rr;
       const bool ok = r < B;
       const int rc = ok ? r : B - 1;
-      const int node = T.rows ? T.rows[rc] : (IDX ? rtab[rc] : rc);
-      const float keepv = T.keep ? T.keep[rc] : 1.f;
+      const int node = nodes[k];
       if (ok && T.pos_set && li == 0) {
         const int key = T.pos_ids ? T.pos_ids[r] : node;
         if (key >= 0) T.pos_set[key] = r;
       }
-      finish_row<VPL>(ok, r, li, lpr, d4, g.js, B, g.de_part, erow(rc), T.inv_den[node], keepv, T.p + (size_t)node * d, T.c, T.dx_b, T.dp_b,
+      finish_row<VPL>(ok, r, li, lpr, d4, g.js, B, g.de_part, erow(rc), T.inv_den[node], keeps[k], T.p + (size_t)node * d, T.c, T.dx_b, T.dp_b,
                       T.w1t ? dp_tile + (size_t)rr * ds : nullptr, T.dgrad_all != 0);
       if (!ok && T.w1t)
         for (int f4 = li; f4 < d4; f4 += lpr) *reinterpret_cast<float4 *>(dp_tile + (size_t)rr * ds + f4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (T.w1t) {
-      // [g_ax | g_am][i0 .. i0 + 16) = dP_tile . [W1 ; W2]: wave w takes output features [w d / 2, (w + 1) d / 2) of the 2 d; the k order
-      // (chunk by chunk, e = 0..3 inside) is gemm_nt_lds_kernel's, so the rows keep the bits of the stand-alone launch
-      __syncthreads();
-      constexpr int NTW = 2 * NG;                   // 16-feature blocks per wave: (2 d / 4) / 16 with d = 64 NG
-      const int jw0 = w * 32 * NG;
-      const bool hi = jw0 >= d;
-      const float *wt = (hi ? T.w2t : T.w1t) + (size_t)((hi ? jw0 - d : jw0) + c) * d + 4 * q;
-      const float *brow = dp_tile + (size_t)c * ds + 4 * q;
-      f32x4 o[NTW];
+  }
+  if (T.w1t) {
+    // [g_ax | g_am][i0 .. i0 + 16) = dP_tile . [W1 ; W2]: wave w takes output features [w d / 2, (w + 1) d / 2) of the 2 d; the k order
+    // (chunk by chunk, e = 0..3 inside) is gemm_nt_lds_kernel's, so the rows keep the bits of the stand-alone launch
+    __syncthreads();
+    const float *brow = dp_tile + (size_t)c * ds + 4 * q;
+    f32x4 o[NTW];
 #pragma unroll
-      for (int u = 0; u < NTW; ++u) o[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int kc = 0; kc < d; kc += 16) {
-        const float4 bv = *reinterpret_cast<const float4 *>(brow + kc);
-        float4 av[NTW];
+    for (int u = 0; u < NTW; ++u) o[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < NTW; ++u) av[u] = ld4(wt + (size_t)(16 * u) * d + kc);
+    for (int k = 0; k < NCHK; ++k) {
+      const float4 bv = *reinterpret_cast<const float4 *>(brow + 16 * k);
+      float4 av[NTW];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float bs = e == 0 ? bv.x : e == 1 ? bv.y : e == 2 ? bv.z : bv.w;
+      for (int u = 0; u < NTW; ++u) av[u] = WREG ? wf[k][u] : ld4(wt + (size_t)(16 * u) * d + 16 * k);
 #pragma unroll
-          for (int u = 0; u < NTW; ++u) {
-            const float as = e == 0 ? av[u].x : e == 1 ? av[u].y : e == 2 ? av[u].z : av[u].w;
-            o[u] = mfma16l(as, bs, o[u]);
-          }
+      for (int e = 0; e < 4; ++e) {
+        const float bs = e == 0 ? bv.x : e == 1 ? bv.y : e == 2 ? bv.z : bv.w;
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) {
+          const float as = e == 0 ? av[u].x : e == 1 ? av[u].y : e == 2 ? av[u].z : av[u].w;
+          o[u] = mfma16l(as, bs, o[u]);
         }
       }
-      if (i_ok) {
-        float *out = (hi ? T.gam_b : T.gax_b) + (size_t)(i0 + c) * d + (hi ? jw0 - d : jw0) + 4 * q;
+    }
+    if (i_ok) {
+      float *out = (hi ? T.gam_b : T.gax_b) + (size_t)(i0 + c) * d + (hi ? jw0 - d : jw0) + 4 * q;
 #pragma unroll
-        for (int u = 0; u < NTW; ++u) st4(out + 16 * u, make_float4(o[u][0], o[u][1], o[u][2], o[u][3]));
-      }
+      for (int u = 0; u < NTW; ++u) st4(out + 16 * u, make_float4(o[u][0], o[u][1], o[u][2], o[u][3]));
     }
   }
   // ---- the loss itself: by the workgroup that finishes the last tile (loss_finish_bwd_kernel's sum, same order)
   if (w == 0) {
-    __threadfence();
-    int last_all = 0;
-    if (lane == 0) {
-      const unsigned old = atomicAdd(&T.tile_cnt[gridDim.x], 1u);
-      last_all = old == gridDim.x - 1u;
-      if (last_all) (void)atomicExch(&T.tile_cnt[gridDim.x], 0u);
-    }
+    int last_all = (lane == 0 && all_old == gridDim.x - 1u) ? 1 : 0;
     last_all = __shfl(last_all, 0, 64);
     if (last_all) {
+      if (lane == 0) (void)atomicExch(&T.tile_cnt[gridDim.x], 0u);
       __threadfence();
       const int nloss = (int)(gridDim.x * gridDim.y);
       double t = 0.0;
@@ -517,7 +576,7 @@ __global__ __launch_bounds__(256) void loss_finish_bwd_kernel(int b, int d4, int
   const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + (lane >> lpr_log2);
   const bool ok = r < b;
   const int rc = ok ? r : 0;
-  const int node = idx[rc];
+  const int node = idx ? idx[rc] : rc;   // idx == NULL: inv_den / p are per member (a shard's gathered batch)
   if (blockIdx.x == 0 && threadIdx.x < 64) {
     double t = 0.0;
     for (int k = threadIdx.x; k < nloss; k += 64) t += loss_part[k];
@@ -526,7 +585,7 @@ __global__ __launch_bounds__(256) void loss_finish_bwd_kernel(int b, int d4, int
   }
   // idx: row of inv_den / p (this shard's local row); pos_ids: the id the batch-position map is keyed by (the same array on
   // one GPU, the padded global id on a shard); keep[r] == 0: another shard owns the row -> zero gradient here
-  if (ok && pos_set && li == 0 && pos_ids[r] >= 0) pos_set[pos_ids[r]] = r;
+  if (ok && pos_set && pos_ids && li == 0 && pos_ids[r] >= 0) pos_set[pos_ids[r]] = r;
   const float *erow = e_b + (size_t)(erows ? erows[rc] : rc) * d4 * 4;
   finish_row<VPL>(ok, r, li, lpr, d4, js, b, de_part, erow, inv_den[node], keep ? keep[rc] : 1.f, p + (size_t)node * d4 * 4, c, dx_b, dp_b, nullptr,
                   false);
@@ -713,6 +772,20 @@ int loss_gather_rows_mapped(int32_t d, const float *e, const int32_t *idx, const
   return GSS_OK;
 }
 
+// [E_B | P_B | inv_B] of the members this shard owns into out ([b (2 d + 1)] floats), see gather_batch_kernel
+int loss_gather_batch(int32_t d, const float *e, const float *p, const float *inv_den, const int32_t *idx, const int32_t *node_map, int32_t lo,
+                      int32_t nl, const int32_t *gid2op, int32_t *pid, int32_t *rloc, float *keep, const int32_t *rows, int32_t b, float *out,
+                      void *stream) {
+  if (int rc = check_d(d)) return rc;
+  GSS_REQUIRE(b > 0 && ((e && p && inv_den) || nl == 0) && out && nl >= 0, "loss_gather_batch: null operand or empty batch");
+  GSS_REQUIRE(idx ? (pid && rloc) : (rows != nullptr), "loss_gather_batch: neither a batch to translate nor prepared rows");
+  BatchMap m{idx, node_map, gid2op, lo, nl, pid, rloc, idx ? keep : nullptr};
+  hipLaunchKernelGGL(gather_batch_kernel, dim3(ceil_div((int64_t)b * d / 4, 256)), dim3(256), 0, as_stream(stream), b, d / 4, e, p, inv_den, m, rows,
+                     keep, out);
+  GSS_LAUNCH_CHECK("gather_batch_kernel");
+  return GSS_OK;
+}
+
 int loss_fused_gathered(int32_t d, int32_t b, float beta, float alpha, float *loss_out, const int32_t *idx, const int32_t *pos_ids,
                         const float *keep, const float *inv_den, const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set,
                         void *ws, void *stream) {
@@ -741,7 +814,6 @@ int loss_fused_gathered(int32_t d, int32_t b, float beta, float alpha, float *lo
 int loss_step(const LossStep &s, void *ws, void *stream, bool *dgrad_done) {
   if (int rc = check_d(s.d)) return rc;
   GSS_REQUIRE(s.b > 0 && s.loss_out && s.inv_den && s.p && s.dx_b && s.dp_b && ws && dgrad_done, "loss_step: null operand");
-  GSS_REQUIRE(s.idx || s.rows, "loss_step: neither a batch to translate nor translated rows");
   GSS_REQUIRE(!s.idx || (s.emb && loss_idx_available(s.b)), "loss_step: the row-table form needs the embeddings and b <= %d", kLossIdxMaxBatch);
   hipStream_t st = as_stream(stream);
   const int d = s.d, b = s.b;
@@ -780,9 +852,10 @@ int loss_step(const LossStep &s, void *ws, void *stream, bool *dgrad_done) {
   if (tail) return GSS_OK;
   // separate finish launch (shapes the tail does not cover, or knob loss_tail = 0).  In idx mode the stand-alone kernel reads the
   // rows the sweep's workgroup 0 stored (rloc_out), or the caller's prepared rows
-  const int32_t *rows = s.rows ? s.rows : s.rloc_out;
-  GSS_REQUIRE(rows, "loss_step: the separate finish needs translated rows (rloc_out)");
+  const int32_t *rows = s.rows ? s.rows : s.rloc_out;      // NULL without a row table: inv_den / p are per member
+  GSS_REQUIRE(rows || !s.idx, "loss_step: the separate finish needs translated rows (rloc_out)");
   const int32_t *pos_ids = s.pos_ids ? s.pos_ids : rows;
+  GSS_REQUIRE(pos_ids || !s.pos_set, "loss_step: a batch-position map needs its keys");
   const int d4 = d / 4;
   int lg = 2;
   while ((1 << lg) < d4 && lg < 6) ++lg;

@@ -128,6 +128,9 @@ int loss_fwd_bwd_fused(int32_t n, int32_t d, const float *e, const int32_t *idx,
 int loss_gather_rows(int32_t d, const float *e, const int32_t *rows, const float *keep, int32_t b, void *ws, float **e_b_out, void *stream);
 int loss_gather_rows_mapped(int32_t d, const float *e, const int32_t *idx, const int32_t *node_map, int32_t lo, int32_t nl, const int32_t *gid2op,
                             int32_t *pid, int32_t *rloc, float *keep, int32_t b, void *ws, float **e_b_out, void *stream);
+int loss_gather_batch(int32_t d, const float *e, const float *p, const float *inv_den, const int32_t *idx, const int32_t *node_map, int32_t lo,
+                      int32_t nl, const int32_t *gid2op, int32_t *pid, int32_t *rloc, float *keep, const int32_t *rows, int32_t b, float *out,
+                      void *stream);
 int loss_fused_gathered(int32_t d, int32_t b, float beta, float alpha, float *loss_out, const int32_t *idx, const int32_t *pos_ids,
                         const float *keep, const float *inv_den, const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set,
                         void *ws, void *stream);

@@ -78,7 +78,14 @@ struct gss_plan {
   int32_t *pid, *rloc;     // per batch: operand row in A_hat^T's column space (or -1) / local row (clamped) of every member
   int32_t *rlist;          // shards, gss_plan_step_lazy: per member its local row when this shard owns it, -1 otherwise (the top layer's row list)
   float *keep;             // per batch: 1.0 where this shard owns the member
-  float *gab;              // [2 * max_batch][d]: the top layer's compact input gradients, all-reduced as one buffer
+  float *gab;              // [2 * max_batch][d]: the top layer's compact input gradients (one buffer: one all-reduce where one is needed)
+  float *bx;               // shards: [max_batch (2 d + 1)] = [E_B | P_B | inv_B], the ONE batch collective of a step (loss.hip gather_batch_kernel)
+  // halo_recompute (knob; shards of graphs below 262,144 nodes): layer 1's AX / AM are constants, so their boundary rows are fetched
+  // ONCE and layer 1's projection runs over own + boundary rows -- layer 2's boundary input rows are then computed here (by the same
+  // kernel from the same operands: the owner's bits) instead of exchanged every step.  ax[0] / am[0] / p[0] are operand-sized then.
+  bool recompute;
+  bool l0h_ready;          // the boundary rows of AX_0 / AM_0 have been fetched
+  int64_t n_coll[3];       // collectives enqueued since the last gss_plan_comm_stats: halo exchanges / batch-row / weight-gradient
   // overlapped hops (gss_shard_desc a_own / a_halo / at_own / at_halo): the boundary rows of a hop travel on `xs` while the entries
   // that reference the shard's own rows are multiplied on the caller's stream; the boundary-column entries are added afterwards
   const gss_csr *a_own, *a_halo, *at_own, *at_halo;
@@ -195,9 +202,10 @@ void carve(gss_plan *p, Carver &c) {
   p->p.assign(L, nullptr);
   p->xin.assign(L, nullptr);
   for (int l = 0; l < L; ++l) {
-    p->ax[l] = c.take<float>(nd);
-    p->am[l] = c.take<float>(nd);
-    p->p[l] = c.take<float>(nd);
+    const size_t nd_l = (l == 0 && p->recompute) ? nd_a : nd;   // halo_recompute: layer 1's AX / AM / P also on the boundary rows
+    p->ax[l] = c.take<float>(nd_l);
+    p->am[l] = c.take<float>(nd_l);
+    p->p[l] = c.take<float>(nd_l);
     p->xin[l] = l == 0 ? p->x0op : c.take<float>(nd_a);       // layer inputs are operands of A_hat
   }
   p->m_tmp = c.take<float>(nd_a);
@@ -225,6 +233,7 @@ void carve(gss_plan *p, Carver &c) {
   p->dx_b = c.take<float>(bd);
   p->dp_b = c.take<float>(bd);
   p->gab = L > 1 ? c.take<float>(2 * bd) : nullptr;            // gax_b = gab, gam_b = gab + b * d: one all-reduce
+  p->bx = sharded ? c.take<float>(2 * bd + (size_t)D.max_batch) : nullptr;
   p->gax_b = p->gam_b = nullptr;
   p->pos = L > 1 ? c.take<int32_t>(p->rows_t ? p->rows_t : 1) : nullptr;
   // from sparse_bits_rows operand rows on: the sparse SpMM tests a bitmap before the 4-byte-per-node map (zero-initialised slab)
@@ -391,6 +400,12 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
     word_offsets(p->lz, p->halo_a);
     word_offsets(p->lzt, p->halo_t);
   }
+  {
+    const int knob = K().halo_recompute;
+    p->recompute = P > 1 && desc->num_layers > 1 && (knob == 1 || (knob < 0 && n_global < 262144));
+    p->l0h_ready = false;
+    p->n_coll[0] = p->n_coll[1] = p->n_coll[2] = 0;
+  }
   Carver sizing;
   carve(p, sizing);
   p->slab_bytes = sizing.off + 256;
@@ -504,6 +519,7 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
 int plan_halo(gss_plan *p, const gss_plan::Halo &h, float *op, void *stream) {
   if (p->P == 1) return GSS_OK;
   PROF(GSS_PROF_COMM);
+  p->n_coll[0] += 1;
   const int d = p->desc.d;
   if (h.n_send > 0)
     if (int rc = pack_rows(d, op, h.d_send_rows, h.n_send, p->sendbuf, stream)) return rc;
@@ -523,6 +539,7 @@ int plan_halo(gss_plan *p, const gss_plan::Halo &h, float *op, void *stream) {
 int plan_halo_requests(gss_plan *p, gss_plan::LazyHalo &z, const gss_plan::Halo &h, const gss_csr *a, const int32_t *need_rows, int32_t b,
                        const uint32_t *src_bits, void *stream) {
   PROF(GSS_PROF_COMM);
+  p->n_coll[0] += 1;
   const int P = p->P, n = p->desc.n;
   const size_t P1 = (size_t)P + 1;
   hipStream_t st = as_stream(stream);
@@ -558,6 +575,7 @@ int plan_halo_requests(gss_plan *p, gss_plan::LazyHalo &z, const gss_plan::Halo 
 // boundary rows' bits become exactly the rows that arrive.
 int plan_halo_transfer(gss_plan *p, gss_plan::LazyHalo &z, const gss_plan::Halo &h, float *op, uint32_t *set_bits, void *stream) {
   PROF(GSS_PROF_COMM);
+  p->n_coll[0] += 1;
   const int P = p->P, d = p->desc.d, n = p->desc.n;
   const int64_t *send_off = z.h_cnt, *recv_off = z.h_cnt + (size_t)P + 1;
   if (int rc = pack_rows(d, op, z.send_list, send_off[P], p->sendbuf, stream)) return rc;
@@ -604,14 +622,16 @@ int plan_hop(gss_plan *p, const gss_plan::Halo &h, bool overlapped, float *op, v
 
 int plan_allreduce(gss_plan *p, float *buf, size_t count, void *stream) {
   if (p->P == 1 || count == 0) return GSS_OK;
-  PROF(GSS_PROF_COMM);
+  PROF(GSS_PROF_COMM_BATCH);
+  p->n_coll[1] += 1;
   return p->comm->all_reduce_sum(&buf, &count, 1, as_stream(stream));
 }
 
 // C2: the four weight-gradient tensors summed over the shards, one fused collective
 int plan_allreduce_grads(gss_plan *p, void *stream) {
   if (p->P == 1) return GSS_OK;
-  PROF(GSS_PROF_COMM);
+  PROF(GSS_PROF_COMM_GRADS);
+  p->n_coll[2] += 1;
   const gss_plan_desc &D = p->desc;
   const size_t cnt[4] = {(size_t)D.d * D.d, (size_t)D.d, (size_t)D.d * D.d, (size_t)D.d};
   return p->comm->all_reduce_sum(p->grad, cnt, 4, as_stream(stream));
@@ -694,7 +714,9 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
           PROF(GSS_PROF_SPMM_FWD_HAD);
           return spmm_fwd(p->a, D.d, xl, p->ax[l], xl, m, stream, nullptr, rbits);
         };
-        if (l == 0) {   // the boundary rows of X_0 are constants, fetched once by plan_x0: nothing to exchange, nothing to overlap
+        if (l == 0 || (l == 1 && p->recompute)) {
+          // the boundary rows of X_0 are constants, fetched once by plan_x0; those of X_1 were computed by layer 1's projection
+          // (halo_recompute): nothing to exchange, nothing to overlap
           if (int rc = full()) return rc;
         } else {
           auto own = [&]() {
@@ -731,6 +753,13 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
         }
       }
       if (l == 0) p->layer1_valid = true;   // (the lazy top layer is never layer 1: gss_plan_step_lazy needs two layers)
+      if (l == 0 && p->recompute && !p->l0h_ready) {
+        // AX_0 / AM_0 are functions of A_hat and X alone: their boundary rows are fetched once (the own rows above them are rewritten
+        // with the same values every step)
+        if (int rc = plan_halo(p, p->halo_a, p->ax[0], stream)) return rc;
+        if (int rc = plan_halo(p, p->halo_a, p->am[0], stream)) return rc;
+        p->l0h_ready = true;
+      }
     }
     PROF(GSS_PROF_DENSE_FWD);
     if (l == L - 1 && dense_fwd_norm_available(D.d)) {
@@ -744,7 +773,9 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
 
     float *xn = (l == L - 1) ? p->x_last : p->xin[l + 1];
     const bool listed = lazy_rows && l == L - 1;
-    if (int rc = dense_fwd(listed ? lazy_b : D.n, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr,
+    // halo_recompute: layer 1's projection also produces the boundary rows of layer 2's input (l == 0 < L - 1 there)
+    const int32_t n_proj = (l == 0 && p->recompute) ? (int32_t)p->rows_a : D.n;
+    if (int rc = dense_fwd(listed ? lazy_b : n_proj, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr,
                            D.layer_decay, p->p[l], xn, stream, listed ? lazy_rows : nullptr))
       return rc;
   }
@@ -784,7 +815,7 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
   GSS_REQUIRE(p->P == 1 || L == 1 || sparse_top, "a sharded plan needs the balanced SpMM (spmm_variant 2)");
   const bool mapped = plan_batch_mapped(p);
   // the batch rows' input gradient rides in the loss kernel's tail where the shapes allow: it needs the transposed weights now
-  const bool want_dgrad = sparse_top && loss_tail_available(D.d, b);
+  const bool want_dgrad = sparse_top && loss_tail_available(D.d, b) && K().loss_tail == 1;
   if (want_dgrad && !wt_ok) {
     PROF(GSS_PROF_ELEMENTWISE);
     if (int rc = transpose2(D.d, p->w1, p->w2, p->w1t, p->w2t, stream)) return rc;
@@ -826,10 +857,28 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
       s.pid_out = p->pid;
     }
     s.emb = p->emb;
+  } else if (p->P > 1) {
+    // shards: ONE batch collective.  Every shard contributes [E_B | P_B | inv_B] of the members it owns (zeros elsewhere); after the
+    // all-reduce (C3; one non-zero contributor per element: exact) every rank holds the whole batch's rows of the embeddings
+    // (model.py:216-217), of the top layer's pre-activation and its 1 / ||x||, runs the same B x B sweep (identical bits everywhere,
+    // no exchange of the loss) and the finish + input gradient of EVERY member: the [2 B][d] input gradients need no second collective
+    {
+      PROF(GSS_PROF_LOSS);
+      if (int rc = loss_gather_batch(D.d, p->emb, p->p[L - 1], p->inv_den, prepared ? nullptr : idx, D.node_map, p->lo, D.n, p->gid2op_t, p->pid,
+                                     p->rloc, p->keep, bv.rows, b, p->bx, stream))
+        return rc;
+    }
+    if (int rc = plan_allreduce(p, p->bx, (size_t)b * (2 * D.d + 1), stream)) return rc;
+    s.e_b = p->bx;
+    s.p = p->bx + (size_t)b * D.d;
+    s.inv_den = p->bx + (size_t)2 * b * D.d;
+    s.rows = nullptr;                       // p / inv_den are per member
+    s.pos_ids = bv.ids;
+    s.dgrad_all = true;
   } else {
     float *e_b = nullptr;
     {
-      // E_B = emb[idx] (model.py:216-217): every shard contributes the rows it owns, one all-reduce assembles them (C3)
+      // E_B = emb[idx] (model.py:216-217) by a gather launch (batches the sweep's row table does not hold)
       PROF(GSS_PROF_LOSS);
       if (mapped && !prepared) {
         if (int rc = loss_gather_rows_mapped(D.d, p->emb, idx, D.node_map, p->lo, D.n, p->gid2op_t, p->pid, p->rloc, p->keep, b, p->loss_ws, &e_b,
@@ -838,7 +887,6 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
       } else if (int rc = loss_gather_rows(D.d, p->emb, bv.rows, bv.keep, b, p->loss_ws, &e_b, stream))
         return rc;
     }
-    if (int rc = plan_allreduce(p, e_b, (size_t)b * D.d, stream)) return rc;
     s.e_b = e_b;
     s.rows = bv.rows;
     s.pos_ids = bv.ids;
@@ -850,6 +898,7 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
     PROF(GSS_PROF_LOSS);
     if (int rc = loss_step(s, p->loss_ws, stream, &dgrad_done)) return rc;
   }
+  // (a shard whose loss kernel had no tail -- widths outside {64, 128, 256} -- falls back to the masked input gradient + its all-reduce)
   return plan_backward_impl(p, bv, b, nullptr, true, wt_ok, stream, deferred_slices, dgrad_done);
 }
 
@@ -903,7 +952,8 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
         PROF(GSS_PROF_DGRAD);
         if (int rc = dense_bwd_input(b, D.d, p->dp_b, p->w1t, p->w2t, nullptr, p->gax_b, p->gam_b, stream)) return rc;
       }
-      if (int rc = plan_allreduce(p, p->gab, (size_t)2 * b * D.d, stream)) return rc;
+      if (!dgrad_done)     // the tail's input gradient covers every member on every rank (LossStep.dgrad_all): nothing to sum
+        if (int rc = plan_allreduce(p, p->gab, (size_t)2 * b * D.d, stream)) return rc;
       if (p->posbits) {
         PROF(GSS_PROF_ELEMENTWISE);
         if (int rc = batch_bits(bv.ids, b, p->posbits, 1, stream)) return rc;
@@ -1210,6 +1260,15 @@ int gss_plan_lazy_halo_rows(const gss_plan *p, int64_t *out6) {
   out6[3] = p->lzt.on ? p->lzt.last_recv : -1;
   out6[4] = p->lzt.on ? p->lzt.last_send : -1;
   out6[5] = p->halo_t.n_halo;
+  return GSS_OK;
+}
+
+int gss_plan_comm_stats(gss_plan *p, int64_t *out3) {
+  GSS_REQUIRE(p && out3, "plan_comm_stats: null argument");
+  for (int k = 0; k < 3; ++k) {
+    out3[k] = p->n_coll[k];
+    p->n_coll[k] = 0;
+  }
   return GSS_OK;
 }
 

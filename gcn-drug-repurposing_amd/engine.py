@@ -183,5 +183,13 @@ class GssEngine:
         _lib.check(self.lib.gss_plan_lazy_halo_rows(self.handle, out), "gss_plan_lazy_halo_rows")
         return tuple(int(v) for v in out)
 
+    def comm_stats(self):
+        """collectives the plan has enqueued since the last call (gss_plan_comm_stats): (boundary-row exchanges, batch-row all-reduces,
+        weight-gradient all-reduces); zeros on one GPU"""
+        import ctypes as C
+        out = (C.c_int64 * 3)()
+        _lib.check(self.lib.gss_plan_comm_stats(self.handle, out), "gss_plan_comm_stats")
+        return tuple(int(v) for v in out)
+
     def device_bytes(self) -> int:
         return int(self.lib.gss_plan_device_bytes(self.handle))

@@ -398,6 +398,11 @@ int gss_plan_step_lazy(gss_plan *p, const int32_t *idx, int32_t b, float beta, v
  * exchanges moved: {rows fetched, rows sent, rows of the whole halo} for (1) and then for (2); fetched / sent are -1 when the plan
  * exchanges whole halos. */
 int gss_plan_lazy_halo_rows(const gss_plan *p, int64_t *out6);
+/* Collectives a sharded plan has enqueued since the last call (then reset): out3 = {boundary-row exchanges, batch-row all-reduces,
+ * weight-gradient all-reduces}.  A steady full step at L layers: 2L - 2 + 2L - 3 exchanges (one less with halo_recompute: layer 2's
+ * boundary input rows are recomputed from layer 1's constant AX / AM), 1 batch-row all-reduce ([E_B | P_B | inv_B] as one buffer; 2
+ * where the loss kernel has no tail), 1 weight-gradient all-reduce.  All zeros on one GPU. */
+int gss_plan_comm_stats(gss_plan *p, int64_t *out3);
 /* layer activations for parity tests: which 0 AX, 1 AM, 2 P of layer `layer` (0-based) */
 const float *gss_plan_activation(const gss_plan *p, int layer, int which);
 size_t gss_plan_device_bytes(const gss_plan *p);
@@ -426,8 +431,10 @@ enum {
   GSS_PROF_ROWNORM = 9,
   GSS_PROF_ELEMENTWISE = 10, /* norm/ELU backward on batch rows, transposes, memsets, scatter */
   GSS_PROF_ADAM = 11,
-  GSS_PROF_COMM = 12,        /* sharded plans: all-gathers / all-reduces */
-  GSS_PROF_CLASSES = 13
+  GSS_PROF_COMM = 12,        /* sharded plans: boundary-row exchanges of the SpMM hops (pack kernel + grouped send / recv) */
+  GSS_PROF_COMM_BATCH = 13,  /* sharded plans: the batch-row all-reduce(s) of the loss */
+  GSS_PROF_COMM_GRADS = 14,  /* sharded plans: the all-reduce of the four weight gradients */
+  GSS_PROF_CLASSES = 15
 };
 int gss_plan_profile(gss_plan *p, int enable);
 int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void *stream);
@@ -445,7 +452,12 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
  * footprint), "wgrad_variant" = 1 (default) / 2 (operands through an LDS-DMA ring), "ppr_fused" = 1 (default) / 0 (separate update
  * pass of the diffusion profiles); "gemm_rows_split" = 1 (default) / 0: the forward projection over a short row list (lazy step)
  * by four waves per 16 rows that split the features / by one wave; "lazy_halo" = -1 (default: graphs of >= 262,144 nodes) / 0 / 1: sharded plans fetch subsets of the
- * boundary rows where a hop reads a subset (gss_plan_lazy_halo_rows; every rank of a job must use the same value).  Every setting computes the same results (some in a different summation order); the defaults are
+ * boundary rows where a hop reads a subset (gss_plan_lazy_halo_rows; every rank of a job must use the same value; over RCCL the
+ * automatic choice is "never" until a multi-GPU run has priced its host round trip); "halo_recompute" = -1 (default: graphs below
+ * 262,144 nodes) / 0 / 1: sharded plans recompute layer 2's boundary input rows from layer 1's constant AX / AM (fetched once)
+ * instead of exchanging them every step (same bits; every rank of a job must use the same value); "loss_idx", "loss_tail" = 1
+ * (default) / 0: the batch-row gather as the loss sweep's prologue / finish + batch-row input gradient as its tail (same bits, two
+ * to three launches fewer per step).  Every setting computes the same results (some in a different summation order); the defaults are
  * the measured optima recorded in DESIGN.md section 4.  The values are process-wide DEFAULTS: a plan (and a gss_ppr handle) takes a
  * snapshot when it is created and runs under it from then on, so changing a knob never re-shapes a live plan -- in particular not
  * the plans of other rank threads of the same process; per-op entry points read the current defaults. */

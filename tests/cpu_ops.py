@@ -150,6 +150,7 @@ class GlooComm:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.rows_received = 0          # rows of all exchange_rows calls (what a step moves over the links)
         self.exchanges = 0
+        self.allreduces = 0
 
     def abort(self):
         pass
@@ -192,6 +193,7 @@ class GlooComm:
 
     def all_reduce_sum_(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self.allreduces += 1
 
 
 def emulate_ppr(prob, alpha, tol, max_iter):

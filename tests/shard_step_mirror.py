@@ -10,9 +10,11 @@ the data layout and the order of the exchange points, line by line:
   operand = [n own rows | n_halo boundary rows grouped by owner]         plan.hip header, carve()
   plan_halo: pack rows send_rows[0..n_send) -> exchange_rows(send_off, recv_off) -> operand[n:]      plan.hip plan_halo
   X_0's and M_0's boundary rows fetched once (constants)                  plan_x0, m0_ready
-  E_B = sum over shards of (own rows of emb[batch] | 0)                   C3, plan_loss_backward_impl
-  batch maps: rloc / keep / pid = gid2op_t[node_map[idx]]                 loss.hip gather_rows_mapped_kernel
-  compact [2B][d] input gradients all-reduced, sparse first hop           plan_backward_impl (sparse_top)
+  halo_recompute (graphs below 262,144 nodes): AX_0 / AM_0 boundary rows fetched once, layer 1's projection over own + boundary
+      rows, so layer 2's boundary input rows are computed here instead of exchanged                      plan_forward_impl (recompute)
+  ONE batch collective: [E_B | P_B | inv_B] = sum over shards of (own rows | 0)                           C3, plan_loss_backward_impl
+  batch maps: rloc / keep / pid = gid2op_t[node_map[idx]]                 loss.hip gather_batch_kernel
+  finish + input gradient of EVERY member on every rank (no second collective), sparse first hop         loss.hip tail, plan_backward_impl
   halo of u (A_hat^T's halo) before every second hop                      plan_backward_impl
   four weight gradients summed over the shards, then Adam                 plan_step_impl (P > 1 branch)
 
@@ -54,6 +56,8 @@ class ShardStepMirror:
         self.ops = NumpyOps()
         self.x0op = None
         self.m0op = None
+        self.recompute = self.P > 1 and self.L > 1 and self.n_global < 262144      # knob halo_recompute, automatic choice
+        self.ax0op = self.am0op = None
         self.loss = None
         self.emb = None
 
@@ -92,6 +96,8 @@ class ShardStepMirror:
                     self.x0op = self._operand(self.ha, self.x)
                     self._halo(self.ha, self.x0op)
                 xl = self.x0op
+            elif l == 1 and self.recompute:
+                xl = x_op                                              # boundary rows computed by layer 1's projection below
             else:
                 xl = self._operand(self.ha, x_own)
                 self._halo(self.ha, xl)
@@ -107,7 +113,18 @@ class ShardStepMirror:
                 m = self._operand(self.ha, m_own)
                 self._halo(self.ha, m)
             am = self._spmm(self.a, m)                                  # model.py:169
-            p, xn = self.ops.dense_fwd(torch.from_numpy(ax), torch.from_numpy(am), self.params, p_prev, self.decay)
+            if l == 0 and self.recompute:
+                # AX_0 / AM_0 are constants: boundary rows fetched once; the projection runs over own + boundary rows
+                if self.ax0op is None:
+                    self.ax0op, self.am0op = self._operand(self.ha, ax), self._operand(self.ha, am)
+                    self._halo(self.ha, self.ax0op)
+                    self._halo(self.ha, self.am0op)
+                self.ax0op[:n], self.am0op[:n] = ax, am
+                p_op, x_op = self.ops.dense_fwd(torch.from_numpy(self.ax0op), torch.from_numpy(self.am0op), self.params, None, self.decay)
+                x_op = x_op.numpy()
+                p, xn = p_op[:n], torch.from_numpy(x_op[:n])
+            else:
+                p, xn = self.ops.dense_fwd(torch.from_numpy(ax), torch.from_numpy(am), self.params, p_prev, self.decay)
             self.act.append({"xin": xl, "ax": ax, "am": am, "p": p.numpy()})
             x_own, p_prev = xn.numpy(), p
         e, inv = self.ops.rownorm_fwd(torch.from_numpy(x_own))         # model.py:205
@@ -131,24 +148,29 @@ class ShardStepMirror:
         b = len(idx)
         rloc, mine, pid = self._batch_maps(idx)
         keep = mine.astype(np.float64)[:, None]
-        e_b = np.zeros((b, d), dtype=np.float32)
+        top = self.act[L - 1]
+        # gather_batch_kernel: [E_B | P_B | inv_B] of the members this shard owns, zeros elsewhere; ONE all-reduce (C3) -- one non-zero
+        # contributor per element -- leaves every rank with the whole batch's rows
+        bx = np.zeros((b, 2 * d + 1), dtype=np.float32)
         if n > 0:
-            e_b[mine] = self.emb[rloc[mine]]
-        e_b = torch.from_numpy(e_b)
-        self.comm.all_reduce_sum_(e_b)                                 # C3: every rank assembles the batch rows
+            bx[mine, :d] = self.emb[rloc[mine]]
+            bx[mine, d:2 * d] = top["p"][rloc[mine]]
+            bx[mine, 2 * d] = self.inv_den[rloc[mine]]
+        bx = torch.from_numpy(bx)
+        self.comm.all_reduce_sum_(bx)
+        e_b = bx[:, :d].contiguous()
         loss, de_b = self.ops.loss_fwd_bwd(e_b, beta, self.alpha)      # model.py:218-221 (+ autograd); the same on every rank
         self.loss = loss
-        top = self.act[L - 1]
         c_top = self.decay if L > 1 else 1.0
-        # loss_finish_bwd_kernel: backward of F.normalize and F.elu on the batch rows, zero where another shard owns the row
+        # the sweep's tail: backward of F.normalize and F.elu on EVERY member (this rank holds p / inv_den of all of them); the rows
+        # another shard owns are zero in dx_b / dp_b (the weight gradient and the residual count each member once, at its owner) but
+        # take part in the input gradient below
         de, eb = de_b.numpy().astype(np.float64), e_b.numpy().astype(np.float64)
-        if n > 0:
-            inv = self.inv_den[rloc].astype(np.float64)[:, None] * keep
-            dx_b = _f32((de - eb * (eb * de).sum(1, keepdims=True)) * inv)
-            dp_b = _f32(c_top * dx_b * _elu_grad(top["p"][rloc].astype(np.float64)))
-        else:
-            dx_b = np.zeros((b, d), np.float32)
-            dp_b = np.zeros((b, d), np.float32)
+        inv_all = bx[:, 2 * d].numpy().astype(np.float64)[:, None]
+        dx_all = _f32((de - eb * (eb * de).sum(1, keepdims=True)) * inv_all)
+        dp_all = _f32(c_top * dx_all * _elu_grad(bx[:, d:2 * d].numpy().astype(np.float64)))
+        dx_b = _f32(dx_all * keep)
+        dp_b = _f32(dp_all * keep)
         w1, b1, w2, b2 = [p.numpy().astype(np.float64) for p in self.params]
         # weight gradients: fixed order top layer (batch rows) first, then the layers below; summed over the shards at the end
         gw1 = np.zeros((d, d))
@@ -165,10 +187,8 @@ class ShardStepMirror:
         if n > 0:
             wgrad(dp_b, top["ax"][rloc], top["am"][rloc])
         if L > 1:
-            # compact input gradients of the batch rows (dense_bwd_input with the transposed weights), summed over the shards (C3)
-            gab = torch.from_numpy(_f32(np.concatenate([dp_b.astype(np.float64) @ w1, dp_b.astype(np.float64) @ w2])))
-            self.comm.all_reduce_sum_(gab)
-            gax_b, gam_b = gab[:b].numpy(), gab[b:].numpy()
+            # compact input gradients of ALL batch rows, computed locally on every rank (the loss kernel's tail): no collective
+            gax_b, gam_b = _f32(dp_all.astype(np.float64) @ w1), _f32(dp_all.astype(np.float64) @ w2)
             # batch-position map over A_hat^T's operand rows (own rows first, then its halo)
             rows_t = n + (self.ht.n_halo if self.P > 1 else 0)
             pos = np.full(max(rows_t, 1), -1, dtype=np.int64)

@@ -69,16 +69,17 @@ def _worker(rank, world, port, case, relabel, out_dir):
                 assert sorted(both.tolist()) == sorted(full.m.indices[full.m.indptr[r]:full.m.indptr[r + 1]].tolist())
         eng = ShardStepMirror(shard, shard_rows(shard, g["X"]), golden_params(g, "init"), comm, num_layers=L, layer_decay=float(g["decay"]),
                               alpha=float(g["alpha"]), lr=float(g["lr"]))
-        losses, ex_per_step, rows_per_step = [], [], []
+        losses, ex_per_step, rows_per_step, ar_per_step = [], [], [], []
         for idx in golden_batches(g):
-            e0, r0 = comm.exchanges, comm.rows_received
+            e0, r0, a0 = comm.exchanges, comm.rows_received, comm.allreduces
             eng.step(idx, float(g["beta"]))
             losses.append(float(eng.loss.item()))
             ex_per_step.append(comm.exchanges - e0)
             rows_per_step.append(comm.rows_received - r0)
+            ar_per_step.append(comm.allreduces - a0)
         emb = eng.gather_embeddings()
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), losses=np.array(losses), emb=emb, lo=lo, hi=hi, ex=np.array(ex_per_step),
-                 rows=np.array(rows_per_step), halo_a=lay.halo_a.n_halo, halo_t=lay.halo_at.n_halo if lay.halo_at is not None else 0,
+                 rows=np.array(rows_per_step), ar=np.array(ar_per_step), halo_a=lay.halo_a.n_halo, halo_t=lay.halo_at.n_halo if lay.halo_at is not None else 0,
                  send_a=int(lay.halo_a.send_off[-1]), send_t=int(lay.halo_at.send_off[-1]) if lay.halo_at is not None else 0,
                  **{k: p.numpy() for k, p in zip(("W1", "b1", "W2", "b2"), eng.params)})
     finally:
@@ -105,11 +106,15 @@ def test_product_shards_as_gloo_processes_match_reference_trajectory(tmp_path, w
     for k in ("W1", "b1", "W2", "b2"):
         assert np.abs(outs[0][k] - g["final_" + k]).max() < T.TRAJ_WEIGHT_LR * float(g["lr"])
     # what the step moves is what the halo layout announces (include/gssgcn.h, gss_plan_create_sharded): per step 2L - 2 exchanges of
-    # A_hat's halo + 2L - 3 of A_hat^T's; the first step also fetches the constant boundary rows of X_0 and M_0
-    steady = (2 * L - 2) + max(0, 2 * L - 3)
+    # A_hat's halo -- one less with halo_recompute (these graphs: layer 2's boundary input rows are computed, not fetched) -- + 2L - 3
+    # of A_hat^T's; the first step also fetches the constant boundary rows of X_0 and M_0 and, with halo_recompute, of AX_0 and AM_0
+    rec = 1 if L > 1 else 0
+    hops_a = 2 * L - 2 - rec
+    steady = hops_a + max(0, 2 * L - 3)
     for o in outs:
-        assert o["ex"][0] == steady + 2 and all(int(e) == steady for e in o["ex"][1:])
-        assert int(o["rows"][1]) == (2 * L - 2) * int(o["halo_a"]) + max(0, 2 * L - 3) * int(o["halo_t"])
+        assert o["ex"][0] == steady + 2 + 2 * rec and all(int(e) == steady for e in o["ex"][1:])
+        assert int(o["rows"][1]) == hops_a * int(o["halo_a"]) + max(0, 2 * L - 3) * int(o["halo_t"])
+        assert all(int(a) == 2 for a in o["ar"])           # all-reduces per step: [E_B | P_B | inv_B], the four weight gradients
     # every row a shard receives is a row a peer sends
     assert sum(int(o["halo_a"]) for o in outs) == sum(int(o["send_a"]) for o in outs)
     assert sum(int(o["halo_t"]) for o in outs) == sum(int(o["send_t"]) for o in outs)

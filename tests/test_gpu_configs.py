@@ -20,6 +20,7 @@ import threading
 import numpy as np
 import pytest
 
+import tolerances as T
 from conftest import record_measured
 from oracle import gss_oracle as O
 
@@ -58,7 +59,9 @@ def _check_grads(got, emb_dev, ref64, tag):
         scale = np.abs(g64[k]).max()
         record_measured("configs._check_grads", lin=np.abs(got[k] - g_ref[k]).max() / scale, allfp64=np.abs(got[k] - g64[k]).max() / scale)
         assert np.abs(got[k] - g_ref[k]).max() < 1e-5 * scale + 1e-12, (tag, k, np.abs(got[k] - g_ref[k]).max(), scale)
-        assert np.abs(got[k] - g64[k]).max() < 1e-3 * scale + 1e-12, (tag, k, np.abs(got[k] - g64[k]).max(), scale)
+        # all-fp64: measured <= 2.5e-7 of scale on these workloads (gpurun_out r4a, GSS_RECORD_PARITY); 1e-5 = 40 x that, the same bound
+        # as the linearised check -- a similarity within fp32 rounding of the relu's kink would show up here first
+        assert np.abs(got[k] - g64[k]).max() < 1e-5 * scale + 1e-12, (tag, k, np.abs(got[k] - g64[k]).max(), scale)
 
 
 @pytest.fixture(scope="module")
@@ -351,8 +354,10 @@ def test_config2_downstream_auc_with_the_real_drug_indication_pairs():
         emb_cpu, loss_cpu = cpu.step(idx.astype(np.int64), beta)
     emb_gpu = eng.emb.cpu().numpy()                                      # the last forward, as train.py:193 writes it
     record_measured("config2_auc.traj", loss_rel=abs(eng.loss.item() - loss_cpu) / abs(loss_cpu), emb_abs=np.abs(emb_gpu - emb_cpu.numpy()).max())
-    assert abs(eng.loss.item() - loss_cpu) < 2e-4 * abs(loss_cpu)
-    assert np.abs(emb_gpu - emb_cpu.numpy()).max() < 2e-4
+    # measured after the 30 steps (round 4, GSS_RECORD_PARITY): loss identical to the CPU port's, max |emb difference| 5.4e-7 (8.2e-7 in
+    # round 3); the bounds are tests/tolerances.py's for a trajectory (10 x the spread between CPU executions), 1e-5 = 12-18 x measured
+    assert abs(eng.loss.item() - loss_cpu) < T.TRAJ_LOSS_RTOL * abs(loss_cpu)
+    assert np.abs(emb_gpu - emb_cpu.numpy()).max() < 1e-5
     drugs = [names[i] for i in np.nonzero(ntype == 0)[0]]
     inds = [names[i] for i in np.nonzero(ntype == 1)[0] if names[i] != "NodeCovid"]
     positives = synth.standin_drug_indications()
@@ -362,7 +367,9 @@ def test_config2_downstream_auc_with_the_real_drug_indication_pairs():
     assert abs(np.median(auc_gpu) - np.median(auc_cpu)) < 1e-4 and abs(auc_gpu.mean() - auc_cpu.mean()) < 1e-4
     delta = np.abs(auc_gpu - auc_cpu)
     record_measured("config2_auc.auc", max_delta=delta.max(), frac_above_1e4=(delta > 1e-4).mean(), median=abs(np.median(auc_gpu) - np.median(auc_cpu)))
-    assert delta.max() < 2e-3 and (delta > 1e-4).mean() < 0.05, (delta.max(), (delta > 1e-4).mean())
+    # the north star's bound on EVERY indication (measured: largest difference 3.6e-5 = one swapped pair of near-equal scores, 0 of
+    # 840 above 1e-4); one positive and one negative drug swapping places moves an indication's AUC by 1 / (n_pos n_neg) <= 1.2e-4 / n_pos
+    assert delta.max() < 1e-4, (delta.max(), (delta > 1e-4).mean())
     # predict_drug.py:55-73: the drugs ranked for the COVID node
     r_gpu, _ = consumer.rank_by_query(emb_gpu, names, "NodeCovid", drugs)
     r_cpu, _ = consumer.rank_by_query(emb_cpu.numpy(), names, "NodeCovid", drugs)

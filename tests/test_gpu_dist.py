@@ -525,3 +525,74 @@ def test_trainer_checkpoint_resume_on_the_sharded_path(tmp_path):
     run(["--epochs", "4", "--out", str(tmp_path / "s.txt")], dict(os.environ))
     assert (tmp_path / "a.txt").read_bytes() == (tmp_path / "b.txt").read_bytes()
     assert (tmp_path / "a.txt").read_bytes() == (tmp_path / "s.txt").read_bytes()       # world = 1 shard == plain plan, bit for bit
+
+
+@pytest.mark.parametrize("world,case,recompute", [(2, "edge_n600_d128_L2", -1), (3, "edge_n600_d128_L2", 0), (3, "knn_n2000_d64_L3", -1),
+                                                  (2, "knn_n200_d16_L2", -1)])
+def test_sharded_step_enqueues_the_announced_collectives(world, case, recompute):
+    """Round 4: a sharded step at L layers is 2L - 3 exchanges of A_hat's boundary rows (2L - 2 without
+    halo_recompute: layer 2's boundary input rows are recomputed from layer 1's constant AX / AM, fetched once) + 2L - 3 of A_hat^T's,
+    ONE batch-row all-reduce ([E_B | P_B | inv_B]; the [2B][d] input gradients are computed on every rank by the loss kernel's tail
+    -- widths the tail does not cover, d = 16 here, keep the second all-reduce) and one weight-gradient all-reduce: 4 collectives at
+    L = 2 where round 3 had 6.  gss_plan_comm_stats counts what the plan enqueued; the results still equal the single-GPU plan's
+    bit for bit (embeddings, losses)."""
+    import gcn_drug_repurposing_amd as pkg
+    from gcn_drug_repurposing_amd.dist import local_comms, sharded_plan_engine
+    from gcn_drug_repurposing_amd.engine import GssEngine
+    from gcn_drug_repurposing_amd.graph import GssGraph
+    g = load_golden(case)
+    n, d, L = (int(v) for v in g["meta"])
+    adj, X, p0 = golden_csr(g, "A"), g["X"], golden_params(g, "init")
+    batches = golden_batches(g)
+    kw = dict(num_layers=L, layer_decay=float(g["decay"]), alpha=float(g["alpha"]), lr=float(g["lr"]))
+    ref = GssEngine(GssGraph(adj, need_transpose=L > 1), torch.from_numpy(X).cuda(),
+                    [torch.from_numpy(p0[k].copy()).cuda() for k in ("W1", "b1", "W2", "b2")], **kw)
+    ref_out = []
+    for idx in batches:
+        ref.step(torch.from_numpy(idx.astype(np.int32)).cuda(), float(g["beta"]))
+        ref_out.append((ref.loss.item(), ref.emb.cpu().numpy().copy()))
+    lib = pkg.load()
+    comms = local_comms(world)
+    results, errors = [None] * world, []
+    gate = threading.Barrier(world)
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                eng = sharded_plan_engine(adj, X, p0, comms[rank], device=torch.device("cuda:0"), **kw)   # (snapshots the knob)
+                gate.wait(60)
+                out = []
+                for k, idx in enumerate(batches):
+                    t = torch.from_numpy(idx.astype(np.int32)).cuda()
+                    (eng.step_lazy if k == 2 else eng.step)(t, float(g["beta"]))
+                    stats = eng.comm_stats()
+                    eng.check_guards()
+                    if k == 2:
+                        eng.forward()            # a lazy step leaves the embeddings valid on the batch rows only
+                        eng.comm_stats()
+                    out.append((eng.loss.item(), eng.gather_embeddings().cpu().numpy(), stats))
+                results[rank] = out
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+            comms[rank].abort()
+            gate.abort()
+
+    assert lib.gss_debug_set_option(b"halo_recompute", recompute) == 0
+    try:
+        ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+        [t.start() for t in ts]
+        [t.join(600) for t in ts]
+    finally:
+        lib.gss_debug_set_option(b"halo_recompute", -1)
+    assert not errors, errors
+    rec = 1 if (recompute != 0 and L > 1) else 0
+    tail = d in (64, 128, 256)
+    steady = ((2 * L - 2 - rec) + max(0, 2 * L - 3), 1 if (tail or L == 1) else 2, 1)
+    for res in results:
+        for k, (loss, emb, stats) in enumerate(res):
+            assert loss == ref_out[k][0], (k, loss, ref_out[k][0])
+            np.testing.assert_array_equal(emb, ref_out[k][1])
+            first = (steady[0] + (2 + 2 * rec if L > 1 else 1), steady[1], steady[2]) if k == 0 else steady
+            assert stats == first, (k, stats, first)
