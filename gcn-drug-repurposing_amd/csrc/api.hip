@@ -133,7 +133,7 @@ int gss_debug_set_option(const char *name, int value) {
     return GSS_OK;
   }
   if (strcmp(name, "halo_recompute") == 0) {
-    GSS_REQUIRE(value >= -1 && value <= 1, "halo_recompute must be -1 (by graph size), 0 or 1");
+    GSS_REQUIRE(value >= -1 && value <= 1, "halo_recompute must be -1 (automatic: on), 0 or 1");
     g_knobs.halo_recompute = value;   // sharded plans created afterwards; every rank of a job must use the same value
     return GSS_OK;
   }

@@ -47,7 +47,7 @@ struct Knobs {
   int loss_tail = 1;         // finish + normalise' / ELU' + the batch rows' input gradient in the sweep's tail (0 = two separate launches,
                              // 2 = the finish in the tail, the input gradient a launch of its own)
   int halo_recompute = -1;   // sharded plans: layer 2's boundary input rows recomputed from layer 1's constant AX / AM instead of exchanged
-                             // (-1 = graphs below 262,144 nodes, 0 = never, 1 = always; every rank of a job must use the same value)
+                             // (-1 = automatic = on, 0 = never, 1 = always; every rank of a job must use the same value)
 };
 template <typename F>
 inline size_t lds_request(F kernel, size_t need, int knob_kb) {

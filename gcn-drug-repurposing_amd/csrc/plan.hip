@@ -80,9 +80,11 @@ struct gss_plan {
   float *keep;             // per batch: 1.0 where this shard owns the member
   float *gab;              // [2 * max_batch][d]: the top layer's compact input gradients (one buffer: one all-reduce where one is needed)
   float *bx;               // shards: [max_batch (2 d + 1)] = [E_B | P_B | inv_B], the ONE batch collective of a step (loss.hip gather_batch_kernel)
-  // halo_recompute (knob; shards of graphs below 262,144 nodes): layer 1's AX / AM are constants, so their boundary rows are fetched
-  // ONCE and layer 1's projection runs over own + boundary rows -- layer 2's boundary input rows are then computed here (by the same
-  // kernel from the same operands: the owner's bits) instead of exchanged every step.  ax[0] / am[0] / p[0] are operand-sized then.
+  // halo_recompute (knob, on by default): layer 1's AX / AM are constants, so their boundary rows are fetched ONCE and layer 1's
+  // projection runs over own + boundary rows -- layer 2's boundary input rows are then computed here (by the same kernel from the same
+  // operands: the owner's bits) instead of exchanged every step.  ax[0] / am[0] / p[0] are operand-sized then.  The trade per boundary
+  // row and step: 2 * 2 d * d flops of fp32 MFMA (0.75 ns at d = 128, measured projection rate) against d * 4 bytes over xGMI (1.5 ns
+  // at the ~340 GB/s a rank's seven links deliver together, plus the collective's latency): recomputing wins at every size.
   bool recompute;
   bool l0h_ready;          // the boundary rows of AX_0 / AM_0 have been fetched
   int64_t n_coll[3];       // collectives enqueued since the last gss_plan_comm_stats: halo exchanges / batch-row / weight-gradient
@@ -402,7 +404,7 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
   }
   {
     const int knob = K().halo_recompute;
-    p->recompute = P > 1 && desc->num_layers > 1 && (knob == 1 || (knob < 0 && n_global < 262144));
+    p->recompute = P > 1 && desc->num_layers > 1 && knob != 0;   // (automatic = on: what it trades is priced below)
     p->l0h_ready = false;
     p->n_coll[0] = p->n_coll[1] = p->n_coll[2] = 0;
   }

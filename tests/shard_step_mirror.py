@@ -10,7 +10,7 @@ the data layout and the order of the exchange points, line by line:
   operand = [n own rows | n_halo boundary rows grouped by owner]         plan.hip header, carve()
   plan_halo: pack rows send_rows[0..n_send) -> exchange_rows(send_off, recv_off) -> operand[n:]      plan.hip plan_halo
   X_0's and M_0's boundary rows fetched once (constants)                  plan_x0, m0_ready
-  halo_recompute (graphs below 262,144 nodes): AX_0 / AM_0 boundary rows fetched once, layer 1's projection over own + boundary
+  halo_recompute (on by default): AX_0 / AM_0 boundary rows fetched once, layer 1's projection over own + boundary
       rows, so layer 2's boundary input rows are computed here instead of exchanged                      plan_forward_impl (recompute)
   ONE batch collective: [E_B | P_B | inv_B] = sum over shards of (own rows | 0)                           C3, plan_loss_backward_impl
   batch maps: rloc / keep / pid = gid2op_t[node_map[idx]]                 loss.hip gather_batch_kernel
@@ -56,7 +56,7 @@ class ShardStepMirror:
         self.ops = NumpyOps()
         self.x0op = None
         self.m0op = None
-        self.recompute = self.P > 1 and self.L > 1 and self.n_global < 262144      # knob halo_recompute, automatic choice
+        self.recompute = self.P > 1 and self.L > 1      # knob halo_recompute, automatic choice (on)
         self.ax0op = self.am0op = None
         self.loss = None
         self.emb = None

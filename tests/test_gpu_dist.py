@@ -548,8 +548,10 @@ def test_sharded_step_enqueues_the_announced_collectives(world, case, recompute)
     ref = GssEngine(GssGraph(adj, need_transpose=L > 1), torch.from_numpy(X).cuda(),
                     [torch.from_numpy(p0[k].copy()).cuda() for k in ("W1", "b1", "W2", "b2")], **kw)
     ref_out = []
-    for idx in batches:
+    for k, idx in enumerate(batches):
         ref.step(torch.from_numpy(idx.astype(np.int32)).cuda(), float(g["beta"]))
+        if k == 2:
+            ref.forward()                # (the shards run a lazy step there and recompute all rows afterwards, with the updated weights)
         ref_out.append((ref.loss.item(), ref.emb.cpu().numpy().copy()))
     lib = pkg.load()
     comms = local_comms(world)
