@@ -92,6 +92,7 @@ SIGNATURES = {
     "gss_adam_step": (C.c_int, [_I64, _P, _P, _P, _P, _I32, _F, _F, _F, _F, _P, _I32, _P]),
     "gss_percentile": (C.c_int, [_I32, _I32, _P, _D, C.POINTER(_F), _P]),
     "gss_knn_topk": (C.c_int, [_I32, _I32, _P, _I32, _P, _P, _P]),
+    "gss_knn_topk_rows": (C.c_int, [_I32, _I32, _P, _I32, _I32, _I32, _P, _P, _P]),
     "gss_write_embs_text": (C.c_int, [C.c_char_p, _P, _I64, _I32, _I32]),
     "gss_format_e18": (C.c_int, [_F, C.c_char_p]),
     "gss_embs_open": (C.c_int, [C.POINTER(_P), C.c_char_p, _I32]),

@@ -17,15 +17,17 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kKnnMaxK = 64;
 
-__global__ __launch_bounds__(256) void knn_topk_kernel(int n, int d, const double *__restrict__ x, int k, double *__restrict__ top_val,
-                                                       int32_t *__restrict__ top_idx) {
+// rows [row_lo, row_hi) against all n columns; top_val / top_idx hold those rows only (a rank of a sharded job computes its own window:
+// a row's MFMA chain and its column sweep do not depend on the window, so the table is the same whoever computes it)
+__global__ __launch_bounds__(256) void knn_topk_kernel(int n, int d, const double *__restrict__ x, int k, int row_lo, int row_hi,
+                                                       double *__restrict__ top_val, int32_t *__restrict__ top_idx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *tile = reinterpret_cast<double *>(smem);        // [64][65] similarity tile (padded)
   double *tv = tile + 64 * 65;                            // [64][k]
   int *ti = reinterpret_cast<int *>(tv + 64 * k);         // [64][k]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int i0 = blockIdx.x * 64;
+  const int i0 = row_lo + blockIdx.x * 64;
   // running top-k state of row (i0 + threadIdx.x) for threads 0..63
   double minv = -INFINITY;
   int minp = 0, filled = 0;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(int n, int d, const doubl
 #pragma unroll
       for (int r = 0; r < 4; ++r) tile[(16 * w + q + 4 * r) * 65 + 16 * t + c] = acc[t][r];
     __syncthreads();
-    if (threadIdx.x < 64 && i0 + threadIdx.x < n) {
+    if (threadIdx.x < 64 && i0 + threadIdx.x < row_hi) {
       const double *row = tile + threadIdx.x * 65;
       double *mv = tv + threadIdx.x * k;
       int *mi = ti + threadIdx.x * k;
@@ -90,8 +92,8 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(int n, int d, const doubl
     }
   }
   __syncthreads();
-  if (threadIdx.x < 64 && i0 + threadIdx.x < n) {
-    const size_t o = (size_t)(i0 + threadIdx.x) * k;
+  if (threadIdx.x < 64 && i0 + threadIdx.x < row_hi) {
+    const size_t o = (size_t)(i0 + threadIdx.x - row_lo) * k;
     for (int p = 0; p < k; ++p) {
       top_val[o + p] = p < filled ? tv[threadIdx.x * k + p] : -INFINITY;
       top_idx[o + p] = p < filled ? ti[threadIdx.x * k + p] : -1;
@@ -103,12 +105,25 @@ __global__ __launch_bounds__(256) void knn_topk_kernel(int n, int d, const doubl
 
 using namespace gss;
 
-extern "C" int gss_knn_topk(int32_t n, int32_t d, const double *x, int32_t k, double *top_val, int32_t *top_idx, void *stream) {
+static int knn_topk_rows(int32_t n, int32_t d, const double *x, int32_t k, int32_t row_lo, int32_t row_hi, double *top_val, int32_t *top_idx,
+                         void *stream) {
   GSS_REQUIRE(n > 0 && x && top_val && top_idx, "knn_topk: null operand");
   GSS_REQUIRE(d >= 8 && d % 8 == 0 && d <= 4096, "knn_topk: d=%d must be a multiple of 8 in [8, 4096]", d);
   GSS_REQUIRE(k >= 1 && k <= kKnnMaxK && k <= n, "knn_topk: k=%d out of [1, min(%d, n)]", k, kKnnMaxK);
+  GSS_REQUIRE(row_lo >= 0 && row_lo <= row_hi && row_hi <= n, "knn_topk: rows [%d, %d) out of [0, %d]", row_lo, row_hi, n);
+  if (row_hi == row_lo) return GSS_OK;
   const size_t lds = sizeof(double) * 64 * 65 + (sizeof(double) + sizeof(int)) * 64 * (size_t)k;
-  hipLaunchKernelGGL(knn_topk_kernel, dim3(ceil_div(n, 64)), dim3(256), lds, as_stream(stream), n, d, x, k, top_val, top_idx);
+  hipLaunchKernelGGL(knn_topk_kernel, dim3(ceil_div(row_hi - row_lo, 64)), dim3(256), lds, as_stream(stream), n, d, x, k, row_lo, row_hi, top_val,
+                     top_idx);
   GSS_LAUNCH_CHECK("knn_topk_kernel");
   return GSS_OK;
+}
+
+extern "C" int gss_knn_topk(int32_t n, int32_t d, const double *x, int32_t k, double *top_val, int32_t *top_idx, void *stream) {
+  return knn_topk_rows(n, d, x, k, 0, n, top_val, top_idx, stream);
+}
+
+extern "C" int gss_knn_topk_rows(int32_t n, int32_t d, const double *x, int32_t k, int32_t row_lo, int32_t row_hi, double *top_val,
+                                 int32_t *top_idx, void *stream) {
+  return knn_topk_rows(n, d, x, k, row_lo, row_hi, top_val, top_idx, stream);
 }

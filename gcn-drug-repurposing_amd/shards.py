@@ -258,6 +258,148 @@ class RmatSource:
         self._cache = None
 
 
+class KnnSource:
+    """train.py's own adjacency -- gen_graph's "descriptor" kNN graph (helpers/helper.py:39-53) -- as a row source: every rank
+    computes the top-k of ITS row window on the device (gss_knn_topk_rows; fp64 MFMA similarity against all N columns), the
+    [N][k] table of (neighbour, similarity) pairs is all-gathered (N k 12 bytes: 1.8 MB at N = 29,960, k = 5), and a rank's rows of
+    A + I are assembled from it: row i holds topk(i) and every j with i in topk(j) (x_adj[i, top] = v, x_adj[top, i] = v, the later
+    iteration wins; zero diagonal, exact zeros dropped -- graph._symmetrise_topk's rule on the rows of one range).  The graph is
+    symmetric, so rows_t = rows.  X itself ([N][d] fp64) is needed whole on every rank: the similarity of a row runs against all
+    columns -- that is the reference's algorithm, O(N^2 d), not a property of this builder."""
+
+    def __init__(self, x_all, k, device="cuda"):
+        x = np.ascontiguousarray(x_all, dtype=np.float64)
+        self.n, d = x.shape
+        self.k = int(min(k, self.n))
+        if d % 8:
+            x = np.concatenate([x, np.zeros((self.n, 8 - d % 8))], axis=1)
+        self.device = torch.device(device)
+        self._x = torch.from_numpy(x).to(self.device)
+        self.ti = self.tv = None
+        self.nnz = None
+
+    def prepare(self, comm: Comm):
+        P, rank, n, k = comm.world, comm.rank, self.n, self.k
+        lo, hi = rank * n // P, (rank + 1) * n // P                     # an even split: this phase is N^2 d / P flops per rank
+        lib = _lib.load()
+        tv = torch.full((max(hi - lo, 1), k), float("-inf"), dtype=torch.float64, device=self.device)
+        ti = torch.full((max(hi - lo, 1), k), -1, dtype=torch.int32, device=self.device)
+        _lib.check(lib.gss_knn_topk_rows(n, self._x.shape[1], self._x.data_ptr(), k, lo, hi, tv.data_ptr(), ti.data_ptr(), _lib.current_stream()),
+                   "gss_knn_topk_rows")
+        bounds = np.array([r * n // P for r in range(P + 1)], dtype=np.int64)
+        # (allgather_ranges moves 1-D tensors: k columns, one at a time)
+        self.tv = torch.stack([allgather_ranges(comm, tv[:hi - lo, c].contiguous(), bounds, self.device) for c in range(k)], dim=1)
+        self.ti = torch.stack([allgather_ranges(comm, ti[:hi - lo, c].contiguous(), bounds, self.device) for c in range(k)], dim=1)
+        self._x = None
+        # every rank derives the same entry list (N k pairs) and from it every node's work
+        i = torch.arange(n, device=self.device).repeat_interleave(k)
+        j = self.ti.reshape(-1).long()
+        v = self.tv.reshape(-1)
+        keep = (j >= 0) & (j != i)
+        i, j, v = i[keep], j[keep], v[keep]
+        r = torch.cat([i, j])
+        c = torch.cat([j, i])
+        it = torch.cat([i, i])
+        vv = torch.cat([v, v])
+        # (row, col) duplicates: the write of the later iteration wins (helper.py:48-50)
+        key = r * n + c
+        order = torch.argsort(key * n + it)          # by (row, col), then iteration  (n^3 < 2^63 for n < 2 M nodes: kNN graphs are small)
+        ks = key[order]
+        last = torch.ones_like(ks, dtype=torch.bool)
+        last[:-1] = ks[1:] != ks[:-1]
+        sel = order[last]
+        sel = sel[vv[sel] != 0]                      # adj.eliminate_zeros()
+        self._r, self._c, self._v = r[sel], c[sel], vv[sel]          # sorted by (row, col)
+        deg = torch.bincount(self._r, minlength=n) + 1                 # + the diagonal of A + I
+        self._work = (2 * deg).cpu().numpy().astype(np.int64)
+        self.nnz = int(self._r.numel()) + n
+        return self
+
+    def work(self, comm, device):
+        if self.ti is None:
+            self.prepare(comm)
+        return self._work
+
+    def rows(self, lo, hi, device, relabel=None):
+        n = self.n
+        if relabel is None:
+            m = (self._r >= lo) & (self._r < hi)
+            rr, cc_old, vv = self._r[m] - lo, self._c[m], self._v[m]
+        else:
+            inv = relabel.inv_dev(self.device)
+            nr = inv[self._r]
+            m = (nr >= lo) & (nr < hi)
+            rr, cc_old, vv = nr[m] - lo, self._c[m], self._v[m]
+        # + the diagonal (A + I, helper.py:83); a row's entries in ascending OLD column order, column ids relabelled
+        dr = torch.arange(hi - lo, device=self.device)
+        d_old = (dr + lo) if relabel is None else relabel.perm_dev(self.device)[dr + lo]
+        rr = torch.cat([rr, dr])
+        cc_old = torch.cat([cc_old, d_old])
+        vv = torch.cat([vv, torch.ones(hi - lo, dtype=torch.float64, device=self.device)])
+        order = torch.argsort(rr * n + cc_old)
+        rr, cc_old, vv = rr[order], cc_old[order], vv[order]
+        rowptr = torch.zeros(hi - lo + 1, dtype=torch.int64, device=self.device)
+        rowptr[1:] = torch.cumsum(torch.bincount(rr, minlength=hi - lo), 0)
+        cols = cc_old if relabel is None else relabel.inv_dev(self.device)[cc_old]
+        return rowptr.to(torch.int32), cols.to(torch.int32), vv.contiguous()
+
+    rows_t = rows                                    # the kNN graph is symmetric by construction
+
+
+class EdgelistSource:
+    """--adj-file: the directed weighted edgelist (embio.read_edgelist: src, dst, w over the .embs.txt rows) as a row source.  A rank
+    keeps the entries of its own rows of A + I and of (A + I)^T only; a repeated (u, v) keeps the last weight (DiGraph.add_edge),
+    a self loop in the file adds to the diagonal's 1 (graph.edgelist_adj + helper.py:83)."""
+
+    def __init__(self, src, dst, w, n, device="cuda"):
+        self.n = int(n)
+        self.device = torch.device(device)
+        src, dst, w = np.asarray(src, np.int64), np.asarray(dst, np.int64), np.asarray(w, np.float64)
+        key = src * self.n + dst
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        last = order[np.r_[ks[1:] != ks[:-1], True]] if len(ks) else order
+        self._src, self._dst, self._w = src[last], dst[last], w[last]                    # distinct (u, v), sorted by (u, v)
+        diag = self._src == self._dst
+        self.nnz = int(len(self._src) - diag.sum() + self.n)
+        deg_out = np.bincount(self._src[~diag], minlength=self.n)
+        deg_in = np.bincount(self._dst[~diag], minlength=self.n)
+        self._work = (deg_out + deg_in + 2).astype(np.int64)
+
+    def work(self, comm, device):
+        return self._work
+
+    def _rows(self, rows_of, cols_of, lo, hi, relabel):
+        n = self.n
+        r_new = rows_of if relabel is None else relabel.inv[rows_of]
+        m = (r_new >= lo) & (r_new < hi)
+        rr, cc_old, vv = r_new[m] - lo, cols_of[m], self._w[m]
+        d_old = np.arange(lo, hi) if relabel is None else relabel.perm[lo:hi]
+        # A + I: the diagonal's 1 is ADDED to a self loop of the file (adj + eye)
+        self_loop = cc_old == d_old[rr]
+        vv = vv + self_loop
+        have = np.zeros(hi - lo, dtype=bool)
+        have[rr[self_loop]] = True
+        miss = np.flatnonzero(~have)
+        rr = np.concatenate([rr, miss])
+        cc_old = np.concatenate([cc_old, d_old[miss]])
+        vv = np.concatenate([vv, np.ones(len(miss))])
+        order = np.argsort(rr * n + cc_old, kind="stable")
+        rr, cc_old, vv = rr[order], cc_old[order], vv[order]
+        rowptr = np.zeros(hi - lo + 1, dtype=np.int64)
+        rowptr[1:] = np.cumsum(np.bincount(rr, minlength=hi - lo))
+        cols = cc_old if relabel is None else relabel.inv[cc_old]
+        dev = self.device
+        return (torch.from_numpy(rowptr.astype(np.int32)).to(dev), torch.from_numpy(cols.astype(np.int32)).to(dev),
+                torch.from_numpy(np.ascontiguousarray(vv, dtype=np.float64)).to(dev))
+
+    def rows(self, lo, hi, device, relabel=None):
+        return self._rows(self._src, self._dst, lo, hi, relabel)
+
+    def rows_t(self, lo, hi, device, relabel=None):
+        return self._rows(self._dst, self._src, lo, hi, relabel)
+
+
 def gaussian_rows(lo, hi, d, seed, block=1 << 16):
     """rows [lo, hi) of a unit-variance Gaussian feature matrix that any rank can generate for its own range: block k
     (rows k * block ...) comes from RandomState(seed * 1000003 + k)"""
@@ -358,6 +500,9 @@ def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="a
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     ops = ops or NativeShardOps()
     P, rank = comm.world, comm.rank
+    import os
+    if split == "auto" and os.environ.get("GSS_SPLIT") in ("0", "1"):
+        split = os.environ["GSS_SPLIT"] == "1"      # job-wide override (every rank inherits the environment): entry points without a flag for it
     work = np.asarray(source.work(comm, dev), dtype=np.int64)
     n = len(work)
     if relabel == "auto":

@@ -144,17 +144,27 @@ def main(argv=None):
         raise Exception(f"--hidden-units {args.hidden_units} must equal the embedding width {d} (modules/model.py:142)")
 
     t0 = time.time()
-    if args.adj_file:
-        src, dst, w, _ = embio.read_edgelist(args.adj_file, names)
-        adj = edgelist_adj(src, dst, w, n)
-    else:
-        adj = knn_descriptor_adj_device(X, args.k, device=dev)   # train.py:93 -> helper.py:39-53, similarity + top-k on device
     # all but test-sized graphs go through the shard builder even on one GPU: it relabels the nodes hub-first for gather
     # locality (shards.build_shard: -2 % of a step at N = 30k, -30 % at 10M; invisible in the results)
     from .shards import RELABEL_MIN_NODES
     shard_path = sharded or n >= RELABEL_MIN_NODES
     graph = None
-    if not shard_path:
+    source = None
+    if shard_path:
+        # a ROW SOURCE instead of a matrix: every rank assembles the rows of A + I (and of its transpose) it owns, nothing more --
+        # the kNN top-k of its own row window on its GPU (train.py:93 -> helper.py:39-53), or its rows of the edgelist
+        from .shards import EdgelistSource, KnnSource
+        if args.adj_file:
+            src, dst, w, _ = embio.read_edgelist(args.adj_file, names)
+            source = EdgelistSource(src, dst, w, n, device=dev)
+        else:
+            source = KnnSource(X, args.k, device=dev)
+    else:
+        if args.adj_file:
+            src, dst, w, _ = embio.read_edgelist(args.adj_file, names)
+            adj = edgelist_adj(src, dst, w, n)
+        else:
+            adj = knn_descriptor_adj_device(X, args.k, device=dev)   # train.py:93 -> helper.py:39-53, similarity + top-k on device
         graph = GssGraph(adj, device=dev, need_transpose=args.num_layers > 1)   # train.py:100-101
         print('Created G with [k={}] [shape=[{}, {}]] [nnz(A_hat)={}] in {:.2f}s'.format(args.k, n, n, graph.nnz, time.time() - t0))
 
@@ -179,10 +189,12 @@ def main(argv=None):
     if shard_path:
         # one process per GPU, node-range shards: a native gss_plan per rank that owns the RCCL communicator and enqueues
         # kernels and collectives from C++ (dist.sharded_plan_engine); same step semantics
-        from .dist import job_comm, local_comms, sharded_plan_engine
+        from .dist import job_comm, local_comms
+        from .shards import build_shard, shard_engine, shard_rows
         comm = job_comm(world, rank) if sharded else local_comms(1)[0]
-        engine = sharded_plan_engine(adj, X32, host_params, comm, num_layers=args.num_layers, layer_decay=args.layer_decay,
-                                     alpha=args.alpha, lr=args.lr, max_batch=min(bsz, n), device=dev, cache_layer1=args.cache_layer1)
+        shard = build_shard(source, comm, need_transpose=args.num_layers > 1, device=dev)
+        engine = shard_engine(shard, shard_rows(shard, X32), host_params, comm, num_layers=args.num_layers, layer_decay=args.layer_decay,
+                              alpha=args.alpha, lr=args.lr, max_batch=min(bsz, n), cache_layer1=args.cache_layer1)
         if rank == 0:
             print('Created G with [k={}] [shape=[{}, {}]] [nnz(A_hat)={}] in {:.2f}s; {} node-range shards'.format(
                 args.k, n, n, engine.global_nnz, time.time() - t0, world))

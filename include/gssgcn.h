@@ -209,6 +209,10 @@ int gss_percentile(int32_t n, int32_t d, const float *e, double q, float *h_out,
  * x_i . x_j over all j (self included, as np.argpartition(x_sim, -k, 1)[:, -k:] returns them; order within the
  * k is unspecified) -> top_val [n][k] fp64, top_idx [n][k] int32.  fp64 MFMA; d multiple of 8, k <= 64. */
 int gss_knn_topk(int32_t n, int32_t d, const double *x, int32_t k, double *top_val, int32_t *top_idx, void *stream);
+/* the same for rows [row_lo, row_hi) only (against all n columns): top_val / top_idx [row_hi - row_lo][k].  What a rank of a sharded
+ * job computes for its own row window (shards.KnnSource); a row's result does not depend on the window. */
+int gss_knn_topk_rows(int32_t n, int32_t d, const double *x, int32_t k, int32_t row_lo, int32_t row_hi, double *top_val,
+                      int32_t *top_idx, void *stream);
 
 /* ---- f4  diffusion profiles, multiscale/diff_prof/diffusion_profiles.py:30-90 ---------------------------
  * Personalised PageRank from every drug / indication, all start nodes at once: column c of the fp64 matrix

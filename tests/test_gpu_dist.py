@@ -323,6 +323,37 @@ def test_two_rccl_ranks_trainer_matches_single_gpu(tmp_path):
 
 
 @pytest.mark.skipif(_visible_gpus() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_rccl_ranks_subset_exchanges_and_overlapped_hops(tmp_path):
+    """the parts of the sharded step that had only ever run on the in-process / host-staged backends, over RCCL between
+    two devices -- the subset exchanges of knob lazy_halo (bitmaps by ncclSend / ncclRecv, the per-step counts through RcclComm::sync)
+    and the overlapped hops on the plan's second stream (one communicator, two streams, event-ordered).  Forced on for a test-sized
+    graph through the job-wide environment knobs; the result is held to the single-GPU trainer's."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    g = load_golden("train_py_n200_d16")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    emb_path = tmp_path / "in.embs.txt"
+    emb_path.write_bytes(bytes(g["in_embs_txt"]))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    common = ["--emb-file", str(emb_path), "--num-layers", "2", "--hidden-units", "16", "--k", "5", "--epochs", "3", "--lr", "0.0003",
+              "--beta-percentile", "98", "--batch-size", "64", "--seed", "7"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "train.py")] + common + ["--ngpus", "2", "--out", str(tmp_path / "two.txt")],
+                         capture_output=True, text=True, env=dict(env, GSS_OPTIONS="lazy_halo=1", GSS_SPLIT="1"), timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    one = subprocess.run([sys.executable, os.path.join(root, "train.py")] + common + ["--out", str(tmp_path / "one.txt")],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    a, b = np.loadtxt(str(tmp_path / "two.txt")), np.loadtxt(str(tmp_path / "one.txt"))
+    assert np.abs(a - b).max() < 1e-5          # (own-column + boundary-column sums and RCCL's reduction order: rounding-level differences)
+
+
+@pytest.mark.skipif(_visible_gpus() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
 def test_two_rccl_ranks_bench_line_is_complete():
     """`bench.py --gpus 2` starts its own two ranks; the line must carry what a scaling run is graded on"""
     import json
@@ -335,9 +366,10 @@ def test_two_rccl_ranks_bench_line_is_complete():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
-    for key in ("roofline", "xgmi", "per_rank", "comm_share", "kernel_ms_per_step", "value_executed"):
+    for key in ("roofline", "xgmi", "per_rank", "comm_share", "kernel_ms_per_step", "value_executed", "collectives_per_step"):
         assert key in line, key
     assert len(line["per_rank"]["ms_per_step"]) == 2 and line["roofline"]["bound"] == "hbm"
+    assert line["collectives_per_step"]["total"] <= 4.0          # L = 2: M_1's and u's boundary rows, the batch rows, the weight gradients
     assert np.isfinite(line["config"]["final_loss"])
 
 
@@ -393,8 +425,12 @@ def test_multi_process_bench_on_one_gpu_host_staged_backend():
     sub = line["xgmi"]["subset_exchange_u"]        # the knob reached both processes: the backward hop fetched a subset of u's halo
     assert all(0 < f <= h for f, h in zip(sub["rows_fetched_last_step_by_rank"], sub["rows_of_the_whole_halo_by_rank"]))
     assert "REHEARSAL" in line["config"]["parallelism"]
-    for key in ("roofline", "xgmi", "per_rank", "comm_share", "kernel_ms_per_step", "value_executed"):
+    for key in ("roofline", "xgmi", "per_rank", "comm_share", "kernel_ms_per_step", "value_executed", "collectives_per_step"):
         assert key in line, key
+    # L = 2 with the subset exchange of u forced on: M_1's boundary rows (1), u's (bitmaps + rows: 2), the batch rows (1), the weight
+    # gradients (1); X_1's boundary rows are recomputed, the batch rows' input gradients are computed on every rank
+    cps = line["collectives_per_step"]
+    assert cps["batch_row_allreduces"] == 1 and cps["weight_gradient_allreduces"] == 1 and cps["boundary_row_exchanges"] == 3, cps
     assert len(line["per_rank"]["ms_per_step"]) == 2 and sum(line["per_rank"]["rows"]) == 29960
     ref = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--spinup-time", "0", "--min-time", "0",
                           "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
@@ -534,8 +570,8 @@ def test_sharded_step_enqueues_the_announced_collectives(world, case, recompute)
     halo_recompute: layer 2's boundary input rows are recomputed from layer 1's constant AX / AM, fetched once) + 2L - 3 of A_hat^T's,
     ONE batch-row all-reduce ([E_B | P_B | inv_B]; the [2B][d] input gradients are computed on every rank by the loss kernel's tail
     -- widths the tail does not cover, d = 16 here, keep the second all-reduce) and one weight-gradient all-reduce: 4 collectives at
-    L = 2 where round 3 had 6.  gss_plan_comm_stats counts what the plan enqueued; the results still equal the single-GPU plan's
-    bit for bit (embeddings, losses)."""
+    L = 2 where round 3 had 6.  gss_plan_comm_stats counts what the plan enqueued; the first step's embeddings and loss still equal
+    the single-GPU plan's bit for bit, the later ones to the trajectory tolerances."""
     import gcn_drug_repurposing_amd as pkg
     from gcn_drug_repurposing_amd.dist import local_comms, sharded_plan_engine
     from gcn_drug_repurposing_amd.engine import GssEngine
@@ -594,7 +630,11 @@ def test_sharded_step_enqueues_the_announced_collectives(world, case, recompute)
     steady = ((2 * L - 2 - rec) + max(0, 2 * L - 3), 1 if (tail or L == 1) else 2, 1)
     for res in results:
         for k, (loss, emb, stats) in enumerate(res):
-            assert loss == ref_out[k][0], (k, loss, ref_out[k][0])
-            np.testing.assert_array_equal(emb, ref_out[k][1])
+            if k == 0:     # one forward: a row's result does not depend on the shard, nor on who computed a boundary row
+                assert loss == ref_out[k][0], (k, loss, ref_out[k][0])
+                np.testing.assert_array_equal(emb, ref_out[k][1])
+            else:          # the ranks' weight gradients are summed in rank order, the single GPU's slabs in slice order: rounding
+                assert abs(loss - ref_out[k][0]) <= T.TRAJ_LOSS_RTOL * abs(ref_out[k][0]), (k, loss, ref_out[k][0])
+                assert np.abs(emb - ref_out[k][1]).max() <= T.TRAJ_EMB_REL * np.abs(ref_out[k][1]).max(), k
             first = (steady[0] + (2 + 2 * rec if L > 1 else 1), steady[1], steady[2]) if k == 0 else steady
             assert stats == first, (k, stats, first)

@@ -571,3 +571,50 @@ def test_subset_exchanges_at_a_halo_of_several_compaction_trips():
         assert sum(r["moved"][k][3] for r in needed) == sum(r["moved"][k][4] for r in needed) > 0
         if k != 1:
             assert sum(r["moved"][k][0] for r in needed) == sum(r["moved"][k][1] for r in needed) > 0
+
+
+@pytest.mark.parametrize("world,relabel", [(1, False), (2, True), (3, False)])
+def test_knn_row_source_builds_the_rows_of_the_reference_graph(world, relabel):
+    """Round 4: train.py's kNN adjacency as a ROW SOURCE -- every rank computes the top-k of its own row window
+    (gss_knn_topk_rows), the [N][k] table is all-gathered, and a rank assembles only its rows of A + I.  Against the whole-graph builder
+    (graph.knn_descriptor_adj_device -> ScipySource): the same work array, and for every range, with and without relabelling, the same
+    rowptr / column ids / values entry for entry -- so build_shard gives the same shard whichever source it is handed."""
+    import threading
+    from gcn_drug_repurposing_amd.dist import local_comms
+    from gcn_drug_repurposing_amd.graph import knn_descriptor_adj_device
+    from gcn_drug_repurposing_amd.shards import KnnSource, Relabel, ScipySource
+    rng = np.random.RandomState(8)
+    n, d, k = 777, 20, 5
+    X = rng.randn(n, d)
+    X[5] = X[9]                                   # a tie between two rows' similarities
+    ref = ScipySource(knn_descriptor_adj_device(X, k))
+    comms = local_comms(world)
+    errors, done = [], [0]
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                src = KnnSource(X, k, device="cuda:0")
+                work = src.work(comms[rank], torch.device("cuda:0"))
+                assert np.array_equal(work, ref.work(None, None))
+                assert src.nnz == ref.nnz
+                rl = Relabel(work) if relabel else None
+                for lo, hi in ((0, n), (100, 431), (n - 1, n), (0, 0)):
+                    for f in ("rows", "rows_t"):
+                        got = getattr(src, f)(lo, hi, "cuda:0", relabel=rl)
+                        want = getattr(ref, f)(lo, hi, "cuda:0", relabel=rl)
+                        for a, b in zip(got, want):
+                            assert torch.equal(a.cpu(), b.cpu()), (rank, lo, hi, f)
+                torch.cuda.current_stream().synchronize()
+                done[0] += 1
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+            comms[rank].abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not errors, errors
+    assert done[0] == world

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A sharded job on a ONE-GPU box: `world` ranks as threads of this process (gss_comm_create_local), each building only its
 own rows of an RMAT graph (shards.RmatSource / build_shard) and running the native sharded plan.
-usage: shard_emulation.py <nodes> <edges> <world> [steps] [d] [split: auto | 0 | 1] [lazy_halo: -1 | 0 | 1]
+usage: shard_emulation.py <nodes> <edges> <world> [steps] [d] [split: auto | 0 | 1] [lazy_halo: -1 | 0 | 1] [halo_recompute: -1 | 0 | 1]
 Reports per rank: rows, stored entries, boundary rows per hop (halo) and their fraction of the other shards' rows, plan
 bytes; for the job: host peak RSS, setup time, ms/step (NOT a performance figure: the ranks share one GPU and the exchanges
 are host-synchronised copies), and the loss after the steps -- compare it with the world = 1 run of the same command.  After the
@@ -29,6 +29,8 @@ d = int(sys.argv[5]) if len(sys.argv) > 5 else 128
 split = {"auto": "auto", "0": False, "1": True}[sys.argv[6] if len(sys.argv) > 6 else "auto"]
 lazy_halo = int(sys.argv[7]) if len(sys.argv) > 7 else -1
 assert pkg.load().gss_debug_set_option(b"lazy_halo", lazy_halo) == 0
+recompute = int(sys.argv[8]) if len(sys.argv) > 8 else -1
+assert pkg.load().gss_debug_set_option(b"halo_recompute", recompute) == 0
 L, B = 2, 2048
 np.random.seed(7)
 w = np.random.randn(d, d) * 1e-5
@@ -54,17 +56,20 @@ def worker(rank):
             idx = [torch.from_numpy(b).cuda() for b in batches]
             eng.step(idx[0], 0.25)
             torch.cuda.current_stream().synchronize()
+            eng.comm_stats()
             t1 = time.perf_counter()
             for k in range(1, steps + 1):
                 eng.step(idx[k], 0.25)
             torch.cuda.current_stream().synchronize()
             t_full = (time.perf_counter() - t1) / steps * 1e3
             loss_full = eng.loss.item()
+            coll_full = [c / steps for c in eng.comm_stats()]
             t2 = time.perf_counter()
             for k in range(steps + 1, 2 * steps + 1):
                 eng.step_lazy(idx[k], 0.25)
             torch.cuda.current_stream().synchronize()
             t_lazy = (time.perf_counter() - t2) / steps * 1e3
+            coll_lazy = [c / steps for c in eng.comm_stats()]
             fetched, sent, _, u_fetched, u_sent, u_halo = eng.lazy_halo_rows()
             fa, ft = shard.layout.halo_fraction()
             out[rank] = dict(rank=rank, rows=hi - lo, nnz=shard.a.nnz, halo_rows_a=shard.layout.halo_a.n_halo, halo_rows_at=shard.layout.halo_at.n_halo,
@@ -80,7 +85,15 @@ def worker(rank):
                              lazy_top_m_rows_sent=(sent if sent >= 0 else int(shard.layout.halo_a.send_off[-1])),
                              lazy_top_m_mb_fetched=round((fetched if fetched >= 0 else shard.layout.halo_a.n_halo) * d * 4 / 2 ** 20, 2),
                              u_rows_fetched=(u_fetched if u_fetched >= 0 else u_halo), u_rows_sent=(u_sent if u_sent >= 0 else int(shard.layout.halo_at.send_off[-1])),
-                             u_mb_fetched=round((u_fetched if u_fetched >= 0 else u_halo) * d * 4 / 2 ** 20, 2), lazy_halo=fetched >= 0)
+                             u_mb_fetched=round((u_fetched if u_fetched >= 0 else u_halo) * d * 4 / 2 ** 20, 2), lazy_halo=fetched >= 0,
+                             # what a step moves INTO this rank: the hops' boundary rows (X_1 only without halo_recompute) + the batch rows
+                             halo_recompute=recompute != 0,
+                             x1_mb_fetched_per_step=0.0 if recompute != 0 else round(shard.layout.halo_a.n_halo * d * 4 / 2 ** 20, 1),
+                             collectives_per_full_step=dict(boundary_row_exchanges=coll_full[0], batch_row_allreduces=coll_full[1], weight_gradient_allreduces=coll_full[2]),
+                             collectives_per_lazy_step=dict(boundary_row_exchanges=coll_lazy[0], batch_row_allreduces=coll_lazy[1], weight_gradient_allreduces=coll_lazy[2]))
+            o = out[rank]
+            o["full_step_mb_received"] = round(o["x1_mb_fetched_per_step"] + o["exchanged_mb_per_hop_a"] + o["u_mb_fetched"], 1)
+            o["lazy_step_mb_received"] = round(o["x1_mb_fetched_per_step"] + o["lazy_top_m_mb_fetched"] + o["u_mb_fetched"], 1)
     except Exception as e:  # noqa: BLE001
         import traceback
         errors.append((rank, repr(e), traceback.format_exc()))
