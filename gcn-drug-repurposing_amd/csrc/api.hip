@@ -123,13 +123,8 @@ int gss_debug_set_option(const char *name, int value) {
     g_knobs.ppr_fused = value ? 1 : 0;   // handles created afterwards
     return GSS_OK;
   }
-  if (strcmp(name, "loss_idx") == 0) {
-    g_knobs.loss_idx = value ? 1 : 0;
-    return GSS_OK;
-  }
-  if (strcmp(name, "loss_tail") == 0) {
-    GSS_REQUIRE(value >= 0 && value <= 2, "loss_tail must be 0, 1 or 2");
-    g_knobs.loss_tail = value;
+  if (strcmp(name, "loss_dgrad") == 0) {
+    g_knobs.loss_dgrad = value ? 1 : 0;
     return GSS_OK;
   }
   if (strcmp(name, "halo_recompute") == 0) {

@@ -41,11 +41,7 @@ struct Knobs {
   int gemm_lds_kb = 0, wgrad_lds_kb = 0, loss_lds_kb = 0;
   int lazy_halo = -1;        // sharded lazy step: fetch only the boundary rows of the top layer's M that the batch rows read (-1 = graphs of >= 262,144 nodes, 0 = never, 1 = always)
   int ppr_fused = 1;         // diffusion profiles: the update and the column errors in the SpMM's epilogue (0 = separate update pass)
-  int loss_idx = 0;          // 1: the loss sweep fetches its operand rows through an LDS row table instead of a gather launch (single GPU,
-                             // b <= 8192; measured +2.4 us per step at config 2 -- three dependent round trips in every workgroup's prologue
-                             // cost more than the 5 us launch they replace -- so off by default)
-  int loss_tail = 1;         // finish + normalise' / ELU' + the batch rows' input gradient in the sweep's tail (0 = two separate launches,
-                             // 2 = the finish in the tail, the input gradient a launch of its own)
+  int loss_dgrad = 1;        // finish + normalise' / ELU' + the batch rows' input gradient in one launch (0 = two launches); d in {64, 128, 256}
   int halo_recompute = -1;   // sharded plans: layer 2's boundary input rows recomputed from layer 1's constant AX / AM instead of exchanged
                              // (-1 = automatic = on, 0 = never, 1 = always; every rank of a job must use the same value)
 };

@@ -25,35 +25,12 @@ __device__ __forceinline__ f32x4 mfma16l(float a, float b, f32x4 c) {
 
 constexpr int kLossWaves = 4;
 
-// What follows the sweep, folded into it (round 4): the last of an i tile's js workgroups to finish sums the tile's partial dE in
-// slab order, runs the backward of F.normalize / F.elu on the tile's 16 batch rows and their input gradient [g_ax | g_am] = dP [W1 ; W2]
-// -- loss_finish_bwd_kernel and the batch-row launch of gemm_nt_lds_kernel<.., EPI_SPLIT>, which were two launches of ~5 us for < 1 us
-// of work each (a kernel boundary costs more than either).  Same lanes, same order, same MFMA sequence as the stand-alone kernels: same bits.
-struct LossTail {
-  unsigned *tile_cnt;        // [ni] arrival counters + [1] finished tiles; zero between launches (the last arriver resets what it used)
-  const int32_t *rows;       // row of inv_den / p per member (NULL: the sweep's own row table, IDX mode)
-  const int32_t *pos_ids;    // key of the batch-position map per member (NULL: as rows)
-  int32_t *pos_set;          // nullable
-  const float *keep;         // nullable: 0 where another shard owns the member (its dx_b / dp_b rows are written as zeros)
-  const float *inv_den, *p;
-  float c;
-  float *dx_b, *dp_b, *loss_out;
-  const float *w1t, *w2t;    // NULL: no input gradient
-  float *gax_b, *gam_b;
-  int dgrad_all;             // the input gradient of EVERY member (a shard that holds p / inv_den of the whole batch), else of the kept ones
-};
-
 struct LossArgs {
   int d, b, js;  // js = grid.y
-  const float *e;  // contiguous E_B [b][d] (gathered by gather_rows_kernel); IDX: the embedding matrix, rows through the table
+  const float *e;  // contiguous E_B [b][d] (gathered by gather_rows_kernel)
   float beta, alpha;
   float *de_part;     // [js][b][d]
   double *loss_part;  // [grid.x * grid.y]
-  // IDX: the batch-row gather and id translation folded into the sweep's prologue (every workgroup builds the row table in LDS;
-  // workgroup 0 also stores the translated ids for the kernels after it)
-  const int32_t *idx, *node_map;
-  int32_t *rloc_out, *pid_out;   // nullable (already prepared)
-  LossTail t;
 };
 
 // E_B = e[idx] (modules/model.py:216-217) into a contiguous buffer, so the MFMA loop has no index indirection
@@ -92,15 +69,6 @@ __global__ __launch_bounds__(256) void gather_rows_mapped_kernel(int b, int d4, 
   st4(out + i * 4, mine ? ld4(e + ((size_t)rel * d4 + f4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
-// EXACT: d == 64 NG, no feature masking anywhere.  From d = 256 on the operand fragments + accumulators need more than the 256
-// registers two workgroups per CU leave a lane (372 B/lane of scratch at NG = 4): one workgroup per CU with the full 512
-// (accumulators in AGPRs), and at NG = 4 no register prefetch of the next j tile, measured at B = 2048, d = 256:
-// 123 us -> 55 us for gather + sweep + finish (tools/loss_prof.py 256).
-// Measured dead ends at d = 128, B = 2048 (gather + sweep + finish 31.6 us, tools/loss_prof.py): 8 waves per workgroup 33.2 us; two j
-// tiles per trip with two operand register sets that swap roles (no copies, every wait a full tile behind its load in the ISA) 34.7 us;
-// the second product's operand loads removed altogether (wrong results, timing only) 30.6 us -- the sweep is bound by neither its
-// loads nor their waits; 1024 MFMAs per SIMD are 13.7 us at 2.4 GHz and ~16.5 us at the ~2.0 GHz an MFMA-saturated loop sustains
-// (tools/micro/mfma_lds.hip: 126-131 of 157 TFLOP/s), the rest is the fixed start (i-tile fragments) and end (wave tree, partial store).
 // A shard's contribution to the ONE batch collective of a step (round 4): [E_B | P_B | inv_B] -- the embedding row, the top layer's
 // pre-activation row and 1 / ||x|| of every member this shard owns, zeros for the others -- so that after one all-reduce (every element
 // has exactly one non-zero contributor: the sum is the owner's value, bit for bit) every rank holds what the finish needs for EVERY
@@ -134,10 +102,10 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(int b, int d4, const 
   if (f4 == 0) out[(size_t)2 * b * d4 * 4 + r] = mine ? inv_den[rel] : 0.f;
 }
 
-// One batch row of the finish (shared by loss_finish_bwd_kernel and the sweep's tail -- the same lanes in the same order, so the two
+// One batch row of the finish (shared by loss_finish_bwd_kernel and loss_finish_dgrad_kernel -- the same lanes in the same order, so the two
 // forms give the same bits): lane li of the row's lane group (lpr lanes) holds float4s li + 64 k.
 //   de = 2 sum_js de_part; dot = e . de; dx = (de - e dot) * inv; dp = c * dx (.) elu'(p)
-// dp_lds (nullable): the row of dP the input-gradient MFMAs of the tail read (unmasked when dgrad_all)
+// dp_lds (nullable): the row of dP the input-gradient MFMAs of loss_finish_dgrad_kernel read (unmasked when dgrad_all)
 template <int VPL>
 __device__ __forceinline__ void finish_row(bool ok, int r, int li, int lpr, int d4, int js, int b, const float *__restrict__ de_part,
                                            const float *__restrict__ erow, float inv_u, float keepv, const float *__restrict__ prow, float c,
@@ -200,16 +168,11 @@ __device__ __forceinline__ void finish_row(bool ok, int r, int li, int lpr, int 
 // the second product's operand loads removed altogether (wrong results, timing only) 30.6 us -- the sweep is bound by neither its
 // loads nor their waits; 1024 MFMAs per SIMD are 13.7 us at 2.4 GHz and ~16.5 us at the ~2.0 GHz an MFMA-saturated loop sustains
 // (tools/micro/mfma_lds.hip: 126-131 of 157 TFLOP/s), the rest is the fixed start (i-tile fragments) and end (wave tree, partial store).
-// IDX (round 4): E_B is never gathered -- the prologue builds the table member -> embedding row in LDS (the id translation of a
-// relabelled graph included) and every operand row is fetched through it (the same values in the same order: same bits).
-// TAIL (round 4, EXACT only): see LossTail.
-template <int NG, bool EXACT, bool IDX = false, bool TAIL = false, bool PF = (NG <= 2), int OCC = (NG >= 4 ? 1 : 2)>
+template <int NG, bool EXACT, bool PF = (NG <= 2), int OCC = (NG >= 4 ? 1 : 2)>
 __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *red = reinterpret_cast<float4 *>(smem);  // [2 slots][NG*4 tiles][64 lanes]
-  int32_t *rtab = reinterpret_cast<int32_t *>(smem + (size_t)2 * NG * 4 * 64 * sizeof(float4));   // IDX: [b] embedding row of every member
   __shared__ double lsum[kLossWaves];
-  __shared__ int s_last;
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int c = lane & 15, q = lane >> 4;
@@ -222,21 +185,7 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
   const float coef = -g.alpha / ((float)B * (float)B);
   const float beta = g.beta;
 
-  if (IDX) {
-    const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
-    for (int t = threadIdx.x; t < B; t += 64 * kLossWaves) {
-      int id = g.idx[t];
-      if (g.node_map) id = g.node_map[id];
-      rtab[t] = id;
-      if (writer && g.rloc_out) g.rloc_out[t] = id;
-      if (writer && g.pid_out) g.pid_out[t] = id;
-    }
-    __syncthreads();
-  }
-  // row of E_B behind member j (j already clamped to [0, B))
-  auto erow = [&](int j) -> const float * { return g.e + (size_t)(IDX ? rtab[j] : j) * d; };
-
-  const float *ei = erow(min(B - 1, i0 + c)) + 4 * q;
+  const float *ei = g.e + (size_t)min(B - 1, i0 + c) * d + 4 * q;
   const bool i_ok = (i0 + c) < B;
   // the i-tile's operand fragments stay in registers for the whole j sweep when d <= 256
   constexpr bool HOLD_I = NG <= 4;
@@ -256,29 +205,21 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
 
   float4 aj[HOLD_I ? NCH : 1];
   if (HOLD_I && PF && slot < nj) {
-    const float *ej0 = erow(min(B - 1, slot * 16 + c)) + 4 * q;
+    const float *ej0 = g.e + (size_t)min(B - 1, slot * 16 + c) * d + 4 * q;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) aj[k] = (EXACT || 16 * k < d) ? ld4(ej0 + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  // IDX: the table entries of a tile are read one trip ahead of the loads that need them (no LDS round trip in front of a fetch)
-  int rid_p2[4] = {0, 0, 0, 0}, rid_an = 0;
-  if (IDX && slot < nj) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) rid_p2[r] = rtab[min(B - 1, slot * 16 + 4 * q + r)];
-    const int jn = slot + nslots;
-    rid_an = rtab[min(B - 1, (jn < nj ? jn : slot) * 16 + c)];
   }
   for (int jt = slot; jt < nj; jt += nslots) {
     const int j0 = jt * 16;
     // ---- S'[j][i] = E_j . E_i  (A = E_j rows, B = E_i rows), k order kc + 4 q + e; two accumulators
     // break the dependent MFMA chain; the next j-tile's operands are requested before this tile's MFMAs
-    const float *ej = (IDX && HOLD_I && PF) ? nullptr : erow(min(B - 1, j0 + c)) + 4 * q;
+    const float *ej = g.e + (size_t)min(B - 1, j0 + c) * d + 4 * q;
     // operands of the second product (rows j0 + 4 q + r of E_B, features fbase + 64 G + 4 c ..): requested now,
     // branch-free, so their latency hides under the 4 NCH MFMAs of the first product
     float4 p2[4][NG];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float *er = IDX ? g.e + (size_t)rid_p2[r] * d : g.e + (size_t)min(B - 1, j0 + 4 * q + r) * d;
+      const float *er = g.e + (size_t)min(B - 1, j0 + 4 * q + r) * d;
 #pragma unroll
       for (int G = 0; G < NG; ++G) {
         const int f = fbase + 64 * G + 4 * c;
@@ -295,11 +236,6 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
     if (HOLD_I && !PF) {
 #pragma unroll
       for (int k = 0; k < NCH; ++k) aj[k] = (EXACT || 16 * k < d) ? ld4(ej + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (IDX) {
-        const int jn = jt + nslots;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rid_p2[r] = rtab[min(B - 1, (jn < nj ? jn : jt) * 16 + 4 * q + r)];
-      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
@@ -311,15 +247,9 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
     } else if (HOLD_I) {
       float4 an[NCH];
       const int jn = jt + nslots;
-      const float *ejn = IDX ? g.e + (size_t)rid_an * d + 4 * q : g.e + (size_t)min(B - 1, (jn < nj ? jn : jt) * 16 + c) * d + 4 * q;
+      const float *ejn = g.e + (size_t)min(B - 1, (jn < nj ? jn : jt) * 16 + c) * d + 4 * q;
 #pragma unroll
       for (int k = 0; k < NCH; ++k) an[k] = (EXACT || 16 * k < d) ? ld4(ejn + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (IDX) {   // the table entries of the NEXT trip's fetches
-        const int j1 = jn < nj ? jn : jt, j2 = (jn + nslots) < nj ? jn + nslots : j1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rid_p2[r] = rtab[min(B - 1, j1 * 16 + 4 * q + r)];
-        rid_an = rtab[min(B - 1, j2 * 16 + c)];
-      }
       __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks every load next to its first use (one exposed
                                           // round trip per 4 MFMAs); issue them all here, consume them later
 #pragma unroll
@@ -332,11 +262,6 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
 #pragma unroll
       for (int k = 0; k < NCH; ++k) aj[k] = an[k];
     } else {
-      if (IDX) {
-        const int jn = jt + nslots;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rid_p2[r] = rtab[min(B - 1, (jn < nj ? jn : jt) * 16 + 4 * q + r)];
-      }
       for (int kc = 0; kc < d; kc += 16) {
         const float4 a4 = ld4(ej + kc);
         const float4 b4 = ld4(ei + kc);
@@ -396,143 +321,25 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
     }
     __syncthreads();
   }
+  // tile (G, e), lane (c, q), reg r: node i0 + c, feature fbase + 64 G + 4 (4 q + r) + e
+  if (w == 0 && i_ok) {
+    float *out = g.de_part + ((size_t)blockIdx.y * B + (i0 + c)) * d;
+#pragma unroll
+    for (int G = 0; G < NG; ++G)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = fbase + 64 * G + 16 * q + 4 * r;
+        if (EXACT || f < d) st4(out + f, make_float4(acc[G][0][r], acc[G][1][r], acc[G][2][r], acc[G][3][r]));
+      }
+  }
   // ---- loss partial (only the z == 0 slab counts it)
   const double ws = wave_sum_d((double)lacc);
   if (lane == 0) lsum[w] = ws;
   __syncthreads();
-  // tile (G, e), lane (c, q), reg r: node i0 + c, feature fbase + 64 G + 4 (4 q + r) + e
-  if (w == 0) {
-    if (i_ok) {
-      float *out = g.de_part + ((size_t)blockIdx.y * B + (i0 + c)) * d;
-#pragma unroll
-      for (int G = 0; G < NG; ++G)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int f = fbase + 64 * G + 16 * q + 4 * r;
-          if (EXACT || f < d) st4(out + f, make_float4(acc[G][0][r], acc[G][1][r], acc[G][2][r], acc[G][3][r]));
-        }
-    }
-    if (lane == 0 && blockIdx.z == 0) {
-      double t = 0.0;
-      for (int k = 0; k < kLossWaves; ++k) t += lsum[k];
-      g.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = t;
-    }
-    if (TAIL) __threadfence();   // this workgroup's partials (all stored by wave 0) are visible device-wide before it counts itself in
-  }
-  if (!TAIL) return;
-
-  // ---- tail: the last of the tile's js workgroups finishes the tile (every workgroup passes here exactly once: no waiting).
-  // A dependent global round trip costs ~1 us on this machine, so the tail is laid out as few of them as possible: [release fence]
-  // [arrival atomic] [one batch of loads: the slabs' partials, E / P rows, 1/||x||, the weight fragments] [compute, stores]; the
-  // job-wide arrival count for the loss travels underneath the compute.
-  const LossTail &T = g.t;
-  const int d4 = d / 4;
-  int lg = 2;
-  while ((1 << lg) < d4 && lg < 6) ++lg;
-  const int lpr = 1 << lg, rpw = 64 >> lg;
-  const int li = lane & (lpr - 1);
-  constexpr int RP = 16 / kLossWaves;         // rows of the tile per wave at most (rpw >= 1 rows per pass, kLossWaves * rpw rows per pass and workgroup)
-  // what does not depend on the other slabs is fetched before the arrival is known: the members' rows / keep flags (a few bytes)
-  int nodes[RP];
-  float keeps[RP];
-#pragma unroll
-  for (int k = 0; k < RP; ++k) {
-    const int rr = w * rpw + (lane >> lg) + k * kLossWaves * rpw;
-    const int rc = min(i0 + min(rr, 15), B - 1);
-    nodes[k] = T.rows ? T.rows[rc] : (IDX ? rtab[rc] : rc);
-    keeps[k] = T.keep ? T.keep[rc] : 1.f;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned old = atomicAdd(&T.tile_cnt[blockIdx.x], 1u);
-    s_last = (old == (unsigned)g.js - 1u) ? 1 : 0;
-    if (s_last) (void)atomicExch(&T.tile_cnt[blockIdx.x], 0u);   // nobody else touches it any more; zero again for the next launch
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();   // the other slabs' partials, written before their arrival, are read from memory below
-  // job-wide arrival (the loss is summed by the workgroup that finishes the last tile): the count is requested now and looked at
-  // after the tile is done.  Every slab of this tile fenced its loss partial before it arrived above, and this fence sits between
-  // that observation and this arrival, so whoever sees the last count may read every partial.
-  unsigned all_old = 0;
-  if (threadIdx.x == 0) all_old = atomicAdd(&T.tile_cnt[gridDim.x], 1u);
-  float *dp_tile = reinterpret_cast<float *>(red);   // [16][d + 4]: the B operand of the input-gradient MFMAs (the tree is done with `red`;
-  const int ds = d + 4;                              // rows 16 B apart in the banks: the 16 rows of a fragment read do not collide)
-  constexpr int VPL = NG <= 4 ? 1 : 2;               // float4s of a row per lane: d4 / 64 rounded up
-  constexpr int NTW = 2 * NG;                        // 16-feature blocks per wave: (2 d / 4) / 16 with d = 64 NG
-  constexpr int NCHK = 4 * NG;                       // 16-wide k chunks of the input gradient
-  constexpr bool WREG = NG <= 2;                     // the wave's weight fragments fit the registers the sweep no longer needs
-  const int jw0 = w * 32 * NG;
-  const bool hi = jw0 >= d;
-  const float *wt = T.w1t ? (hi ? T.w2t : T.w1t) + (size_t)((hi ? jw0 - d : jw0) + c) * d + 4 * q : nullptr;
-  float4 wf[WREG ? NCHK : 1][WREG ? NTW : 1];
-  if (WREG && T.w1t) {
-#pragma unroll
-    for (int k = 0; k < NCHK; ++k)
-#pragma unroll
-      for (int u = 0; u < NTW; ++u) wf[k][u] = ld4(wt + (size_t)(16 * u) * d + 16 * k);
-  }
-#pragma unroll
-  for (int k = 0; k < RP; ++k) {
-    const int rr = w * rpw + (lane >> lg) + k * kLossWaves * rpw;   // (the lanes of a row's group share rr: the shuffles inside stay whole)
-    if (rr < 16) {
-      const int r = i0 + rr;
-      const bool ok = r < B;
-      const int rc = ok ? r : B - 1;
-      const int node = nodes[k];
-      if (ok && T.pos_set && li == 0) {
-        const int key = T.pos_ids ? T.pos_ids[r] : node;
-        if (key >= 0) T.pos_set[key] = r;
-      }
-      finish_row<VPL>(ok, r, li, lpr, d4, g.js, B, g.de_part, erow(rc), T.inv_den[node], keeps[k], T.p + (size_t)node * d, T.c, T.dx_b, T.dp_b,
-                      T.w1t ? dp_tile + (size_t)rr * ds : nullptr, T.dgrad_all != 0);
-      if (!ok && T.w1t)
-        for (int f4 = li; f4 < d4; f4 += lpr) *reinterpret_cast<float4 *>(dp_tile + (size_t)rr * ds + f4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  if (T.w1t) {
-    // [g_ax | g_am][i0 .. i0 + 16) = dP_tile . [W1 ; W2]: wave w takes output features [w d / 2, (w + 1) d / 2) of the 2 d; the k order
-    // (chunk by chunk, e = 0..3 inside) is gemm_nt_lds_kernel's, so the rows keep the bits of the stand-alone launch
-    __syncthreads();
-    const float *brow = dp_tile + (size_t)c * ds + 4 * q;
-    f32x4 o[NTW];
-#pragma unroll
-    for (int u = 0; u < NTW; ++u) o[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < NCHK; ++k) {
-      const float4 bv = *reinterpret_cast<const float4 *>(brow + 16 * k);
-      float4 av[NTW];
-#pragma unroll
-      for (int u = 0; u < NTW; ++u) av[u] = WREG ? wf[k][u] : ld4(wt + (size_t)(16 * u) * d + 16 * k);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float bs = e == 0 ? bv.x : e == 1 ? bv.y : e == 2 ? bv.z : bv.w;
-#pragma unroll
-        for (int u = 0; u < NTW; ++u) {
-          const float as = e == 0 ? av[u].x : e == 1 ? av[u].y : e == 2 ? av[u].z : av[u].w;
-          o[u] = mfma16l(as, bs, o[u]);
-        }
-      }
-    }
-    if (i_ok) {
-      float *out = (hi ? T.gam_b : T.gax_b) + (size_t)(i0 + c) * d + (hi ? jw0 - d : jw0) + 4 * q;
-#pragma unroll
-      for (int u = 0; u < NTW; ++u) st4(out + 16 * u, make_float4(o[u][0], o[u][1], o[u][2], o[u][3]));
-    }
-  }
-  // ---- the loss itself: by the workgroup that finishes the last tile (loss_finish_bwd_kernel's sum, same order)
-  if (w == 0) {
-    int last_all = (lane == 0 && all_old == gridDim.x - 1u) ? 1 : 0;
-    last_all = __shfl(last_all, 0, 64);
-    if (last_all) {
-      if (lane == 0) (void)atomicExch(&T.tile_cnt[gridDim.x], 0u);
-      __threadfence();
-      const int nloss = (int)(gridDim.x * gridDim.y);
-      double t = 0.0;
-      for (int k = lane; k < nloss; k += 64) t += g.loss_part[k];
-      t = wave_sum_d(t);
-      if (lane == 0) T.loss_out[0] = (float)(-0.5 * (double)g.alpha * t / ((double)B * (double)B));
-    }
+  if (threadIdx.x == 0 && blockIdx.z == 0) {
+    double t = 0.0;
+    for (int k = 0; k < kLossWaves; ++k) t += lsum[k];
+    g.loss_part[blockIdx.y * gridDim.x + blockIdx.x] = t;
   }
 }
 
@@ -555,8 +362,8 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(int b, int d, int js, 
   }
 }
 
-// plan path: loss_finish + the backward of F.normalize and F.elu on the batch rows in one launch (the stand-alone form of the sweep's
-// tail, for the shapes the tail does not cover).
+// plan path: loss_finish + the backward of F.normalize and F.elu on the batch rows in one launch (the widths
+// loss_finish_dgrad_kernel does not cover).
 // One lane group per batch row: de = 2 sum_js de_part (the row of dLoss/dE_B), then
 // dx = (de - e (e . de)) * inv_den[node], dp = c * dx (.) elu'(p[node]); e rows come from the gathered E_B, or (erows != NULL) from
 // the embedding matrix through the row list.
@@ -591,6 +398,111 @@ __global__ __launch_bounds__(256) void loss_finish_bwd_kernel(int b, int d4, int
                   false);
 }
 
+// finish + the batch rows' input gradient in ONE launch (round 4; d in {64, 128, 256}): what used to be loss_finish_bwd_kernel followed
+// by the batch-row launch of gemm_nt_lds_kernel<.., EPI_SPLIT> -- two ~5 us launches, each a short chain of dependent global round
+// trips (~1 us apiece on this machine) around < 1 us of work.  One workgroup per 16 batch rows: the 4 waves finish the rows (finish_row:
+// loss_finish_bwd_kernel's lanes and order), park the 16 x d tile of dP in LDS, and multiply it with [W1 ; W2] (pre-transposed): wave w
+// takes output features [w d / 2, (w + 1) d / 2) of the 2 d, its weight fragments requested in the SAME round trip as the rows'
+// operands (NG <= 2: into registers).  The k order (chunk by chunk, e = 0..3 inside) is gemm_nt_lds_kernel's, so [g_ax | g_am] keeps
+// the bits of the stand-alone launch.  (Folding all of this into the sweep itself -- the last-arriving workgroup of an i tile as
+// finisher -- was built and measured slower: profiles/r04_loss_fold_ab.txt.)
+struct FinishDgrad {
+  int b, d, js, nloss;
+  const float *de_part;
+  const double *loss_part;
+  float alpha;
+  const float *e_b;          // [b][d] gathered batch rows
+  const int32_t *rows;       // row of inv_den / p per member (NULL: the member's position -- a shard's gathered batch)
+  const int32_t *pos_ids;    // key of the batch-position map per member (nullable with pos_set)
+  int32_t *pos_set;          // nullable
+  const float *keep;         // nullable: 0 where another shard owns the member (its dx_b / dp_b rows are written as zeros)
+  const float *inv_den, *p;
+  float c;
+  float *dx_b, *dp_b, *loss_out;
+  const float *w1t, *w2t;
+  float *gax_b, *gam_b;
+  int dgrad_all;             // the input gradient of EVERY member (a shard that holds p / inv_den of the whole batch), else of the kept ones
+};
+
+template <int NG>
+__global__ __launch_bounds__(256) void loss_finish_dgrad_kernel(FinishDgrad T) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *dp_tile = reinterpret_cast<float *>(smem);   // [16][d + 4]: rows 16 B apart in the banks (the 16 rows of a fragment read do not collide)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int d = T.d, B = T.b, d4 = d / 4, ds = d + 4;
+  const int i0 = blockIdx.x * 16;
+  int lg = 2;
+  while ((1 << lg) < d4 && lg < 6) ++lg;
+  const int lpr = 1 << lg, rpw = 64 >> lg;
+  const int li = lane & (lpr - 1);
+  constexpr int RP = 4;                              // rows of the tile per wave at most (4 waves, rpw >= 1 rows per pass)
+  constexpr int NTW = 2 * NG;                        // 16-feature blocks per wave: (2 d / 4) / 16 with d = 64 NG
+  constexpr int NCHK = 4 * NG;                       // 16-wide k chunks
+  constexpr bool WREG = NG <= 2;                     // a wave's weight fragments in registers (32 float4 at d = 128)
+  const int jw0 = w * 32 * NG;
+  const bool hi = jw0 >= d;
+  const float *wt = (hi ? T.w2t : T.w1t) + (size_t)((hi ? jw0 - d : jw0) + c) * d + 4 * q;
+  float4 wf[WREG ? NCHK : 1][WREG ? NTW : 1];
+  if (WREG) {
+#pragma unroll
+    for (int k = 0; k < NCHK; ++k)
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) wf[k][u] = ld4(wt + (size_t)(16 * u) * d + 16 * k);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    double t = 0.0;
+    for (int k = threadIdx.x; k < T.nloss; k += 64) t += T.loss_part[k];
+    t = wave_sum_d(t);
+    if (threadIdx.x == 0) T.loss_out[0] = (float)(-0.5 * (double)T.alpha * t / ((double)B * (double)B));
+  }
+#pragma unroll
+  for (int k = 0; k < RP; ++k) {
+    const int rr = w * rpw + (lane >> lg) + k * 4 * rpw;   // (the lanes of a row's group share rr: the shuffles inside stay whole)
+    if (rr < 16) {
+      const int r = i0 + rr;
+      const bool ok = r < B;
+      const int rc = ok ? r : B - 1;
+      const int node = T.rows ? T.rows[rc] : rc;
+      const float keepv = T.keep ? T.keep[rc] : 1.f;
+      if (ok && T.pos_set && li == 0) {
+        const int key = T.pos_ids ? T.pos_ids[r] : node;
+        if (key >= 0) T.pos_set[key] = r;
+      }
+      finish_row<1>(ok, r, li, lpr, d4, T.js, B, T.de_part, T.e_b + (size_t)rc * d, T.inv_den[node], keepv, T.p + (size_t)node * d, T.c, T.dx_b,
+                    T.dp_b, dp_tile + (size_t)rr * ds, T.dgrad_all != 0);
+      if (!ok)
+        for (int f4 = li; f4 < d4; f4 += lpr) *reinterpret_cast<float4 *>(dp_tile + (size_t)rr * ds + f4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  const float *brow = dp_tile + (size_t)c * ds + 4 * q;
+  f32x4 o[NTW];
+#pragma unroll
+  for (int u = 0; u < NTW; ++u) o[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NCHK; ++k) {
+    const float4 bv = *reinterpret_cast<const float4 *>(brow + 16 * k);
+    float4 av[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) av[u] = WREG ? wf[k][u] : ld4(wt + (size_t)(16 * u) * d + 16 * k);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float bs = e == 0 ? bv.x : e == 1 ? bv.y : e == 2 ? bv.z : bv.w;
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) {
+        const float as = e == 0 ? av[u].x : e == 1 ? av[u].y : e == 2 ? av[u].z : av[u].w;
+        o[u] = mfma16l(as, bs, o[u]);
+      }
+    }
+  }
+  if (i0 + c < B) {
+    float *out = (hi ? T.gam_b : T.gax_b) + (size_t)(i0 + c) * d + (hi ? jw0 - d : jw0) + 4 * q;
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) st4(out + 16 * u, make_float4(o[u][0], o[u][1], o[u][2], o[u][3]));
+  }
+}
+
 // debug knob "loss_wgs": workgroups the (i-tile x j-split) grid aims at.  One workgroup per CU wins at B = 2048 (gather + sweep + finish,
 // d = 128: 128 / 256 / 384 / 512 / 768 / 1024 workgroups -> 49.4 / 31.4 / 38.3 / 34.6 / 39.8 / 43.9 us; d = 256: 124.0 at 256 vs 126.3 at 512)
 
@@ -607,17 +519,12 @@ static void loss_geometry(int32_t b, int32_t d, int &ni, int &js, int &nz, int &
   nz = ceil_div(groups, ng);
 }
 
-// workspace: [4 KB header: the tail's arrival counters, at a place that does not move with b] [de_part] [loss_part] [E_B]
-constexpr size_t kLossHeader = 4096;
-constexpr int kLossTailMaxTiles = (int)(kLossHeader / sizeof(unsigned)) - 1;
-constexpr int kLossIdxMaxBatch = 8192;   // rows of the LDS table (32 KB)
-
 size_t loss_workspace_bytes(int32_t b, int32_t d) {
   int ni, js, nz, ng;
   loss_geometry(b, d, ni, js, nz, ng);
   size_t de = sizeof(float) * (size_t)js * b * d;
   de = (de + 15) / 16 * 16;
-  return kLossHeader + de + (sizeof(double) * (size_t)ni * js + 15) / 16 * 16 + sizeof(float) * (size_t)b * d;
+  return de + (sizeof(double) * (size_t)ni * js + 15) / 16 * 16 + sizeof(float) * (size_t)b * d;
 }
 
 // The workspace is NOT monotone in b: the number of j slabs grows as the i tiles get fewer (B = 2048 -> 128 tiles x 2 slabs, 3 B d floats;
@@ -634,7 +541,6 @@ size_t loss_workspace_bytes_max(int32_t b_max, int32_t d) {
 
 struct LossLaunch {
   int ni, js, nz, ng;
-  unsigned *cnt;
   float *de_part;
   double *loss_part;
   float *e_b;
@@ -645,11 +551,9 @@ static void loss_layout(int32_t d, int32_t b, void *ws, LossLaunch &L) {
   size_t de_bytes = sizeof(float) * (size_t)L.js * b * d;
   de_bytes = (de_bytes + 15) / 16 * 16;
   const size_t lp_bytes = (sizeof(double) * (size_t)L.ni * L.js + 15) / 16 * 16;
-  char *base = (char *)ws + kLossHeader;
-  L.cnt = (unsigned *)ws;
-  L.de_part = (float *)base;
-  L.loss_part = (double *)(base + de_bytes);
-  L.e_b = (float *)(base + de_bytes + lp_bytes);
+  L.de_part = (float *)ws;
+  L.loss_part = (double *)((char *)ws + de_bytes);
+  L.e_b = (float *)((char *)ws + de_bytes + lp_bytes);
 }
 
 // stage 1: E_B = e[idx] (zero where keep == 0) into the workspace; returns where it is
@@ -660,60 +564,27 @@ static int loss_gather(int32_t d, const float *e, const int32_t *idx, const floa
   return GSS_OK;
 }
 
-// debug knobs "loss_idx" / "loss_tail": 0 = the gather launch / the finish and batch-row input-gradient launches stay separate kernels
-bool loss_tail_available(int32_t d, int32_t b) {
-  int ni, js, nz, ng;
-  loss_geometry(b, d, ni, js, nz, ng);
-  return K().loss_tail != 0 && d == 64 * ng && nz == 1 && ng <= 4 && ni <= kLossTailMaxTiles;
-}
-bool loss_idx_available(int32_t b) { return K().loss_idx != 0 && b <= kLossIdxMaxBatch; }
-
-// stage 2: the fused S / G / dE sweep.  idx mode (g.idx != NULL): operand rows through the LDS table; tail: see LossTail
-static int loss_sweep(hipStream_t st, LossLaunch &L, LossArgs g, bool tail) {
-  const int d = g.d;
+// stage 2: the fused S / G / dE sweep over the gathered rows `e_b`
+static int loss_sweep(int32_t d, int32_t b, float beta, float alpha, const float *e_b, hipStream_t st, LossLaunch &L) {
+  LossArgs g{d, b, L.js, e_b, beta, alpha, L.de_part, L.loss_part};
   dim3 grid(L.ni, L.js, L.nz), block(64 * kLossWaves);
-  const bool idx = g.idx != nullptr;
-  const size_t lds = (size_t)2 * L.ng * 4 * 64 * sizeof(float4) + (idx ? sizeof(int32_t) * (size_t)g.b : 0);
+  const size_t lds = (size_t)2 * L.ng * 4 * 64 * sizeof(float4);
   const bool exact = (d == 64 * L.ng) && L.nz == 1;
-  if (tail && !(exact && L.ng <= 4 && L.ni <= kLossTailMaxTiles)) return fail(GSS_EINVAL, "loss_sweep: the fused tail is not available at d=%d, b=%d", d, g.b);
-  if (idx && g.b > kLossIdxMaxBatch) return fail(GSS_EINVAL, "loss_sweep: the row table does not fit b=%d", g.b);
-  g.js = L.js;
-  g.de_part = L.de_part;
-  g.loss_part = L.loss_part;
-  g.t.tile_cnt = L.cnt;
-#define GSS_LOSS_LAUNCH(NGV, EX, IX, TL) \
-  hipLaunchKernelGGL((loss_fused_kernel<NGV, EX, IX, TL>), grid, block, lds_request(loss_fused_kernel<NGV, EX, IX, TL>, lds, K().loss_lds_kb), st, g)
-#define GSS_LOSS_CASE(NGV)                            \
-  case NGV:                                           \
-    if (exact && tail && idx)                         \
-      GSS_LOSS_LAUNCH(NGV, true, true, true);         \
-    else if (exact && tail)                           \
-      GSS_LOSS_LAUNCH(NGV, true, false, true);        \
-    else if (exact && idx)                            \
-      GSS_LOSS_LAUNCH(NGV, true, true, false);        \
-    else if (exact)                                   \
-      GSS_LOSS_LAUNCH(NGV, true, false, false);       \
-    else if (idx)                                     \
-      GSS_LOSS_LAUNCH(NGV, false, true, false);       \
-    else                                              \
-      GSS_LOSS_LAUNCH(NGV, false, false, false);      \
+#define GSS_LOSS_CASE(NGV)                                                              \
+  case NGV:                                                                             \
+    if (exact)                                                                          \
+      hipLaunchKernelGGL((loss_fused_kernel<NGV, true>), grid, block, lds_request(loss_fused_kernel<NGV, true>, lds, K().loss_lds_kb), st, g);      \
+    else                                                                                \
+      hipLaunchKernelGGL((loss_fused_kernel<NGV, false>), grid, block, lds_request(loss_fused_kernel<NGV, false>, lds, K().loss_lds_kb), st, g);     \
     break;
   switch (L.ng) {
     GSS_LOSS_CASE(1)
     GSS_LOSS_CASE(2)
     GSS_LOSS_CASE(4)
     default:
-      if (exact && idx)
-        GSS_LOSS_LAUNCH(8, true, true, false);
-      else if (exact)
-        GSS_LOSS_LAUNCH(8, true, false, false);
-      else if (idx)
-        GSS_LOSS_LAUNCH(8, false, true, false);
-      else
-        GSS_LOSS_LAUNCH(8, false, false, false);
+      GSS_LOSS_CASE(8)
   }
 #undef GSS_LOSS_CASE
-#undef GSS_LOSS_LAUNCH
   GSS_LAUNCH_CHECK("loss_fused_kernel");
   return GSS_OK;
 }
@@ -725,13 +596,7 @@ int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32
   hipStream_t st = as_stream(stream);
   LossLaunch L;
   if (int rc = loss_gather(d, e, idx, nullptr, b, ws, st, L)) return rc;
-  LossArgs g{};
-  g.d = d;
-  g.b = b;
-  g.e = L.e_b;
-  g.beta = beta;
-  g.alpha = alpha;
-  if (int rc = loss_sweep(st, L, g, false)) return rc;
+  if (int rc = loss_sweep(d, b, beta, alpha, L.e_b, st, L)) return rc;
   const int nb = ceil_div((int64_t)b * d / 4, 256);
   hipLaunchKernelGGL(loss_finish_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, b, d, L.js, L.ni * L.js, L.de_part, L.loss_part,
                      alpha, de_b, loss_out);
@@ -748,7 +613,7 @@ int loss_fwd_bwd_fused(int32_t n, int32_t d, const float *e, const int32_t *idx,
   return loss_fused_gathered(d, b, beta, alpha, loss_out, idx, idx, nullptr, inv_den, p, c, dx_b, dp_b, pos_set, ws, stream);
 }
 
-// the two halves of loss_fwd_bwd_fused, for a sharded plan that all-reduces the gathered rows in between
+// the two halves of loss_fwd_bwd_fused, for a plan that gathers the rows itself
 int loss_gather_rows(int32_t d, const float *e, const int32_t *rows, const float *keep, int32_t b, void *ws, float **e_b_out, void *stream) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(b > 0 && (e || keep) && rows && ws && e_b_out, "loss_gather_rows: null operand or empty batch");  // e may be null on an empty shard
@@ -804,58 +669,47 @@ int loss_fused_gathered(int32_t d, int32_t b, float beta, float alpha, float *lo
   s.dx_b = dx_b;
   s.dp_b = dp_b;
   s.pos_set = pos_set;
-  s.no_tail = true;
   bool dgrad_done = false;
   return loss_step(s, ws, stream, &dgrad_done);
 }
 
-// The loss of one step on the plan's path: sweep (+ gather in its prologue when s.idx is given) + finish (+ the batch rows' input
-// gradient when s.w1t is given), in as few launches as the shapes allow.  *dgrad_done says whether gax_b / gam_b were written.
+// debug knob "loss_dgrad": 1 (default) = finish + the batch rows' input gradient in one launch (loss_finish_dgrad_kernel), 0 = two
+bool loss_dgrad_available(int32_t d, int32_t b) {
+  int ni, js, nz, ng;
+  loss_geometry(b, d, ni, js, nz, ng);
+  return K().loss_dgrad != 0 && d == 64 * ng && nz == 1 && ng <= 4;
+}
+
+// The loss of one step on the plan's path, over rows gathered beforehand: the sweep, then the finish -- with the batch rows' input
+// gradient in the same launch when s.w1t is given and the width allows.  *dgrad_done says whether gax_b / gam_b were written.
 int loss_step(const LossStep &s, void *ws, void *stream, bool *dgrad_done) {
   if (int rc = check_d(s.d)) return rc;
   GSS_REQUIRE(s.b > 0 && s.loss_out && s.inv_den && s.p && s.dx_b && s.dp_b && ws && dgrad_done, "loss_step: null operand");
-  GSS_REQUIRE(!s.idx || (s.emb && loss_idx_available(s.b)), "loss_step: the row-table form needs the embeddings and b <= %d", kLossIdxMaxBatch);
+  GSS_REQUIRE(s.pos_ids || s.rows || !s.pos_set, "loss_step: a batch-position map needs its keys");
+  GSS_REQUIRE(!s.w1t || (s.w2t && s.gax_b && s.gam_b), "loss_step: incomplete input-gradient operands");
   hipStream_t st = as_stream(stream);
   const int d = s.d, b = s.b;
   LossLaunch L;
   loss_layout(d, b, ws, L);
-  const bool tail = !s.no_tail && loss_tail_available(d, b);
-  LossArgs g{};
-  g.d = d;
-  g.b = b;
-  g.e = s.idx ? s.emb : (s.e_b ? s.e_b : L.e_b);
-  g.beta = s.beta;
-  g.alpha = s.alpha;
-  g.idx = s.idx;
-  g.node_map = s.node_map;
-  g.rloc_out = s.rloc_out;
-  g.pid_out = s.pid_out;
-  LossTail &T = g.t;
-  T.rows = s.rows;
-  T.pos_ids = s.pos_ids;
-  T.pos_set = s.pos_set;
-  T.keep = s.keep;
-  T.inv_den = s.inv_den;
-  T.p = s.p;
-  T.c = s.c;
-  T.dx_b = s.dx_b;
-  T.dp_b = s.dp_b;
-  T.loss_out = s.loss_out;
-  T.w1t = s.w1t;
-  T.w2t = s.w2t;
-  T.gax_b = s.gax_b;
-  T.gam_b = s.gam_b;
-  T.dgrad_all = s.dgrad_all ? 1 : 0;
-  GSS_REQUIRE(!s.w1t || (s.w2t && s.gax_b && s.gam_b), "loss_step: incomplete input-gradient operands");
-  if (int rc = loss_sweep(st, L, g, tail)) return rc;
-  *dgrad_done = tail && s.w1t != nullptr;
-  if (tail) return GSS_OK;
-  // separate finish launch (shapes the tail does not cover, or knob loss_tail = 0).  In idx mode the stand-alone kernel reads the
-  // rows the sweep's workgroup 0 stored (rloc_out), or the caller's prepared rows
-  const int32_t *rows = s.rows ? s.rows : s.rloc_out;      // NULL without a row table: inv_den / p are per member
-  GSS_REQUIRE(rows || !s.idx, "loss_step: the separate finish needs translated rows (rloc_out)");
-  const int32_t *pos_ids = s.pos_ids ? s.pos_ids : rows;
-  GSS_REQUIRE(pos_ids || !s.pos_set, "loss_step: a batch-position map needs its keys");
+  const float *e_b = s.e_b ? s.e_b : L.e_b;
+  if (int rc = loss_sweep(d, b, s.beta, s.alpha, e_b, st, L)) return rc;
+  const int32_t *pos_ids = s.pos_ids ? s.pos_ids : s.rows;
+  *dgrad_done = false;
+  if (s.w1t && loss_dgrad_available(d, b)) {
+    FinishDgrad T{b, d, L.js, L.ni * L.js, L.de_part, L.loss_part, s.alpha, e_b, s.rows, pos_ids, s.pos_set, s.keep, s.inv_den, s.p, s.c,
+                  s.dx_b, s.dp_b, s.loss_out, s.w1t, s.w2t, s.gax_b, s.gam_b, s.dgrad_all ? 1 : 0};
+    dim3 grid(L.ni), block(256);
+    const size_t lds = sizeof(float) * 16 * (size_t)(d + 4);
+    if (L.ng == 1)
+      hipLaunchKernelGGL((loss_finish_dgrad_kernel<1>), grid, block, lds, st, T);
+    else if (L.ng == 2)
+      hipLaunchKernelGGL((loss_finish_dgrad_kernel<2>), grid, block, lds, st, T);
+    else
+      hipLaunchKernelGGL((loss_finish_dgrad_kernel<4>), grid, block, lds, st, T);
+    GSS_LAUNCH_CHECK("loss_finish_dgrad_kernel");
+    *dgrad_done = true;
+    return GSS_OK;
+  }
   const int d4 = d / 4;
   int lg = 2;
   while ((1 << lg) < d4 && lg < 6) ++lg;
@@ -863,7 +717,7 @@ int loss_step(const LossStep &s, void *ws, void *stream, bool *dgrad_done) {
   dim3 grid(ceil_div(b, 4 * (64 >> lg))), block(256);
 #define GSS_FIN(V)                                                                                                              \
   hipLaunchKernelGGL((loss_finish_bwd_kernel<V>), grid, block, 0, st, b, d4, lg, L.js, L.ni * L.js, L.de_part, L.loss_part, s.alpha, \
-                     g.e, s.idx ? rows : nullptr, rows, pos_ids, s.keep, s.inv_den, s.p, s.c, s.dx_b, s.dp_b, s.pos_set, s.loss_out)
+                     e_b, (const int32_t *)nullptr, s.rows, pos_ids, s.keep, s.inv_den, s.p, s.c, s.dx_b, s.dp_b, s.pos_set, s.loss_out)
   if (vpl == 1)
     GSS_FIN(1);
   else if (vpl == 2)

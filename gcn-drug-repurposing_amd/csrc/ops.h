@@ -134,35 +134,27 @@ int loss_gather_batch(int32_t d, const float *e, const float *p, const float *in
 int loss_fused_gathered(int32_t d, int32_t b, float beta, float alpha, float *loss_out, const int32_t *idx, const int32_t *pos_ids,
                         const float *keep, const float *inv_den, const float *p, float c, float *dx_b, float *dp_b, int32_t *pos_set,
                         void *ws, void *stream);
-// One step's loss on the plan's path (loss.hip loss_step): the sweep, with the batch-row gather + id translation in its prologue when
-// `idx` is given (single GPU) and finish + normalise' / ELU' + the batch rows' input gradient in its tail where the shapes allow
+// One step's loss on the plan's path (loss.hip loss_step), over batch rows gathered beforehand: the sweep + the finish, with the batch
+// rows' input gradient in the finish launch where the width allows
 struct LossStep {
   int32_t d, b;
   float beta, alpha;
   float *loss_out;
-  // operand rows: either the batch itself, translated in the sweep's prologue and fetched from the embedding matrix ...
-  const int32_t *idx, *node_map;    // idx != NULL: row table mode (single GPU, loss_idx_available(b))
-  const float *emb;
-  int32_t *rloc_out, *pid_out;      // nullable: the translated ids for the kernels after the loss
-  // ... or rows gathered beforehand: the workspace's E_B, or e_b when given ([b][d], e.g. the all-reduced rows of a shard)
-  const float *e_b;
-  // finish
-  const int32_t *rows;              // row of inv_den / p per member (NULL in row table mode: the table)
+  const float *e_b;                 // [b][d] gathered rows (NULL: the workspace's E_B, written by loss_gather_rows*)
+  const int32_t *rows;              // row of inv_den / p per member (NULL: the member's position -- a shard's gathered batch)
   const int32_t *pos_ids;           // key of the batch-position map per member (NULL: as rows)
   int32_t *pos_set;                 // nullable
-  const float *keep;                // nullable
+  const float *keep;                // nullable: 0 where another shard owns the member
   const float *inv_den, *p;
   float c;
   float *dx_b, *dp_b;
   // the batch rows' input gradient [g_ax | g_am] = dP [W1 ; W2] (nullable: w1t == NULL)
   const float *w1t, *w2t;
   float *gax_b, *gam_b;
-  bool dgrad_all;                   // see LossTail
-  bool no_tail;                     // force the separate finish launch
+  bool dgrad_all;                   // the input gradient of EVERY member (a shard that holds p / inv_den of the whole batch)
 };
 int loss_step(const LossStep &s, void *ws, void *stream, bool *dgrad_done);
-bool loss_tail_available(int32_t d, int32_t b);
-bool loss_idx_available(int32_t b);
+bool loss_dgrad_available(int32_t d, int32_t b);
 int transpose2(int32_t dim, const float *a, const float *b, float *at, float *bt, void *stream);
 size_t loss_workspace_bytes(int32_t b, int32_t d);
 size_t loss_workspace_bytes_max(int32_t b_max, int32_t d);   // enough for every batch of 1..b_max rows (the size is not monotone in b)

@@ -816,8 +816,8 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
   const bool sparse_top = L > 1 && spmm_sparse_available();
   GSS_REQUIRE(p->P == 1 || L == 1 || sparse_top, "a sharded plan needs the balanced SpMM (spmm_variant 2)");
   const bool mapped = plan_batch_mapped(p);
-  // the batch rows' input gradient rides in the loss kernel's tail where the shapes allow: it needs the transposed weights now
-  const bool want_dgrad = sparse_top && loss_tail_available(D.d, b) && K().loss_tail == 1;
+  // the batch rows' input gradient shares the launch of the loss's finish where the width allows: it needs the transposed weights now
+  const bool want_dgrad = sparse_top && loss_dgrad_available(D.d, b);
   if (want_dgrad && !wt_ok) {
     PROF(GSS_PROF_ELEMENTWISE);
     if (int rc = transpose2(D.d, p->w1, p->w2, p->w1t, p->w2t, stream)) return rc;
@@ -842,23 +842,21 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
     s.gax_b = p->gab;
     s.gam_b = p->gab + (size_t)b * D.d;
   }
-  if (p->P == 1 && loss_idx_available(b)) {
-    // one GPU: no gather launch -- the sweep fetches the batch rows of the embedding matrix through a row table its prologue builds
-    // (E_B = emb[idx], model.py:216-217), the id translation of a relabelled graph included
-    if (!mapped) {
-      s.idx = idx;
-      s.rows = s.pos_ids = idx;
-    } else if (prepared) {
-      s.idx = p->rloc;
-      s.rows = p->rloc;
-      s.pos_ids = p->pid;
-    } else {
-      s.idx = idx;
-      s.node_map = D.node_map;
-      s.rloc_out = p->rloc;
-      s.pid_out = p->pid;
+  if (p->P == 1) {
+    float *e_b = nullptr;
+    {
+      // E_B = emb[idx] (model.py:216-217), the batch-id translation of a relabelled graph in the same launch
+      PROF(GSS_PROF_LOSS);
+      if (mapped && !prepared) {
+        if (int rc = loss_gather_rows_mapped(D.d, p->emb, idx, D.node_map, p->lo, D.n, p->gid2op_t, p->pid, p->rloc, p->keep, b, p->loss_ws, &e_b,
+                                             stream))
+          return rc;
+      } else if (int rc = loss_gather_rows(D.d, p->emb, bv.rows, bv.keep, b, p->loss_ws, &e_b, stream))
+        return rc;
     }
-    s.emb = p->emb;
+    s.e_b = e_b;
+    s.rows = bv.rows;
+    s.pos_ids = bv.ids;
   } else if (p->P > 1) {
     // shards: ONE batch collective.  Every shard contributes [E_B | P_B | inv_B] of the members it owns (zeros elsewhere); after the
     // all-reduce (C3; one non-zero contributor per element: exact) every rank holds the whole batch's rows of the embeddings
@@ -877,21 +875,6 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
     s.rows = nullptr;                       // p / inv_den are per member
     s.pos_ids = bv.ids;
     s.dgrad_all = true;
-  } else {
-    float *e_b = nullptr;
-    {
-      // E_B = emb[idx] (model.py:216-217) by a gather launch (batches the sweep's row table does not hold)
-      PROF(GSS_PROF_LOSS);
-      if (mapped && !prepared) {
-        if (int rc = loss_gather_rows_mapped(D.d, p->emb, idx, D.node_map, p->lo, D.n, p->gid2op_t, p->pid, p->rloc, p->keep, b, p->loss_ws, &e_b,
-                                             stream))
-          return rc;
-      } else if (int rc = loss_gather_rows(D.d, p->emb, bv.rows, bv.keep, b, p->loss_ws, &e_b, stream))
-        return rc;
-    }
-    s.e_b = e_b;
-    s.rows = bv.rows;
-    s.pos_ids = bv.ids;
   }
   bool dgrad_done = false;
   {
@@ -900,7 +883,7 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
     PROF(GSS_PROF_LOSS);
     if (int rc = loss_step(s, p->loss_ws, stream, &dgrad_done)) return rc;
   }
-  // (a shard whose loss kernel had no tail -- widths outside {64, 128, 256} -- falls back to the masked input gradient + its all-reduce)
+  // (a shard at a width the fused finish does not cover -- outside {64, 128, 256} -- falls back to the masked input gradient + its all-reduce)
   return plan_backward_impl(p, bv, b, nullptr, true, wt_ok, stream, deferred_slices, dgrad_done);
 }
 
@@ -950,11 +933,11 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
       // sum over the shards (C3) is the batch's gradient
       p->gax_b = p->gab;
       p->gam_b = p->gab + (size_t)b * D.d;
-      if (!dgrad_done) {   // (else the loss kernel's tail already wrote them)
+      if (!dgrad_done) {   // (else the loss's finish launch already wrote them)
         PROF(GSS_PROF_DGRAD);
         if (int rc = dense_bwd_input(b, D.d, p->dp_b, p->w1t, p->w2t, nullptr, p->gax_b, p->gam_b, stream)) return rc;
       }
-      if (!dgrad_done)     // the tail's input gradient covers every member on every rank (LossStep.dgrad_all): nothing to sum
+      if (!dgrad_done)     // the finish launch's input gradient covers every member on every rank (LossStep.dgrad_all): nothing to sum
         if (int rc = plan_allreduce(p, p->gab, (size_t)2 * b * D.d, stream)) return rc;
       if (p->posbits) {
         PROF(GSS_PROF_ELEMENTWISE);

@@ -458,9 +458,8 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
  * by four waves per 16 rows that split the features / by one wave; "lazy_halo" = -1 (default: graphs of >= 262,144 nodes) / 0 / 1: sharded plans fetch subsets of the
  * boundary rows where a hop reads a subset (gss_plan_lazy_halo_rows; every rank of a job must use the same value; over RCCL the
  * automatic choice is "never" until a multi-GPU run has priced its host round trip); "halo_recompute" = -1 (default: on) / 0 / 1: sharded plans recompute layer 2's boundary input rows from layer 1's constant AX / AM (fetched once)
- * instead of exchanging them every step (same bits; every rank of a job must use the same value); "loss_idx", "loss_tail" = 1
- * (default) / 0: the batch-row gather as the loss sweep's prologue / finish + batch-row input gradient as its tail (same bits, two
- * to three launches fewer per step).  Every setting computes the same results (some in a different summation order); the defaults are
+ * instead of exchanging them every step (same bits; every rank of a job must use the same value); "loss_dgrad" = 1 (default) / 0: the
+ * loss finish and the batch rows' input gradient in one launch / in two (same bits).  Every setting computes the same results (some in a different summation order); the defaults are
  * the measured optima recorded in DESIGN.md section 4.  The values are process-wide DEFAULTS: a plan (and a gss_ppr handle) takes a
  * snapshot when it is created and runs under it from then on, so changing a knob never re-shapes a live plan -- in particular not
  * the plans of other rank threads of the same process; per-op entry points read the current defaults. */
