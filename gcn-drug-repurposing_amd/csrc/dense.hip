@@ -44,6 +44,8 @@ struct GemmArgs {
   // EPI_SPLIT
   const int32_t *rows;  // scatter map for the output row (nullable)
   float *inv_den;       // EPI_FWD_NORM: 1 / max(||x_row||, eps) per node (x_next then receives the unit-norm rows)
+  float *rows_out;      // EPI_FWD_NORM over a row list (nullable): the unit-norm row of tile row t ALSO goes to rows_out[t] -- the lazy step's
+                        // tile rows are the batch positions, so this IS E_B = emb[idx] (model.py:216-217) without a gather launch
   int xcd_remap;        // renumber the workgroups so that those sharing input rows sit on one XCD (xcd_ids below)
   int prio_cut;         // > 0: workgroups whose linear id is below it raise their wave priority (debug knob "gemm_prio")
   int stagger;          // > 0: workgroups of the second generation (linear id >= 256) start this many x 512 cycles late (knob "gemm_stagger")
@@ -195,6 +197,7 @@ __device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&ac
     const size_t off = (size_t)ndc * g.ld_out0 + j0 + 16 * u + 4 * q;   // ndc == nd for a live row without a row list
     st4(g.out0 + off, pv[u]);
     st4(g.x_next + off, EPI == EPI_FWD_NORM ? scale4(inv, o[u]) : o[u]);
+    if (EPI == EPI_FWD_NORM && g.rows_out) st4(g.rows_out + (size_t)nd * g.ld_out0 + j0 + 16 * u + 4 * q, scale4(inv, o[u]));
   }
   if (EPI == EPI_FWD_NORM && q == 0) g.inv_den[ndc] = inv;
 }
@@ -625,7 +628,8 @@ bool dense_fwd_norm_available(int32_t d) { return K().gemm_variant >= 2 && (d ==
 bool dense_row_list_available() { return K().gemm_variant >= 2; }   // the projection over a row list (gss_plan_step_lazy) is the LDS-staged kernel's
 
 int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
-                   const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream, const int32_t *row_list) {
+                   const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream, const int32_t *row_list,
+                   float *rows_out) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(n >= 0 && ax && am && w1 && b1 && w2 && b2 && p && e && inv_den, "dense_fwd_norm: null operand");
   GSS_REQUIRE(dense_fwd_norm_available(d), "dense_fwd_norm: needs d in {16, 32, 64, 128} and the LDS-staged GEMM");
@@ -650,6 +654,8 @@ int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const
   g.decay = decay;
   g.inv_den = inv_den;
   g.rows = row_list;
+  GSS_REQUIRE(!rows_out || row_list, "dense_fwd_norm: rows_out goes with a row list");
+  g.rows_out = rows_out;
   return launch_gemm<EPI_FWD_NORM>(g, d, as_stream(stream));
 }
 

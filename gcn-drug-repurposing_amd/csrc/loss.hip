@@ -456,23 +456,75 @@ __global__ __launch_bounds__(256) void loss_finish_dgrad_kernel(FinishDgrad T) {
     t = wave_sum_d(t);
     if (threadIdx.x == 0) T.loss_out[0] = (float)(-0.5 * (double)T.alpha * t / ((double)B * (double)B));
   }
+  // The rows of this wave (RP at most), in three phases so that every load of the launch is in flight before the first store (a store
+  // between two loads orders them for the compiler; a dependent round trip costs ~1 us here): (1) the members' rows / keep flags,
+  // (2) all operands of all rows, (3) arithmetic -- finish_row's, in its order -- and stores.
+  int rrs[RP], nodes[RP];
+  float keeps[RP];
 #pragma unroll
   for (int k = 0; k < RP; ++k) {
-    const int rr = w * rpw + (lane >> lg) + k * 4 * rpw;   // (the lanes of a row's group share rr: the shuffles inside stay whole)
+    rrs[k] = w * rpw + (lane >> lg) + k * 4 * rpw;   // (the lanes of a row's group share rr: the shuffles below stay whole)
+    const int rc = min(i0 + min(rrs[k], 15), B - 1);
+    nodes[k] = T.rows ? T.rows[rc] : rc;
+    keeps[k] = T.keep ? T.keep[rc] : 1.f;
+  }
+  float4 g[RP], ev[RP], pv[RP];
+  float invs[RP];
+  const bool col = li < d4;                          // (d4 <= 64 here: one float4 of a row per lane)
+#pragma unroll
+  for (int k = 0; k < RP; ++k) {
+    const int r = i0 + rrs[k];
+    const bool in = rrs[k] < 16 && r < B && col;
+    const int rc = min(i0 + min(rrs[k], 15), B - 1);
+    float4 sgm = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in) {
+      const size_t off = ((size_t)r * d4 + li) * 4;
+      sgm = ld4(T.de_part + off);
+      for (int t = 1; t < T.js; ++t) sgm = add4(sgm, ld4(T.de_part + (size_t)t * B * d + off));
+      sgm = scale4(2.f, sgm);
+    }
+    g[k] = sgm;
+    ev[k] = in ? ld4(T.e_b + (size_t)rc * d + (size_t)li * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    pv[k] = in ? ld4(T.p + (size_t)nodes[k] * d + (size_t)li * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    invs[k] = T.inv_den[nodes[k]];
+  }
+#pragma unroll
+  for (int k = 0; k < RP; ++k) {
+    const int rr = rrs[k];
     if (rr < 16) {
       const int r = i0 + rr;
       const bool ok = r < B;
-      const int rc = ok ? r : B - 1;
-      const int node = T.rows ? T.rows[rc] : rc;
-      const float keepv = T.keep ? T.keep[rc] : 1.f;
-      if (ok && T.pos_set && li == 0) {
-        const int key = T.pos_ids ? T.pos_ids[r] : node;
-        if (key >= 0) T.pos_set[key] = r;
+      float dot = g[k].x * ev[k].x + g[k].y * ev[k].y + g[k].z * ev[k].z + g[k].w * ev[k].w;
+      for (int o = 1; o < lpr; o <<= 1) dot += __shfl_xor(dot, o, 64);
+      float *dl = dp_tile + (size_t)rr * ds + (size_t)li * 4;
+      if (ok && col) {
+        if (T.pos_set && li == 0) {
+          const int key = T.pos_ids ? T.pos_ids[r] : nodes[k];
+          if (key >= 0) T.pos_set[key] = r;
+        }
+        const float inv = keeps[k] != 0.f ? invs[k] : 0.f;
+        float4 dx;
+        dx.x = (g[k].x - ev[k].x * dot) * inv;
+        dx.y = (g[k].y - ev[k].y * dot) * inv;
+        dx.z = (g[k].z - ev[k].z * dot) * inv;
+        dx.w = (g[k].w - ev[k].w * dot) * inv;
+        st4(T.dx_b + ((size_t)r * d4 + li) * 4, dx);
+        const float4 pg = elu_grad4(pv[k]);
+        const float4 dp = scale4(T.c, mul4(dx, pg));
+        st4(T.dp_b + ((size_t)r * d4 + li) * 4, dp);
+        float4 dlv = dp;
+        if (T.dgrad_all && keeps[k] == 0.f) {   // a member another shard owns: its gradient row all the same (this shard holds its p / inv_den)
+          float4 du;
+          du.x = (g[k].x - ev[k].x * dot) * invs[k];
+          du.y = (g[k].y - ev[k].y * dot) * invs[k];
+          du.z = (g[k].z - ev[k].z * dot) * invs[k];
+          du.w = (g[k].w - ev[k].w * dot) * invs[k];
+          dlv = scale4(T.c, mul4(du, pg));
+        }
+        *reinterpret_cast<float4 *>(dl) = dlv;
+      } else if (col) {
+        *reinterpret_cast<float4 *>(dl) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      finish_row<1>(ok, r, li, lpr, d4, T.js, B, T.de_part, T.e_b + (size_t)rc * d, T.inv_den[node], keepv, T.p + (size_t)node * d, T.c, T.dx_b,
-                    T.dp_b, dp_tile + (size_t)rr * ds, T.dgrad_all != 0);
-      if (!ok)
-        for (int f4 = li; f4 < d4; f4 += lpr) *reinterpret_cast<float4 *>(dp_tile + (size_t)rr * ds + f4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   __syncthreads();
@@ -554,6 +606,12 @@ static void loss_layout(int32_t d, int32_t b, void *ws, LossLaunch &L) {
   L.de_part = (float *)ws;
   L.loss_part = (double *)((char *)ws + de_bytes);
   L.e_b = (float *)((char *)ws + de_bytes + lp_bytes);
+}
+
+float *loss_workspace_e_b(int32_t d, int32_t b, void *ws) {
+  LossLaunch L;
+  loss_layout(d, b, ws, L);
+  return L.e_b;
 }
 
 // stage 1: E_B = e[idx] (zero where keep == 0) into the workspace; returns where it is

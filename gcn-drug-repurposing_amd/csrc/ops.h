@@ -63,7 +63,8 @@ bool dense_fwd_norm_available(int32_t d);
 bool dense_row_list_available();
 int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
                    const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream,
-                   const int32_t *row_list = nullptr);
+                   const int32_t *row_list = nullptr, float *rows_out = nullptr);   // rows_out: tile row t's unit-norm row also to rows_out[t]
+float *loss_workspace_e_b(int32_t d, int32_t b, void *ws);   // where loss_gather_rows* would put E_B for a batch of b rows
 int dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t, const float *w2t, const int32_t *rows,
                     float *g_ax, float *g_am, void *stream);
 size_t wgrad_workspace_bytes(int32_t n, int32_t d);

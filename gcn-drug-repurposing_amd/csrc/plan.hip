@@ -88,6 +88,8 @@ struct gss_plan {
   bool recompute;
   bool l0h_ready;          // the boundary rows of AX_0 / AM_0 have been fetched
   int64_t n_coll[3];       // collectives enqueued since the last gss_plan_comm_stats: halo exchanges / batch-row / weight-gradient
+  int32_t eb_rows;         // > 0: this step's lazy forward already wrote E_B for a batch of that many rows into the loss workspace (one GPU:
+                           // the row-list projection's tile rows are the batch positions), so the loss needs no gather launch
   // overlapped hops (gss_shard_desc a_own / a_halo / at_own / at_halo): the boundary rows of a hop travel on `xs` while the entries
   // that reference the shard's own rows are multiplied on the caller's stream; the boundary-column entries are added afterwards
   const gss_csr *a_own, *a_halo, *at_own, *at_halo;
@@ -407,6 +409,7 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
     p->recompute = P > 1 && desc->num_layers > 1 && knob != 0;   // (automatic = on: what it trades is priced below)
     p->l0h_ready = false;
     p->n_coll[0] = p->n_coll[1] = p->n_coll[2] = 0;
+    p->eb_rows = 0;
   }
   Carver sizing;
   carve(p, sizing);
@@ -766,9 +769,15 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
     PROF(GSS_PROF_DENSE_FWD);
     if (l == L - 1 && dense_fwd_norm_available(D.d)) {
       // last layer: F.normalize fused into the GEMM epilogue (no x_last round trip, no extra launch)
-      if (lazy_rows)
-        return dense_fwd_norm(lazy_b, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr, D.layer_decay,
-                              p->p[l], p->emb, p->inv_den, stream, lazy_rows);
+      if (lazy_rows) {
+        // one GPU: every listed row is a batch member in batch order -- the epilogue also drops its unit-norm row into E_B
+        float *e_b = (p->P == 1 && lazy_b > 0) ? loss_workspace_e_b(D.d, lazy_b, p->loss_ws) : nullptr;
+        if (int rc = dense_fwd_norm(lazy_b, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr, D.layer_decay,
+                                    p->p[l], p->emb, p->inv_den, stream, lazy_rows, e_b))
+          return rc;
+        p->eb_rows = e_b ? lazy_b : 0;
+        return GSS_OK;
+      }
       return dense_fwd_norm(D.n, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr, D.layer_decay,
                             p->p[l], p->emb, p->inv_den, stream);
     }
@@ -842,7 +851,13 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
     s.gax_b = p->gab;
     s.gam_b = p->gab + (size_t)b * D.d;
   }
-  if (p->P == 1) {
+  const bool eb_ready = prepared && p->P == 1 && p->eb_rows == b;   // the lazy forward of this step wrote E_B itself
+  p->eb_rows = 0;
+  if (eb_ready) {
+    s.e_b = loss_workspace_e_b(D.d, b, p->loss_ws);
+    s.rows = bv.rows;
+    s.pos_ids = bv.ids;
+  } else if (p->P == 1) {
     float *e_b = nullptr;
     {
       // E_B = emb[idx] (model.py:216-217), the batch-id translation of a relabelled graph in the same launch

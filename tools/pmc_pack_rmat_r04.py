@@ -16,6 +16,7 @@ out = {"note": "rocprofv3 --pmc, one counter group per pass (tools/pmc_run.sh), 
        "workload": f"RMAT {n} nodes / {m} edges (+{n} self loops), d = {d}, hub-first relabelled, as bench.py --workload rmat:{n}:{m} builds it",
        "alg_bytes_per_product": alg, "cases": {}, "hbm_traffic": {}}
 for tag, what in (("base", "single pass (the product's kernel: H = 65,536 hubs declared hot, cold rows non-temporal, 2 time-separated slices)"),
+                  ("fwd1", "single pass with the Hadamard epilogue (AX = A_hat x, M = AX (.) x): the bench line's `roofline` kernel; algorithmic bytes + 4 N d"),
                   ("two", f"two passes over a column split at H = {h}: hot entries with {ns} XCD-pinned slices of {d * 4 // ns} B, cold entries streaming")):
     acc, dur = collections.defaultdict(float), 0.0
     for dd in glob.glob(os.path.join(PMC, f"r04_rmat_{tag}_*")):
@@ -34,13 +35,16 @@ for tag, what in (("base", "single pass (the product's kernel: H = 65,536 hubs d
     fetch, write = c["FETCH_SIZE"] * 1024 * 2, c.get("WRITE_SIZE", 0.0) * 1024
     hit, miss = c.get("TCC_HIT_sum", 0.0), c.get("TCC_MISS_sum", 0.0)
     us = dur / REPS
-    out["cases"][tag] = {"what": what, "counters_per_product": c, "fetch_bytes_corrected": fetch, "write_bytes": write,
-                         "traffic_bytes_per_product": fetch + write, "traffic_over_alg": (fetch + write) / alg,
+    alg_t = alg + (4 * n * d if tag == "fwd1" else 0)
+    out["cases"][tag] = {"what": what, "alg_bytes": alg_t, "counters_per_product": c, "fetch_bytes_corrected": fetch, "write_bytes": write,
+                         "traffic_bytes_per_product": fetch + write, "traffic_over_alg": (fetch + write) / alg_t,
                          "l2_hit_rate": hit / (hit + miss) if hit + miss else None, "us_per_product_profiled": us,
-                         "traffic_TBps": (fetch + write) / us / 1e6 if us else None, "alg_TBps": alg / us / 1e6 if us else None,
-                         "alg_frac_of_8TBps": alg / us / 1e6 / 8.0 if us else None}
+                         "traffic_TBps": (fetch + write) / us / 1e6 if us else None, "alg_TBps": alg_t / us / 1e6 if us else None,
+                         "alg_frac_of_8TBps": alg_t / us / 1e6 / 8.0 if us else None}
 if "base" in out["cases"]:
     out["hbm_traffic"]["plain"] = {"traffic_bytes_per_launch": out["cases"]["base"]["traffic_bytes_per_product"]}
+if "fwd1" in out["cases"]:
+    out["hbm_traffic"]["fwd1"] = {"traffic_bytes_per_launch": out["cases"]["fwd1"]["traffic_bytes_per_product"]}
 json.dump(out, open(os.path.join(ROOT, "profiles", "r04_spmm_pmc_rmat10m.json" if n == 10000000 else f"r04_spmm_pmc_rmat_{n}.json"), "w"), indent=1)
 for tag, c in out["cases"].items():
     print(f"{tag:5s} traffic {c['traffic_bytes_per_product'] / 1e9:8.3f} GB = {c['traffic_over_alg']:.2f} x alg, L2 hit {c['l2_hit_rate']}, "

@@ -9,5 +9,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   t=$(echo $grp | cut -d' ' -f1)
   PMC_TIMEOUT=500 bash $R/tools/pmc_run.sh "r04_rmat_base_$t" "$grp" tools/spmm_two_pass.py $N $M 128 base 3 | grep -v "^$"
   PMC_TIMEOUT=500 bash $R/tools/pmc_run.sh "r04_rmat_two_$t" "$grp" tools/spmm_two_pass.py $N $M 128 two $H $NS 3 | grep -v "^$"
+  PMC_TIMEOUT=500 bash $R/tools/pmc_run.sh "r04_rmat_fwd1_$t" "$grp" tools/spmm_two_pass.py $N $M 128 fwd1 3 | grep -v "^$"
 done
 python3 $R/tools/pmc_pack_rmat_r04.py $N $M $H $NS

@@ -12,6 +12,7 @@ feature slices -- slice s of every row is only ever gathered by XCD s mod 8, so 
 
 usage: spmm_two_pass.py <nodes> <edges> [d] sweep            time the single pass and every (H, slices) pair, check the results
        spmm_two_pass.py <nodes> <edges> [d] base <reps>      `reps` single-pass products   (for rocprofv3 --pmc)
+       spmm_two_pass.py <nodes> <edges> [d] fwd1 <reps>      `reps` single-pass products with the Hadamard epilogue (AX = A x, M = AX (.) x)
        spmm_two_pass.py <nodes> <edges> [d] two <H> <slices> <reps>   `reps` two-pass products  (for rocprofv3 --pmc)
 """
 import os
@@ -97,6 +98,12 @@ if mode == "base":
         single()
     torch.cuda.synchronize()
     print(f"base: n={n} nnz={nnz} d={d} alg={alg}")
+elif mode == "fwd1":
+    m_out = torch.empty(n, d, device="cuda")
+    for _ in range(int(sys.argv[5])):
+        _lib.check(lib.gss_spmm(a.handle, d, x.data_ptr(), y.data_ptr(), x.data_ptr(), m_out.data_ptr(), st))
+    torch.cuda.synchronize()
+    print(f"fwd1: n={n} nnz={nnz} d={d} alg={alg + 4 * n * d}")
 elif mode == "two":
     h, ns, reps = int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
     hot, cold, share = split(h)
