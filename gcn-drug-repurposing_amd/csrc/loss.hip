@@ -31,6 +31,7 @@ struct LossArgs {
   float beta, alpha;
   float *de_part;     // [js][b][d]
   double *loss_part;  // [grid.x * grid.y]
+  int tile0, tile_stride;   // workgroup x of the grid takes i tile tile0 + x * tile_stride (a rank's row slab of the sweep; 0 / 1: all tiles)
 };
 
 // E_B = e[idx] (modules/model.py:216-217) into a contiguous buffer, so the MFMA loop has no index indirection
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
   const int c = lane & 15, q = lane >> 4;
   const int d = g.d, B = g.b;
   const int fbase = blockIdx.z * (64 * NG);
-  const int i0 = blockIdx.x * 16;
+  const int i0 = (g.tile0 + (int)blockIdx.x * g.tile_stride) * 16;
   const int nj = (B + 15) / 16;
   const int nslots = kLossWaves * g.js;
   const int slot = blockIdx.y * kLossWaves + w;
@@ -362,6 +363,32 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(int b, int d, int js, 
   }
 }
 
+// Row-slab sweep (a shard took the i tiles tile0, tile0 + stride, ...): de_x = sum_js de_part on the rows of those tiles, zeros on the
+// others, and this rank's share of the loss behind the last row -- the buffer the ranks then sum (every element has one non-zero
+// contributor, the loss P of them).  The factor 2 of dE = 2 G E is applied by the finish, as in the replicated form.
+__global__ __launch_bounds__(256) void loss_slab_sum_kernel(int b, int d, int js, int nloss, int tile0, int tile_stride,
+                                                             const float *__restrict__ de_part, const double *__restrict__ loss_part,
+                                                             float alpha, float *__restrict__ de_x) {
+  const size_t n4 = (size_t)b * d / 4;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) {
+    const int tile = (int)(i * 4 / d) / 16;
+    const bool mine = tile >= tile0 && (tile - tile0) % tile_stride == 0;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mine) {
+      s = ld4(de_part + i * 4);
+      for (int k = 1; k < js; ++k) s = add4(s, ld4(de_part + ((size_t)k * b * d) + i * 4));
+    }
+    st4(de_x + i * 4, s);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    double t = 0.0;
+    for (int k = threadIdx.x; k < nloss; k += 64) t += loss_part[k];
+    t = wave_sum_d(t);
+    if (threadIdx.x == 0) de_x[(size_t)b * d] = (float)(-0.5 * (double)alpha * t / ((double)b * (double)b));
+  }
+}
+
 // plan path: loss_finish + the backward of F.normalize and F.elu on the batch rows in one launch (the widths
 // loss_finish_dgrad_kernel does not cover).
 // One lane group per batch row: de = 2 sum_js de_part (the row of dLoss/dE_B), then
@@ -384,7 +411,7 @@ __global__ __launch_bounds__(256) void loss_finish_bwd_kernel(int b, int d4, int
   const bool ok = r < b;
   const int rc = ok ? r : 0;
   const int node = idx ? idx[rc] : rc;   // idx == NULL: inv_den / p are per member (a shard's gathered batch)
-  if (blockIdx.x == 0 && threadIdx.x < 64) {
+  if (nloss > 0 && blockIdx.x == 0 && threadIdx.x < 64) {   // (nloss == 0: the loss came with the summed de, row-slab sweep)
     double t = 0.0;
     for (int k = threadIdx.x; k < nloss; k += 64) t += loss_part[k];
     t = wave_sum_d(t);
@@ -450,7 +477,7 @@ __global__ __launch_bounds__(256) void loss_finish_dgrad_kernel(FinishDgrad T) {
 #pragma unroll
       for (int u = 0; u < NTW; ++u) wf[k][u] = ld4(wt + (size_t)(16 * u) * d + 16 * k);
   }
-  if (blockIdx.x == 0 && threadIdx.x < 64) {
+  if (T.nloss > 0 && blockIdx.x == 0 && threadIdx.x < 64) {   // (nloss == 0: the loss came with the summed de, row-slab sweep)
     double t = 0.0;
     for (int k = threadIdx.x; k < T.nloss; k += 64) t += T.loss_part[k];
     t = wave_sum_d(t);
@@ -558,10 +585,11 @@ __global__ __launch_bounds__(256) void loss_finish_dgrad_kernel(FinishDgrad T) {
 // debug knob "loss_wgs": workgroups the (i-tile x j-split) grid aims at.  One workgroup per CU wins at B = 2048 (gather + sweep + finish,
 // d = 128: 128 / 256 / 384 / 512 / 768 / 1024 workgroups -> 49.4 / 31.4 / 38.3 / 34.6 / 39.8 / 43.9 us; d = 256: 124.0 at 256 vs 126.3 at 512)
 
-static void loss_geometry(int32_t b, int32_t d, int &ni, int &js, int &nz, int &ng) {
+// parts > 1: the i tiles are dealt to `parts` ranks (row-slab sweep); js then follows the tiles ONE rank sweeps -- the same on every rank
+static void loss_geometry(int32_t b, int32_t d, int &ni, int &js, int &nz, int &ng, int parts = 1) {
   ni = ceil_div(b, 16);
   const int nj = ni;
-  js = ceil_div(K().loss_wgs, ni);
+  js = ceil_div(K().loss_wgs, ceil_div(ni, parts > 1 ? parts : 1));
   const int js_max = ceil_div(nj, kLossWaves);
   if (js > js_max) js = js_max;
   if (js > 16) js = 16;
@@ -571,9 +599,9 @@ static void loss_geometry(int32_t b, int32_t d, int &ni, int &js, int &nz, int &
   nz = ceil_div(groups, ng);
 }
 
-size_t loss_workspace_bytes(int32_t b, int32_t d) {
+size_t loss_workspace_bytes(int32_t b, int32_t d, int parts) {
   int ni, js, nz, ng;
-  loss_geometry(b, d, ni, js, nz, ng);
+  loss_geometry(b, d, ni, js, nz, ng, parts);
   size_t de = sizeof(float) * (size_t)js * b * d;
   de = (de + 15) / 16 * 16;
   return de + (sizeof(double) * (size_t)ni * js + 15) / 16 * 16 + sizeof(float) * (size_t)b * d;
@@ -582,11 +610,12 @@ size_t loss_workspace_bytes(int32_t b, int32_t d) {
 // The workspace is NOT monotone in b: the number of j slabs grows as the i tiles get fewer (B = 2048 -> 128 tiles x 2 slabs, 3 B d floats;
 // B = 2032 -> 127 x 3, 4 B d), so a plan sized for max_batch alone is too small for the shorter last batch of an epoch.  Upper bound over
 // every b in [1, b_max]: within one tile count the largest b needs the most, so one candidate per tile count.
-size_t loss_workspace_bytes_max(int32_t b_max, int32_t d) {
+size_t loss_workspace_bytes_max(int32_t b_max, int32_t d, int parts) {
   size_t worst = 0;
   for (int ni = 1; ni <= ceil_div(b_max, 16); ++ni) {
     const int b = std::min(16 * ni, (int)b_max);
-    worst = std::max(worst, loss_workspace_bytes(b, d));
+    worst = std::max(worst, loss_workspace_bytes(b, d, 1));
+    if (parts > 1) worst = std::max(worst, loss_workspace_bytes(b, d, parts));
   }
   return worst;
 }
@@ -598,8 +627,8 @@ struct LossLaunch {
   float *e_b;
 };
 
-static void loss_layout(int32_t d, int32_t b, void *ws, LossLaunch &L) {
-  loss_geometry(b, d, L.ni, L.js, L.nz, L.ng);
+static void loss_layout(int32_t d, int32_t b, void *ws, LossLaunch &L, int parts = 1) {
+  loss_geometry(b, d, L.ni, L.js, L.nz, L.ng, parts);
   size_t de_bytes = sizeof(float) * (size_t)L.js * b * d;
   de_bytes = (de_bytes + 15) / 16 * 16;
   const size_t lp_bytes = (sizeof(double) * (size_t)L.ni * L.js + 15) / 16 * 16;
@@ -623,9 +652,12 @@ static int loss_gather(int32_t d, const float *e, const int32_t *idx, const floa
 }
 
 // stage 2: the fused S / G / dE sweep over the gathered rows `e_b`
-static int loss_sweep(int32_t d, int32_t b, float beta, float alpha, const float *e_b, hipStream_t st, LossLaunch &L) {
-  LossArgs g{d, b, L.js, e_b, beta, alpha, L.de_part, L.loss_part};
-  dim3 grid(L.ni, L.js, L.nz), block(64 * kLossWaves);
+static int loss_sweep(int32_t d, int32_t b, float beta, float alpha, const float *e_b, hipStream_t st, LossLaunch &L, int tile0 = 0,
+                      int tile_stride = 1) {
+  LossArgs g{d, b, L.js, e_b, beta, alpha, L.de_part, L.loss_part, tile0, tile_stride};
+  const int ni_mine = tile0 < L.ni ? ceil_div(L.ni - tile0, tile_stride) : 0;
+  if (ni_mine == 0) return GSS_OK;
+  dim3 grid(ni_mine, L.js, L.nz), block(64 * kLossWaves);
   const size_t lds = (size_t)2 * L.ng * 4 * 64 * sizeof(float4);
   const bool exact = (d == 64 * L.ng) && L.nz == 1;
 #define GSS_LOSS_CASE(NGV)                                                              \
@@ -738,6 +770,23 @@ bool loss_dgrad_available(int32_t d, int32_t b) {
   return K().loss_dgrad != 0 && d == 64 * ng && nz == 1 && ng <= 4;
 }
 
+// Row-slab form of the sweep for a shard (LossStep.slab_parts > 1), first half: this rank's i tiles (rank, rank + parts, ...), then
+// de_x = its rows of sum_js de_part (zeros elsewhere) + its share of the loss behind them ([b d + 1] floats) -- what the ranks sum.
+int loss_step_slab_sweep(const LossStep &s, void *ws, float *de_x, void *stream) {
+  if (int rc = check_d(s.d)) return rc;
+  GSS_REQUIRE(s.b > 0 && s.e_b && de_x && ws && s.slab_parts > 1 && s.slab_rank >= 0 && s.slab_rank < s.slab_parts, "loss_step_slab_sweep: bad argument");
+  hipStream_t st = as_stream(stream);
+  LossLaunch L;
+  loss_layout(s.d, s.b, ws, L, s.slab_parts);
+  if (int rc = loss_sweep(s.d, s.b, s.beta, s.alpha, s.e_b, st, L, s.slab_rank, s.slab_parts)) return rc;
+  const int ni_mine = s.slab_rank < L.ni ? ceil_div(L.ni - s.slab_rank, s.slab_parts) : 0;
+  const int nb = ceil_div((int64_t)s.b * s.d / 4, 256);
+  hipLaunchKernelGGL(loss_slab_sum_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, s.b, s.d, L.js, ni_mine * L.js, s.slab_rank, s.slab_parts,
+                     L.de_part, L.loss_part, s.alpha, de_x);
+  GSS_LAUNCH_CHECK("loss_slab_sum_kernel");
+  return GSS_OK;
+}
+
 // The loss of one step on the plan's path, over rows gathered beforehand: the sweep, then the finish -- with the batch rows' input
 // gradient in the same launch when s.w1t is given and the width allows.  *dgrad_done says whether gax_b / gam_b were written.
 int loss_step(const LossStep &s, void *ws, void *stream, bool *dgrad_done) {
@@ -750,7 +799,15 @@ int loss_step(const LossStep &s, void *ws, void *stream, bool *dgrad_done) {
   LossLaunch L;
   loss_layout(d, b, ws, L);
   const float *e_b = s.e_b ? s.e_b : L.e_b;
-  if (int rc = loss_sweep(d, b, s.beta, s.alpha, e_b, st, L)) return rc;
+  if (s.de_x) {
+    // second half of the row-slab form: the ranks' sums are in de_x ([b][d], the loss behind it was copied out by the caller) -- one
+    // "slab" for the finish, no loss partials
+    L.js = 1;
+    L.ni = 0;
+    L.de_part = const_cast<float *>(s.de_x);
+  } else if (int rc = loss_sweep(d, b, s.beta, s.alpha, e_b, st, L)) {
+    return rc;
+  }
   const int32_t *pos_ids = s.pos_ids ? s.pos_ids : s.rows;
   *dgrad_done = false;
   if (s.w1t && loss_dgrad_available(d, b)) {
@@ -791,8 +848,8 @@ int loss_step(const LossStep &s, void *ws, void *stream, bool *dgrad_done) {
 
 using namespace gss;
 extern "C" {
-size_t gss_loss_workspace_bytes(int32_t b, int32_t d) { return loss_workspace_bytes(b, d); }
-size_t gss_loss_workspace_bytes_max(int32_t b_max, int32_t d) { return b_max > 0 ? loss_workspace_bytes_max(b_max, d) : 0; }
+size_t gss_loss_workspace_bytes(int32_t b, int32_t d) { return loss_workspace_bytes(b, d, 1); }
+size_t gss_loss_workspace_bytes_max(int32_t b_max, int32_t d) { return b_max > 0 ? loss_workspace_bytes_max(b_max, d, 1) : 0; }
 int gss_loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha,
                      float *loss_out, float *de_b, void *ws, void *stream) {
   return loss_fwd_bwd(n, d, e, idx, b, beta, alpha, loss_out, de_b, ws, stream);

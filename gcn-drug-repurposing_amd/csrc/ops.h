@@ -153,12 +153,17 @@ struct LossStep {
   const float *w1t, *w2t;
   float *gax_b, *gam_b;
   bool dgrad_all;                   // the input gradient of EVERY member (a shard that holds p / inv_den of the whole batch)
+  // row-slab sweep of a shard: the i tiles slab_rank, slab_rank + slab_parts, ... (loss_step_slab_sweep), the ranks' sums in de_x
+  int slab_rank, slab_parts;
+  const float *de_x;                // loss_step after the ranks summed de_x: [b][d] = sum_js de_part of every row (NULL: sweep here)
 };
 int loss_step(const LossStep &s, void *ws, void *stream, bool *dgrad_done);
+int loss_step_slab_sweep(const LossStep &s, void *ws, float *de_x, void *stream);
 bool loss_dgrad_available(int32_t d, int32_t b);
 int transpose2(int32_t dim, const float *a, const float *b, float *at, float *bt, void *stream);
-size_t loss_workspace_bytes(int32_t b, int32_t d);
-size_t loss_workspace_bytes_max(int32_t b_max, int32_t d);   // enough for every batch of 1..b_max rows (the size is not monotone in b)
+size_t loss_workspace_bytes(int32_t b, int32_t d, int parts = 1);
+size_t loss_workspace_bytes_max(int32_t b_max, int32_t d, int parts = 1);   // enough for every batch of 1..b_max rows (the size is not monotone in b);
+                                                                              // parts > 1: also for the row-slab sweep over that many ranks
 int loss_fwd_bwd(int32_t n, int32_t d, const float *e, const int32_t *idx, int32_t b, float beta, float alpha,
                  float *loss_out, float *de_b, void *ws, void *stream);
 }  // namespace gss

@@ -80,6 +80,7 @@ struct gss_plan {
   float *keep;             // per batch: 1.0 where this shard owns the member
   float *gab;              // [2 * max_batch][d]: the top layer's compact input gradients (one buffer: one all-reduce where one is needed)
   float *bx;               // shards: [max_batch (2 d + 1)] = [E_B | P_B | inv_B], the ONE batch collective of a step (loss.hip gather_batch_kernel)
+  float *dex;              // shards: [max_batch d + 1], row-slab sweep (knob loss_slab): the ranks' rows of sum_js de_part + their loss shares
   // halo_recompute (knob, on by default): layer 1's AX / AM are constants, so their boundary rows are fetched ONCE and layer 1's
   // projection runs over own + boundary rows -- layer 2's boundary input rows are then computed here (by the same kernel from the same
   // operands: the owner's bits) instead of exchanged every step.  ax[0] / am[0] / p[0] are operand-sized then.  The trade per boundary
@@ -238,6 +239,7 @@ void carve(gss_plan *p, Carver &c) {
   p->dp_b = c.take<float>(bd);
   p->gab = L > 1 ? c.take<float>(2 * bd) : nullptr;            // gax_b = gab, gam_b = gab + b * d: one all-reduce
   p->bx = sharded ? c.take<float>(2 * bd + (size_t)D.max_batch) : nullptr;
+  p->dex = sharded ? c.take<float>(bd + 1) : nullptr;
   p->gax_b = p->gam_b = nullptr;
   p->pos = L > 1 ? c.take<int32_t>(p->rows_t ? p->rows_t : 1) : nullptr;
   // from sparse_bits_rows operand rows on: the sparse SpMM tests a bitmap before the 4-byte-per-node map (zero-initialised slab)
@@ -256,7 +258,7 @@ void carve(gss_plan *p, Carver &c) {
     p->adam_m[k] = c.take<float>(cnt[k]);
     p->adam_v[k] = c.take<float>(cnt[k]);
   }
-  p->loss_ws = c.take<char>(loss_workspace_bytes_max(D.max_batch, D.d));   // not monotone in the batch size: the worst case over 1..max_batch
+  p->loss_ws = c.take<char>(loss_workspace_bytes_max(D.max_batch, D.d, p->P));   // not monotone in the batch size: the worst case over 1..max_batch
   const int wg_total = wgrad_slices_max(D.max_batch, D.d) + (L - 1) * wgrad_slices(D.n, D.d);
   p->wgrad_ws = c.take<char>(sizeof(float) * (size_t)wg_total * ((size_t)D.d * 2 * D.d + D.d));
 }
@@ -891,10 +893,27 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
     s.pos_ids = bv.ids;
     s.dgrad_all = true;
   }
+  // Row-slab sweep ("each GPU computes its row-slab of S and of 2 G E_B"; knob loss_slab, automatic from B = 8192): with
+  // the whole batch's rows on every rank, rank r sweeps the i tiles r, r + P, ... -- 1 / P of the B^2 d work whoever owns the members
+  // -- and the ranks sum their rows of dE (and their shares of the loss) in one more all-reduce.  Below that size the sweep (25 us at
+  // B = 2048, d = 128) is replicated instead: a second batch collective costs more than the (P - 1) / P of it that a slab saves.
+  const int slab_knob = K().loss_slab;
+  const bool slab = p->P > 1 && (slab_knob == 1 || (slab_knob < 0 && b >= 8192));
+  if (slab) {
+    s.slab_rank = p->rank;
+    s.slab_parts = p->P;
+    {
+      PROF(GSS_PROF_LOSS);
+      if (int rc = loss_step_slab_sweep(s, p->loss_ws, p->dex, stream)) return rc;
+    }
+    if (int rc = plan_allreduce(p, p->dex, (size_t)b * D.d + 1, stream)) return rc;
+    GSS_HIP(hipMemcpyAsync(p->loss, p->dex + (size_t)b * D.d, sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+    s.de_x = p->dex;
+  }
   bool dgrad_done = false;
   {
-    // loss, dLoss/dE_B and the backward of F.normalize / F.elu on the batch rows (every shard computes the full B x B
-    // sweep -- identical bits everywhere, no exchange of the loss -- and keeps the gradient rows it owns)
+    // loss, dLoss/dE_B and the backward of F.normalize / F.elu on the batch rows (replicated form: every shard computes the full
+    // B x B sweep -- identical bits everywhere, no exchange of the loss); the gradient rows a shard owns feed its weight gradient
     PROF(GSS_PROF_LOSS);
     if (int rc = loss_step(s, p->loss_ws, stream, &dgrad_done)) return rc;
   }

@@ -405,7 +405,7 @@ int gss_plan_lazy_halo_rows(const gss_plan *p, int64_t *out6);
 /* Collectives a sharded plan has enqueued since the last call (then reset): out3 = {boundary-row exchanges, batch-row all-reduces,
  * weight-gradient all-reduces}.  A steady full step at L layers: 2L - 2 + 2L - 3 exchanges (one less with halo_recompute: layer 2's
  * boundary input rows are recomputed from layer 1's constant AX / AM), 1 batch-row all-reduce ([E_B | P_B | inv_B] as one buffer; 2
- * where the loss kernel has no tail), 1 weight-gradient all-reduce.  All zeros on one GPU. */
+ * at widths outside {64, 128, 256} or with the row-slab loss sweep, knob loss_slab), 1 weight-gradient all-reduce.  Zeros on one GPU. */
 int gss_plan_comm_stats(gss_plan *p, int64_t *out3);
 /* layer activations for parity tests: which 0 AX, 1 AM, 2 P of layer `layer` (0-based) */
 const float *gss_plan_activation(const gss_plan *p, int layer, int which);
@@ -459,7 +459,9 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
  * boundary rows where a hop reads a subset (gss_plan_lazy_halo_rows; every rank of a job must use the same value; over RCCL the
  * automatic choice is "never" until a multi-GPU run has priced its host round trip); "halo_recompute" = -1 (default: on) / 0 / 1: sharded plans recompute layer 2's boundary input rows from layer 1's constant AX / AM (fetched once)
  * instead of exchanging them every step (same bits; every rank of a job must use the same value); "loss_dgrad" = 1 (default) / 0: the
- * loss finish and the batch rows' input gradient in one launch / in two (same bits).  Every setting computes the same results (some in a different summation order); the defaults are
+ * loss finish and the batch rows' input gradient in one launch / in two (same bits); "loss_slab" = -1 (default: batches of >= 8192
+ * rows) / 0 / 1: sharded plans sweep the B x B loss as row slabs (rank r the i tiles r, r + P, ...; one more all-reduce of B d + 1
+ * floats) instead of replicating it on every rank (every rank of a job must use the same value; results agree to rounding).  Every setting computes the same results (some in a different summation order); the defaults are
  * the measured optima recorded in DESIGN.md section 4.  The values are process-wide DEFAULTS: a plan (and a gss_ppr handle) takes a
  * snapshot when it is created and runs under it from then on, so changing a knob never re-shapes a live plan -- in particular not
  * the plans of other rank threads of the same process; per-op entry points read the current defaults. */

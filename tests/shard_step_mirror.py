@@ -30,7 +30,7 @@ def _f32(a):
 
 
 class ShardStepMirror:
-    def __init__(self, shard, x_local, params_host, comm, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, shard, x_local, params_host, comm, num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, slab=False):
         lay = shard.layout
         self.shard, self.lay, self.comm = shard, lay, comm
         self.P, self.rank = comm.world, comm.rank
@@ -57,6 +57,7 @@ class ShardStepMirror:
         self.x0op = None
         self.m0op = None
         self.recompute = self.P > 1 and self.L > 1      # knob halo_recompute, automatic choice (on)
+        self.slab = slab and self.P > 1                 # knob loss_slab (automatic: batches of >= 8192 rows)
         self.ax0op = self.am0op = None
         self.loss = None
         self.emb = None
@@ -160,6 +161,20 @@ class ShardStepMirror:
         self.comm.all_reduce_sum_(bx)
         e_b = bx[:, :d].contiguous()
         loss, de_b = self.ops.loss_fwd_bwd(e_b, beta, self.alpha)      # model.py:218-221 (+ autograd); the same on every rank
+        if self.slab:
+            # row-slab sweep (knob loss_slab): rank r keeps the rows of the i tiles r, r + P, ... of dE and 1 / P-th ... its own tiles'
+            # share of the loss; one more all-reduce assembles them (loss.hip loss_slab_sum_kernel, plan_loss_backward_impl)
+            tiles = np.arange(b) // 16
+            mine_t = (tiles % self.P) == self.rank
+            dex = torch.zeros(b * d + 1)
+            dex[:b * d] = (de_b * torch.from_numpy(mine_t.astype(np.float32))[:, None]).reshape(-1)
+            # the loss is a sum over (i, j) pairs: this rank's share = the rows i of its tiles
+            s_ = e_b.double() @ e_b.double().t()
+            t_ = torch.clamp(s_, min=0.0) - beta
+            dex[b * d] = float((-0.5 * self.alpha * (t_ * t_)[torch.from_numpy(mine_t)].sum() / (b * b)))
+            self.comm.all_reduce_sum_(dex)
+            de_b = dex[:b * d].reshape(b, d).contiguous()
+            loss = dex[b * d].clone()
         self.loss = loss
         c_top = self.decay if L > 1 else 1.0
         # the sweep's tail: backward of F.normalize and F.elu on EVERY member (this rank holds p / inv_den of all of them); the rows

@@ -28,7 +28,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, relabel, out_dir):
+def _worker(rank, world, port, case, relabel, out_dir, slab=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -68,7 +68,7 @@ def _worker(rank, world, port, case, relabel, out_dir):
                 both = np.concatenate([own.m.indices[own.m.indptr[r]:own.m.indptr[r + 1]], hal.m.indices[hal.m.indptr[r]:hal.m.indptr[r + 1]]])
                 assert sorted(both.tolist()) == sorted(full.m.indices[full.m.indptr[r]:full.m.indptr[r + 1]].tolist())
         eng = ShardStepMirror(shard, shard_rows(shard, g["X"]), golden_params(g, "init"), comm, num_layers=L, layer_decay=float(g["decay"]),
-                              alpha=float(g["alpha"]), lr=float(g["lr"]))
+                              alpha=float(g["alpha"]), lr=float(g["lr"]), slab=slab)
         losses, ex_per_step, rows_per_step, ar_per_step = [], [], [], []
         for idx in golden_batches(g):
             e0, r0, a0 = comm.exchanges, comm.rows_received, comm.allreduces
@@ -86,11 +86,12 @@ def _worker(rank, world, port, case, relabel, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case,relabel", [(2, "edge_n600_d128_L2", False), (2, "edge_n600_d128_L2", True), (3, "knn_n200_d16_L2", False),
-                                                (2, "knn_n2000_d64_L3", True), (3, "toy_sif_d64_L2", False)])
-def test_product_shards_as_gloo_processes_match_reference_trajectory(tmp_path, world, case, relabel):
+@pytest.mark.parametrize("world,case,relabel,slab", [(2, "edge_n600_d128_L2", False, False), (2, "edge_n600_d128_L2", True, False),
+                                                     (3, "knn_n200_d16_L2", False, False), (2, "knn_n2000_d64_L3", True, False),
+                                                     (3, "toy_sif_d64_L2", False, False), (3, "edge_n600_d128_L2", True, True)])
+def test_product_shards_as_gloo_processes_match_reference_trajectory(tmp_path, world, case, relabel, slab):
     import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(world, _free_port(), case, relabel, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), case, relabel, str(tmp_path), slab), nprocs=world, join=True)
     g = load_golden(case)
     n, d, L = (int(v) for v in g["meta"])
     outs = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
@@ -114,7 +115,8 @@ def test_product_shards_as_gloo_processes_match_reference_trajectory(tmp_path, w
     for o in outs:
         assert o["ex"][0] == steady + 2 + 2 * rec and all(int(e) == steady for e in o["ex"][1:])
         assert int(o["rows"][1]) == hops_a * int(o["halo_a"]) + max(0, 2 * L - 3) * int(o["halo_t"])
-        assert all(int(a) == 2 for a in o["ar"])           # all-reduces per step: [E_B | P_B | inv_B], the four weight gradients
+        # all-reduces per step: [E_B | P_B | inv_B], the four weight gradients (+ the ranks' rows of dE with the row-slab loss sweep)
+        assert all(int(a) == (3 if slab else 2) for a in o["ar"])
     # every row a shard receives is a row a peer sends
     assert sum(int(o["halo_a"]) for o in outs) == sum(int(o["send_a"]) for o in outs)
     assert sum(int(o["halo_t"]) for o in outs) == sum(int(o["send_t"]) for o in outs)

@@ -1,0 +1,6 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}; export GRAFT_REPO_ROOT=$R
+O=$R/gpurun_out/r4h; mkdir -p $O; cd $R
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest.txt 2>&1; rc=$?; tail -8 $O/pytest.txt; echo "pytest rc=$rc"
+[ $rc -eq 0 ] || exit $rc
+bash tools/gpu_r04g.sh
