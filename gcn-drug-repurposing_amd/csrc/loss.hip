@@ -803,15 +803,15 @@ int loss_step(const LossStep &s, void *ws, void *stream, bool *dgrad_done) {
     // second half of the row-slab form: the ranks' sums are in de_x ([b][d], the loss behind it was copied out by the caller) -- one
     // "slab" for the finish, no loss partials
     L.js = 1;
-    L.ni = 0;
     L.de_part = const_cast<float *>(s.de_x);
   } else if (int rc = loss_sweep(d, b, s.beta, s.alpha, e_b, st, L)) {
     return rc;
   }
   const int32_t *pos_ids = s.pos_ids ? s.pos_ids : s.rows;
+  const int nloss = s.de_x ? 0 : L.ni * L.js;      // loss partials for the finish to sum (none: the loss came with de_x)
   *dgrad_done = false;
   if (s.w1t && loss_dgrad_available(d, b)) {
-    FinishDgrad T{b, d, L.js, L.ni * L.js, L.de_part, L.loss_part, s.alpha, e_b, s.rows, pos_ids, s.pos_set, s.keep, s.inv_den, s.p, s.c,
+    FinishDgrad T{b, d, L.js, nloss, L.de_part, L.loss_part, s.alpha, e_b, s.rows, pos_ids, s.pos_set, s.keep, s.inv_den, s.p, s.c,
                   s.dx_b, s.dp_b, s.loss_out, s.w1t, s.w2t, s.gax_b, s.gam_b, s.dgrad_all ? 1 : 0};
     dim3 grid(L.ni), block(256);
     const size_t lds = sizeof(float) * 16 * (size_t)(d + 4);
@@ -831,7 +831,7 @@ int loss_step(const LossStep &s, void *ws, void *stream, bool *dgrad_done) {
   const int vpl = d4 <= 64 ? 1 : d4 <= 128 ? 2 : 4;
   dim3 grid(ceil_div(b, 4 * (64 >> lg))), block(256);
 #define GSS_FIN(V)                                                                                                              \
-  hipLaunchKernelGGL((loss_finish_bwd_kernel<V>), grid, block, 0, st, b, d4, lg, L.js, L.ni * L.js, L.de_part, L.loss_part, s.alpha, \
+  hipLaunchKernelGGL((loss_finish_bwd_kernel<V>), grid, block, 0, st, b, d4, lg, L.js, nloss, L.de_part, L.loss_part, s.alpha, \
                      e_b, (const int32_t *)nullptr, s.rows, pos_ids, s.keep, s.inv_den, s.p, s.c, s.dx_b, s.dp_b, s.pos_set, s.loss_out)
   if (vpl == 1)
     GSS_FIN(1);
