@@ -5,6 +5,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; export GRAFT_REPO_ROOT=$R
 O=$R/gpurun_out/r4g; mkdir -p $O; cd $R
 bash tools/pmc_rmat_r04.sh 10000000 200000000 65536 2 > $O/pmc_rmat.log 2>&1; echo "pmc_rmat rc=$?"; tail -8 $O/pmc_rmat.log
 cp profiles/r04_spmm_pmc_rmat10m.json $O/ 2>/dev/null
+# the raw counter / trace csvs of nine passes over 210 M-entry launches are large: keep the summaries (log.txt), drop the rest
+find $R/gpurun_out/pmc -name "*.csv" -size +200k -delete 2>/dev/null
 timeout -k 10 400 python3 bench.py --workload rmat:10000000:200000000 --steps 5 --warmup 2 --min-time 0 --spinup-time 0 > $O/bench_rmat10m.json 2> $O/bench_rmat10m.err; echo "bench rmat rc=$?"
 python3 - <<'PY'
 import json,os
