@@ -634,6 +634,9 @@ def main():
             rows = all_ranks([lh[3], lh[5]])
             out["xgmi"]["subset_exchange_u"] = {"rows_fetched_last_step_by_rank": rows[:, 0].astype(int).tolist(),
                                                 "rows_of_the_whole_halo_by_rank": rows[:, 1].astype(int).tolist(),
+                                                # a subset hop blocks the host once (gss_comm_sync: stream drain + the 144-byte
+                                                # D2H copy of the per-peer counts); its cost is inside ms_per_step, not inside the comm brackets
+                                                "host_round_trips_per_full_step": 1, "host_round_trips_per_lazy_step": 2,
                                                 "note": "ideal_exchange_us_per_step above is priced on whole halos"}
         fa, ft = shard.layout.halo_fraction()
         halo_info.update({"halo_fraction_a": fa, "halo_fraction_at": ft})
