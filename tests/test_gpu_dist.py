@@ -645,3 +645,60 @@ def test_sharded_step_enqueues_the_announced_collectives(world, case, recompute,
                 assert np.abs(emb - ref_out[k][1]).max() <= T.TRAJ_EMB_REL * np.abs(ref_out[k][1]).max(), k
             first = (steady[0] + (2 + 2 * rec if L > 1 else 1), steady[1], steady[2]) if k == 0 else steady
             assert stats == first, (k, stats, first)
+
+
+def test_large_batches_sweep_the_loss_as_row_slabs_by_themselves():
+    """knob loss_slab left at its default: from B = 8192 on a sharded plan sweeps the B x B loss as row slabs (rank r the i tiles r, r + P,
+    ...; the ranks' rows of dE and shares of the loss summed by a second batch all-reduce), below it the sweep is replicated.  Config 2's
+    graph at world 2, d = 64: B = 2048 (replicated), B = 8192 and the reference's default --batch-size 0, i.e. ONE batch of all N =
+    29,960 nodes (1873 i tiles: 937 / 936 per rank) -- losses and embeddings against the single-GPU plan."""
+    from gcn_drug_repurposing_amd.dist import local_comms, sharded_plan_engine
+    from gcn_drug_repurposing_amd.engine import GssEngine
+    from gcn_drug_repurposing_amd.graph import GssGraph
+    from gcn_drug_repurposing_amd.synth import whole_graph_standin
+    adj = whole_graph_standin(seed=1)[0]
+    n, d, L, world = adj.shape[0], 64, 2, 2
+    rng = np.random.RandomState(6)
+    X = (rng.randn(n, d) / 4).astype(np.float32)
+    w = (rng.randn(d, d) * 1e-2).astype(np.float32)
+    np.fill_diagonal(w, 1.0)
+    p0 = {"W1": w, "b1": np.zeros(d, np.float32), "W2": w.copy(), "b2": np.zeros(d, np.float32)}
+    batches = [rng.permutation(n)[:b].astype(np.int32) for b in (2048, 8192, n, 8200)]
+    kw = dict(num_layers=L, layer_decay=0.3, alpha=1.0, lr=1e-3, max_batch=n)
+    ref = GssEngine(GssGraph(adj), torch.from_numpy(X).cuda(), [torch.from_numpy(p0[k].copy()).cuda() for k in ("W1", "b1", "W2", "b2")], **kw)
+    ref_out = []
+    for idx in batches:
+        ref.step(torch.from_numpy(idx).cuda(), 0.2)
+        ref_out.append((ref.loss.item(), ref.emb.cpu().numpy().copy()))
+    comms = local_comms(world)
+    results, errors = [None] * world, []
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                eng = sharded_plan_engine(adj, X, p0, comms[rank], device=torch.device("cuda:0"), **kw)
+                out = []
+                for idx in batches:
+                    eng.comm_stats()
+                    eng.step(torch.from_numpy(idx).cuda(), 0.2)
+                    stats = eng.comm_stats()
+                    eng.check_guards()
+                    out.append((eng.loss.item(), eng.gather_embeddings().cpu().numpy(), stats))
+                results[rank] = out
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+            comms[rank].abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(900) for t in ts]
+    assert not errors, errors
+    for res in results:
+        assert res is not None
+        for k, (loss, emb, stats) in enumerate(res):
+            assert stats[1] == (1 if len(batches[k]) < 8192 else 2), (k, stats)          # batch-row all-reduces: the slab adds one
+            assert abs(loss - ref_out[k][0]) <= T.TRAJ_LOSS_RTOL * abs(ref_out[k][0]), (k, loss, ref_out[k][0])
+            assert np.abs(emb - ref_out[k][1]).max() <= T.TRAJ_EMB_REL * np.abs(ref_out[k][1]).max(), k
+    assert results[0][2][0] == results[1][2][0]                                             # replicas agree bit for bit
