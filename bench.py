@@ -608,7 +608,10 @@ def main():
         mine = [own_ms_per_step, comm_ms, halo_bytes_a, halo_bytes_t, pair_a, pair_t, out["roofline"]["frac"] if out["roofline"] else 0.0,
                 out["roofline"]["avg_launch_us"] if out["roofline"] else 0.0, n_loc, nnz_loc]
         allv = all_ranks(mine)
-        hops_a, hops_t = max(0, 2 * L - 2 - (1 if L > 1 else 0)), max(0, 2 * L - 3)     # (halo_recompute: layer 2's boundary input rows are computed, not fetched)
+        # (halo_recompute: layer 2's boundary input rows are computed, not fetched; two layers: the last backward hop runs on A_hat's shard
+        #  transposed in place and fetches nothing)
+        tloc = L == 2 and getattr(shard.layout, "a_loc_t", None) is not None
+        hops_a, hops_t = max(0, 2 * L - 2 - (1 if L > 1 else 0)), max(0, 2 * L - 3 - (1 if tloc else 0))
         # a hop is done when its most loaded pair is: every pair has its own xGMI link (8 GPUs fully connected), so the floor per hop
         # is max over pairs of bytes / link rate; the all-reduces (B d, 2 B d and 2 (d^2 + d) floats) are latency-bound and not priced
         ideal_us = (hops_a * allv[:, 4].max() + hops_t * allv[:, 5].max()) / (XGMI_LINK_GBS * 1e9) * 1e6

@@ -40,7 +40,8 @@ class HaloDesc(C.Structure):
 
 class ShardDesc(C.Structure):
     _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("h_bounds", C.c_void_p), ("halo_a", HaloDesc), ("halo_at", HaloDesc),
-                ("d_gid2op_t", C.c_void_p), ("a_own", C.c_void_p), ("a_halo", C.c_void_p), ("at_own", C.c_void_p), ("at_halo", C.c_void_p)]
+                ("d_gid2op_t", C.c_void_p), ("a_own", C.c_void_p), ("a_halo", C.c_void_p), ("at_own", C.c_void_p), ("at_halo", C.c_void_p),
+                ("a_loc_t", C.c_void_p)]
 
 
 class PlanIO(C.Structure):

@@ -107,7 +107,7 @@ int batch_bits(const int32_t *ids, int32_t b, uint32_t *bits, int set, void *str
 bool spmm_sparse_available();
 int spmm_bwd2_sparse_res(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res_b,
                          const int32_t *pos_row, float *dp, float *gx_out, void *stream, const uint32_t *nzbits = nullptr,
-                         const float *y_in = nullptr);
+                         const float *y_in = nullptr, int32_t pos_row_limit = 0);   // pos_row_limit > 0: pos_row covers output rows below it only
 // rlist (nullable): per member the local row when this shard owns it, -1 otherwise -- the row list of the lazy top layer
 int batch_prepare(const int32_t *idx, int32_t b, const int32_t *node_map, int32_t lo, int32_t nl, const int32_t *gid2op, int32_t *rloc,
                   int32_t *pid, float *keep, int32_t *pos, void *stream, int32_t *rlist = nullptr);

@@ -94,6 +94,9 @@ struct gss_plan {
   // overlapped hops (gss_shard_desc a_own / a_halo / at_own / at_halo): the boundary rows of a hop travel on `xs` while the entries
   // that reference the shard's own rows are multiplied on the caller's stream; the boundary-column entries are added afterwards
   const gss_csr *a_own, *a_halo, *at_own, *at_halo;
+  // the shard's A_hat transposed in place (gss_shard_desc.a_loc_t; used with halo_recompute at two layers): the last backward hop in
+  // scatter-by-owner form, no exchange of u
+  const gss_csr *tloc;
   hipStream_t xs;
   hipEvent_t ev_ready, ev_halo;
   // lazy halo (knob lazy_halo; gss_plan_step_lazy on shards): of the top layer's M only the boundary rows that the batch rows this
@@ -228,7 +231,7 @@ void carve(gss_plan *p, Carver &c) {
     p->g_am = c.take<float>(nd_t);                             // operands of A_hat^T
     p->u = c.take<float>(nd_t);
     p->t = c.take<float>(nd);
-    p->dp = c.take<float>(nd);
+    p->dp = c.take<float>(p->tloc ? nd_a : nd);              // (tloc: the last hop's dP also on the boundary rows)
     p->gx[0] = L > 2 ? c.take<float>(nd) : nullptr;
     p->gx[1] = L > 2 ? c.take<float>(nd) : nullptr;
   } else {
@@ -259,8 +262,7 @@ void carve(gss_plan *p, Carver &c) {
     p->adam_v[k] = c.take<float>(cnt[k]);
   }
   p->loss_ws = c.take<char>(loss_workspace_bytes_max(D.max_batch, D.d, p->P));   // not monotone in the batch size: the worst case over 1..max_batch
-  const int wg_total = wgrad_slices_max(D.max_batch, D.d) + (L - 1) * wgrad_slices(D.n, D.d);
-  p->wgrad_ws = c.take<char>(sizeof(float) * (size_t)wg_total * ((size_t)D.d * 2 * D.d + D.d));
+  p->wgrad_ws = c.take<char>(sizeof(float) * (size_t)p->wg_total * ((size_t)D.d * 2 * D.d + D.d));
 }
 
 bool halo_ok(const gss_halo_desc &h, int P, int rank) {
@@ -350,6 +352,7 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
   p->rows_t = (size_t)desc->n + (size_t)hat;
   p->gid2op_t = (P > 1 && desc->num_layers > 1) ? shard->d_gid2op_t : nullptr;
   p->a_own = p->a_halo = p->at_own = p->at_halo = nullptr;
+  p->tloc = nullptr;
   p->xs = nullptr;
   p->ev_ready = p->ev_halo = nullptr;
   if (P > 1 && shard->a_own && shard->a_halo) {
@@ -378,7 +381,7 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
   p->step = 0;
   p->layer1_valid = false;
   p->wt_valid = false;
-  p->wg_total = wgrad_slices_max(desc->max_batch, desc->d) + (desc->num_layers - 1) * wgrad_slices(desc->n, desc->d);
+
   p->prof_on = false;
   p->ev_used = 0;
   for (int k = 0; k < GSS_PROF_CLASSES; ++k) {
@@ -409,10 +412,25 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
   {
     const int knob = K().halo_recompute;
     p->recompute = P > 1 && desc->num_layers > 1 && knob != 0;   // (automatic = on: what it trades is priced below)
+    if (p->recompute && desc->num_layers == 2 && shard->a_loc_t) {
+      const gss_csr *t = shard->a_loc_t;
+      if (!(t->n_rows == desc->n + ha && t->n_cols == desc->n && t->nnz == a->nnz)) {
+        const int r_ = t->n_rows, c_ = t->n_cols;
+        const long long z_ = (long long)t->nnz;
+        delete p;
+        return fail(GSS_EINVAL, "plan_create_sharded: a_loc_t is %d x %d with %lld entries, expected the transpose of A_hat's shard (%lld x %d, %lld)",
+                    r_, c_, z_, (long long)(desc->n + ha), desc->n, (long long)a->nnz);
+      }
+      p->tloc = t;
+    }
     p->l0h_ready = false;
     p->n_coll[0] = p->n_coll[1] = p->n_coll[2] = 0;
     p->eb_rows = 0;
   }
+  // slices of the shared weight-gradient partial buffer: the top layer's batch rows + every layer below over its rows (the bottom layer
+  // over own + boundary rows with tloc)
+  p->wg_total = wgrad_slices_max(desc->max_batch, desc->d) + (desc->num_layers - 1) * wgrad_slices(desc->n, desc->d);
+  if (p->tloc) p->wg_total += wgrad_slices((int32_t)p->rows_a, desc->d);
   Carver sizing;
   carve(p, sizing);
   p->slab_bytes = sizing.off + 256;
@@ -1016,6 +1034,7 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
       const float *res = (lp + 2 <= L - 1) ? p->gx[(lp + 2) & 1] : nullptr;
       float *gx_out = (lp >= 1 && L > 2) ? p->gx[(lp + 1) & 1] : nullptr;
       const bool fold_res = deferred_slices && sparse_top && lp + 2 == L;
+      bool use_tloc = false;
       {
         // gx = t + A_hat^T u needs u's boundary rows (C1).  fold_res: dP += dx_b on the batch rows inside the SpMM epilogue (no separate
         // scatter-add launch).  Overlapped: the own-column sums go to dp first (with the non-zero-row filter of u where there is one)
@@ -1037,7 +1056,19 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
         };
         // fold_res with the non-zero-row bitmap: u is zero outside the batch's neighbourhood -- the owners send the rows that are not
         const bool subset = fold_res && p->lzt.on && p->nzbits;
-        if (int rc = plan_hop(p, p->halo_t, split_t, p->u, stream, full, own, rest, nullptr, 0, subset ? p->nzbits : nullptr)) return rc;
+        // tloc (two layers, halo_recompute, the shard's A_hat transposed in place): dP_0 only feeds the bottom layer's weight gradient,
+        // a sum over ALL nodes that the ranks' all-reduce completes anyway -- so this shard multiplies ITS rows of u into every row they
+        // touch, own and boundary (T_loc u_own), applies c * (t + .) (.) ELU'(P_0) there (t exists on own rows; P_0 of the boundary
+        // rows is what layer 1's projection over own + boundary rows left behind) and sums the weight gradient over own + boundary
+        // rows below.  Every (entry, u row) pair is counted once, at the owner of the u row: no exchange.
+        use_tloc = fold_res && lp == 0 && p->tloc != nullptr;
+        if (use_tloc) {
+          PROF(GSS_PROF_SPMM_BWD2);
+          if (int rc = spmm_bwd2_sparse_res(p->tloc, D.d, p->u, p->t, p->p[0], c, p->dx_b, pos_row, p->dp, nullptr, stream, p->nzbits, nullptr, D.n))
+            return rc;
+        } else if (int rc = plan_hop(p, p->halo_t, split_t, p->u, stream, full, own, rest, nullptr, 0, subset ? p->nzbits : nullptr)) {
+          return rc;
+        }
       }
       if (lp + 2 == L && !fold_res) {
         PROF(GSS_PROF_ELEMENTWISE);
@@ -1047,7 +1078,8 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
         PROF(GSS_PROF_WGRAD);
         if (merge_top && lp == L - 2) {
           int n_top = 0;
-          if (int rc = wgrad_partial_pair(D.d, D.n, p->dp, p->ax[lp], p->am[lp], nullptr, wg_used, b, p->dp_b, p->ax[L - 1], p->am[L - 1], bv.rows,
+          const int32_t n_w = use_tloc ? (int32_t)p->rows_a : D.n;       // tloc: dP_0 lives on own + boundary rows
+          if (int rc = wgrad_partial_pair(D.d, n_w, p->dp, p->ax[lp], p->am[lp], nullptr, wg_used, b, p->dp_b, p->ax[L - 1], p->am[L - 1], bv.rows,
                                           0, p->wgrad_ws, p->wg_total, &wg_n, &n_top, stream))
             return rc;
         } else {

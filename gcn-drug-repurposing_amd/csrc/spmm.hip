@@ -49,6 +49,8 @@ struct SpmmEpi {
                                 // first pass of a two-pass SPMM_BWD2S, whose second pass carries the same bitmap as posbits)
   const uint32_t *rowbits;      // SPMM_PLAIN, optional: only rows whose bit is set are computed (the first pass of a two-pass SPMM_FWD1
                                 // under a row bitmap, whose second pass carries the same bitmap as posbits)
+  int pos_row_limit;            // SPMM_BWD2S, > 0: pos_row is defined for output rows below it only (a shard's own rows; the rows behind
+                                // them -- the boundary rows of the in-place transposed A_hat -- are never batch rows of this shard)
 };
 
 struct CsrView {
@@ -247,6 +249,7 @@ constexpr int kBalWaves = kBalThreads / 64;
 template <int MODE>
 __device__ __forceinline__ long compact_off(const SpmmEpi &ep, int row, int d4, int f4) {
   if (MODE != SPMM_BWD1S && MODE != SPMM_BWD2S) return -1;
+  if (MODE == SPMM_BWD2S && ep.pos_row_limit > 0 && row >= ep.pos_row_limit) return -1;
   const int pr = ep.pos_row[row];
   return pr >= 0 ? ((long)pr * d4 + f4) * 4 : -1;
 }
@@ -254,6 +257,7 @@ __device__ __forceinline__ long compact_off(const SpmmEpi &ep, int row, int d4, 
 // SPMM_BWD2S with a bitmap: a clear bit says row `row` of t is zero
 template <int MODE>
 __device__ __forceinline__ bool row_t_zero(const SpmmEpi &ep, int row) {
+  if (MODE == SPMM_BWD2S && ep.pos_row_limit > 0 && row >= ep.pos_row_limit) return true;   // a boundary row: t exists on own rows only
   if (MODE != SPMM_BWD2S || !ep.posbits) return false;
   return ((ep.posbits[(unsigned)row >> 5] >> (row & 31)) & 1u) == 0u;
 }
@@ -679,11 +683,13 @@ int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const fl
 }
 
 int spmm_bwd2_sparse_res(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res_b,
-                         const int32_t *pos_row, float *dp, float *gx_out, void *stream, const uint32_t *nzbits, const float *y_in) {
+                         const int32_t *pos_row, float *dp, float *gx_out, void *stream, const uint32_t *nzbits, const float *y_in,
+                         int32_t pos_row_limit) {
   GSS_REQUIRE(u && t && p && res_b && pos_row && dp, "spmm_bwd2_sparse_res: null operand");
   GSS_REQUIRE(K().spmm_variant == 2, "spmm_bwd2_sparse_res needs the balanced SpMM (spmm_variant 2)");
   SpmmEpi ep{t, p, res_b, dp, gx_out, c, nullptr, pos_row, nzbits, nullptr, 0};
   ep.y_in = y_in;
+  ep.pos_row_limit = pos_row_limit;
   return launch_spmm<SPMM_BWD2S>(at, d, u, ep, stream);
 }
 

@@ -290,12 +290,14 @@ class Halo:
 class ShardLayout:
     """everything gss_plan_create_sharded borrows for one shard; keeps the host arrays and device tensors alive"""
 
-    def __init__(self, part: Partition, rank, halo_a: Halo, halo_at, device, split_a=None, split_at=None):
+    def __init__(self, part: Partition, rank, halo_a: Halo, halo_at, device, split_a=None, split_at=None, a_loc_t=None):
         self.part, self.rank, self.world = part, rank, part.parts
         self.bounds = np.ascontiguousarray(part.bounds, dtype=np.int64)
         self.halo_a, self.halo_at = halo_a, halo_at
         # (own-column CSR, boundary-column CSR) of A_hat / A_hat^T, or None: with them the plan overlaps a hop with its exchange
         self.split_a, self.split_at = split_a, split_at
+        # the shard's A_hat transposed in place ([n + n_halo_a] x [n]), or None: with it the last backward hop needs no exchange of u
+        self.a_loc_t = a_loc_t
         self.gid2op_t = torch.from_numpy(halo_at.gid2op).to(device) if halo_at is not None else None
         self._empty = np.zeros(part.parts + 1, dtype=np.int64)
 
@@ -305,7 +307,8 @@ class ShardLayout:
             return pair[k].handle if pair is not None else None
         return _lib.ShardDesc(self.world, self.rank, self.bounds.ctypes.data, self.halo_a.c_desc(),
                               self.halo_at.c_desc() if self.halo_at is not None else none, _lib.ptr(self.gid2op_t),
-                              h(self.split_a, 0), h(self.split_a, 1), h(self.split_at, 0), h(self.split_at, 1))
+                              h(self.split_a, 0), h(self.split_a, 1), h(self.split_at, 0), h(self.split_at, 1),
+                              self.a_loc_t.handle if self.a_loc_t is not None else None)
 
     @property
     def overlapped(self):

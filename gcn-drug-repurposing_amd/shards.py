@@ -488,7 +488,22 @@ def split_by_column(rowptr, col_local, val32, nl, device):
     return out
 
 
-def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="auto", row_weight=ROW_WEIGHT, ops=None, split="auto") -> Shard:
+def transpose_in_place(rowptr, col_local, val32, nl, n_cols, device):
+    """the shard's A_hat ([nl] x [n_cols], operand-row column ids) transposed: (rowptr [n_cols + 1], col = own row ids, val), a row's
+    entries in ascending own-row order"""
+    nnz = int(col_local.numel()) if nl else 0
+    counts = (rowptr[1:] - rowptr[:-1]).long()
+    row_of = torch.repeat_interleave(torch.arange(nl, device=device), counts) if nl else torch.zeros(0, dtype=torch.long, device=device)
+    c = col_local[:row_of.numel()].long()
+    order = torch.argsort(c * max(nl, 1) + row_of)
+    rp = torch.zeros(n_cols + 1, dtype=torch.int64, device=device)
+    if row_of.numel():
+        rp[1:] = torch.cumsum(torch.bincount(c, minlength=n_cols), 0)
+    return rp.to(torch.int32), row_of[order].to(torch.int32).contiguous(), val32[:row_of.numel()][order].contiguous()
+
+
+def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="auto", row_weight=ROW_WEIGHT, ops=None, split="auto",
+                local_transpose="auto") -> Shard:
     """relabel: True / False / "auto" (hub-first node order when the graph has >= RELABEL_MIN_NODES nodes; the non-temporal
     treatment of the cold rows additionally needs an operand far beyond the caches, gss_csr_set_hot).  Relabelling is invisible in
     the results: a row's entries keep their original
@@ -496,11 +511,15 @@ def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="a
     GssEngine.gather_embeddings returns original order.  ops: the device side (NativeShardOps unless a test plugs its own).
     split: True / False / "auto" -- also keep every matrix split into its own-column and boundary-column entries, so that the plan
     overlaps each hop with its halo exchange (gss_shard_desc.a_own ...; results then differ from the single-GPU plan by rounding,
-    not bit for bit).  "auto": when a hop fetches >= SPLIT_MIN_HALO_ROWS boundary rows on some rank (RMAT scale), never on one rank."""
+    not bit for bit).  "auto": when a hop fetches >= SPLIT_MIN_HALO_ROWS boundary rows on some rank (RMAT scale), never on one rank.
+    local_transpose: True / False / "auto" (on unless GSS_LOCAL_TRANSPOSE=0) -- also keep A_hat's shard transposed in place, so that the
+    plan's last backward hop needs no exchange of u (gss_shard_desc.a_loc_t)."""
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     ops = ops or NativeShardOps()
     P, rank = comm.world, comm.rank
     import os
+    if local_transpose == "auto":      # job-wide: every rank inherits the environment
+        local_transpose = os.environ.get("GSS_LOCAL_TRANSPOSE", "1") != "0"
     if split == "auto" and os.environ.get("GSS_SPLIT") in ("0", "1"):
         split = os.environ["GSS_SPLIT"] == "1"      # job-wide override (every rank inherits the environment): entry points without a flag for it
     work = np.asarray(source.work(comm, dev), dtype=np.int64)
@@ -544,18 +563,25 @@ def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="a
                 if hot is not None:
                     ops.set_hot(part_csr, *hot)
                 halves.append(part_csr)
-        return csr, halo, halves
+        loc_t = None
+        if not transposed and P > 1 and need_transpose and local_transpose:
+            # A_hat's shard transposed in place, for the exchange-free last backward hop (gss_shard_desc.a_loc_t)
+            rp, cl, vl = transpose_in_place(rowptr, col_local, val32, nl, nl + halo.n_halo, dev)
+            loc_t = ops.csr(rp.cpu().numpy(), cl, vl if vl.numel() else val32[:1], nl + halo.n_halo, nl, dev)
+            if hot is not None:
+                ops.set_hot(loc_t, hot[0], nl, nl)          # its operand is u's OWN rows: the shard's own hubs
+        return csr, halo, halves, loc_t
 
-    a, halo_a, split_a = finish(rowptr, col, val, 0)
+    a, halo_a, split_a, a_loc_t = finish(rowptr, col, val, 0)
     del rowptr, col, val
     at, halo_at, split_at = None, None, None
     if need_transpose:
         rowptr, col, val = source.rows_t(lo, hi, dev, relabel=rl)
-        at, halo_at, split_at = finish(rowptr, col, val, 1)
+        at, halo_at, split_at, _ = finish(rowptr, col, val, 1)
         del rowptr, col, val
     if hasattr(source, "release"):
         source.release()
-    layout = ShardLayout(part, rank, halo_a, halo_at, dev, split_a=split_a, split_at=split_at)
+    layout = ShardLayout(part, rank, halo_a, halo_at, dev, split_a=split_a, split_at=split_at, a_loc_t=a_loc_t)
     node_map = rl.inv_dev(dev).to(torch.int32).contiguous() if rl is not None else None
     return Shard(a, at, layout, part, int(source.nnz), rowsum[:nl], rl, node_map, split_a=split_a, split_at=split_at)
 

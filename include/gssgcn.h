@@ -370,6 +370,14 @@ typedef struct gss_shard_desc {
    * there.  A row is then summed as (own entries) + (boundary entries) instead of in column order: results differ from the
    * single-GPU plan by rounding (~1e-7 relative), no longer bit for bit.  All NULL: exchange, then one pass (the default). */
   const gss_csr *a_own, *a_halo, *at_own, *at_halo;
+  /* Optional (round 4): the shard's A_hat transposed IN PLACE -- rows = its operand rows (own rows, then the boundary rows), columns =
+   * its own rows, [n + n_halo_a] x [n], the same values.  With it (and halo_recompute) the LAST backward hop, whose result only feeds
+   * the bottom layer's weight gradient, runs in scatter-by-owner form: this shard multiplies ITS rows of u into every row they touch
+   * (own and boundary), applies ELU'(P) there (P of the boundary rows is what halo_recompute computes anyway) and sums the weight
+   * gradient over own + boundary rows; the ranks' all-reduce of the weight gradients completes the sum.  No exchange of u's boundary
+   * rows in that hop: 3 collectives per step at two layers.  The weight gradients then add per-rank partial sums (rounding-level
+   * differences, as with any other change of their summation order).  NULL: the hop fetches u's boundary rows (the default). */
+  const gss_csr *a_loc_t;
 } gss_shard_desc;
 int gss_plan_create_sharded(gss_plan **out, const gss_plan_desc *desc, const gss_shard_desc *shard, gss_comm *comm,
                             const gss_csr *a, const gss_csr *at, const gss_plan_io *io);

@@ -15,7 +15,8 @@ the data layout and the order of the exchange points, line by line:
   ONE batch collective: [E_B | P_B | inv_B] = sum over shards of (own rows | 0)                           C3, plan_loss_backward_impl
   batch maps: rloc / keep / pid = gid2op_t[node_map[idx]]                 loss.hip gather_batch_kernel
   finish + input gradient of EVERY member on every rank (no second collective), sparse first hop         loss.hip tail, plan_backward_impl
-  halo of u (A_hat^T's halo) before every second hop                      plan_backward_impl
+  halo of u (A_hat^T's halo) before every second hop -- except the LAST one at two layers, which runs in scatter-by-owner form over
+      A_hat's shard transposed in place (gss_shard_desc.a_loc_t): no exchange                           plan_backward_impl (use_tloc)
   four weight gradients summed over the shards, then Adam                 plan_step_impl (P > 1 branch)
 
 The arithmetic is NumpyOps' (fp64 inside an op, fp32 between ops)."""
@@ -58,6 +59,9 @@ class ShardStepMirror:
         self.m0op = None
         self.recompute = self.P > 1 and self.L > 1      # knob halo_recompute, automatic choice (on)
         self.slab = slab and self.P > 1                 # knob loss_slab (automatic: batches of >= 8192 rows)
+        # gss_shard_desc.a_loc_t: A_hat's shard transposed in place -- two layers + halo_recompute: the last backward hop without an exchange
+        t_loc = getattr(lay, "a_loc_t", None)
+        self.tloc = t_loc.m if (t_loc is not None and self.recompute and self.L == 2) else None
         self.ax0op = self.am0op = None
         self.loss = None
         self.emb = None
@@ -126,7 +130,8 @@ class ShardStepMirror:
                 p, xn = p_op[:n], torch.from_numpy(x_op[:n])
             else:
                 p, xn = self.ops.dense_fwd(torch.from_numpy(ax), torch.from_numpy(am), self.params, p_prev, self.decay)
-            self.act.append({"xin": xl, "ax": ax, "am": am, "p": p.numpy()})
+            self.act.append({"xin": xl, "ax": ax, "am": am, "p": p.numpy(),
+                             "p_op": (p_op.numpy() if (l == 0 and self.recompute) else None)})
             x_own, p_prev = xn.numpy(), p
         e, inv = self.ops.rownorm_fwd(torch.from_numpy(x_own))         # model.py:205
         self.emb, self.inv_den = e.numpy(), inv.numpy()
@@ -220,6 +225,19 @@ class ShardStepMirror:
             for lp in range(L - 2, -1, -1):
                 lay = self.act[lp]
                 c = 1.0 if lp == 0 else self.decay
+                if self.tloc is not None and lp == 0:
+                    # plan_backward_impl, use_tloc: this shard's rows of u multiplied into every row they touch (own + boundary), ELU'(P_0)
+                    # applied there, the weight gradient summed over own + boundary rows -- no exchange of u; the ranks' all-reduce of the
+                    # weight gradients completes the sum
+                    rows_a = n + self.ha.n_halo
+                    g_ext = self.tloc @ u_own.astype(np.float64)
+                    g_ext[:n] += t.astype(np.float64)
+                    dp_ext = c * g_ext * _elu_grad(lay["p_op"].astype(np.float64))
+                    if n > 0:
+                        np.add.at(dp_ext, rloc[mine], dx_b[mine].astype(np.float64))
+                    assert dp_ext.shape[0] == rows_a
+                    wgrad(_f32(dp_ext), self.ax0op, self.am0op)
+                    continue
                 u = self._operand(self.ht, u_own)
                 self._halo(self.ht, u)                                 # C1 on A_hat^T's halo
                 g = t.astype(np.float64) + self.at @ u.astype(np.float64)

@@ -369,7 +369,7 @@ def test_two_rccl_ranks_bench_line_is_complete():
     for key in ("roofline", "xgmi", "per_rank", "comm_share", "kernel_ms_per_step", "value_executed", "collectives_per_step"):
         assert key in line, key
     assert len(line["per_rank"]["ms_per_step"]) == 2 and line["roofline"]["bound"] == "hbm"
-    assert line["collectives_per_step"]["total"] <= 4.0          # L = 2: M_1's and u's boundary rows, the batch rows, the weight gradients
+    assert line["collectives_per_step"]["total"] <= 3.0          # L = 2: M_1's boundary rows, the batch rows, the weight gradients
     assert np.isfinite(line["config"]["final_loss"])
 
 
@@ -418,7 +418,8 @@ def test_multi_process_bench_on_one_gpu_host_staged_backend():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--spinup-time", "0",
-                        "--min-time", "0"], capture_output=True, text=True, env=dict(_host_env(), GSS_OPTIONS="lazy_halo=1"), timeout=900)
+                        "--min-time", "0"], capture_output=True, text=True,
+                       env=dict(_host_env(), GSS_OPTIONS="lazy_halo=1", GSS_LOCAL_TRANSPOSE="0"), timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["rehearsal"] is True
@@ -427,8 +428,9 @@ def test_multi_process_bench_on_one_gpu_host_staged_backend():
     assert "REHEARSAL" in line["config"]["parallelism"]
     for key in ("roofline", "xgmi", "per_rank", "comm_share", "kernel_ms_per_step", "value_executed", "collectives_per_step"):
         assert key in line, key
-    # L = 2 with the subset exchange of u forced on: M_1's boundary rows (1), u's (bitmaps + rows: 2), the batch rows (1), the weight
-    # gradients (1); X_1's boundary rows are recomputed, the batch rows' input gradients are computed on every rank
+    # L = 2 with the subset exchange of u forced on and the exchange-free last hop switched off (GSS_LOCAL_TRANSPOSE=0, so that the
+    # subset exchange runs across processes): M_1's boundary rows (1), u's (bitmaps + rows: 2), the batch rows (1), the weight gradients
+    # (1); X_1's boundary rows are recomputed, the batch rows' input gradients are computed on every rank
     cps = line["collectives_per_step"]
     assert cps["batch_row_allreduces"] == 1 and cps["weight_gradient_allreduces"] == 1 and cps["boundary_row_exchanges"] == 3, cps
     assert len(line["per_rank"]["ms_per_step"]) == 2 and sum(line["per_rank"]["rows"]) == 29960
@@ -437,6 +439,13 @@ def test_multi_process_bench_on_one_gpu_host_staged_backend():
     assert ref.returncode == 0, ref.stderr[-3000:]
     one = json.loads([l for l in ref.stdout.splitlines() if l.startswith("{")][-1])
     assert abs(line["config"]["final_loss"] - one["config"]["final_loss"]) <= T.SPREAD_LOSS_REL * 10 * abs(one["config"]["final_loss"])
+    # the defaults: 3 collectives per step (M_1's boundary rows, the batch rows, the weight gradients)
+    r3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--spinup-time", "0",
+                         "--min-time", "0"], capture_output=True, text=True, env=_host_env(), timeout=900)
+    assert r3.returncode == 0, r3.stderr[-3000:]
+    l3 = json.loads([l for l in r3.stdout.splitlines() if l.startswith("{")][-1])
+    assert l3["collectives_per_step"]["total"] == 3.0, l3["collectives_per_step"]
+    assert abs(l3["config"]["final_loss"] - one["config"]["final_loss"]) <= T.SPREAD_LOSS_REL * 10 * abs(one["config"]["final_loss"])
 
 
 def test_multi_process_job_with_a_dying_rank_ends_instead_of_hanging():
@@ -571,7 +580,8 @@ def test_sharded_step_enqueues_the_announced_collectives(world, case, recompute,
     halo_recompute: layer 2's boundary input rows are recomputed from layer 1's constant AX / AM, fetched once) + 2L - 3 of A_hat^T's,
     ONE batch-row all-reduce ([E_B | P_B | inv_B]; the [2B][d] input gradients are computed on every rank by the loss kernel's tail
     -- widths the tail does not cover, d = 16 here, keep the second all-reduce) and one weight-gradient all-reduce: 4 collectives at
-    L = 2 where round 3 had 6.  gss_plan_comm_stats counts what the plan enqueued; the first step's embeddings and loss still equal
+    L = 2 where round 3 had 6 -- and 3 with A_hat's shard transposed in place (gss_shard_desc.a_loc_t, what build_shard passes by default): the
+    last backward hop then multiplies this shard's rows of u into own + boundary rows and needs no exchange.  gss_plan_comm_stats counts what the plan enqueued; the first step's embeddings and loss still equal
     the single-GPU plan's bit for bit, the later ones to the trajectory tolerances.  slab = 1: the row-slab form of the loss sweep
     (knob loss_slab, automatic from B = 8192: rank r sweeps the i tiles r, r + P, ...; the ranks' rows of dE and shares of the loss
     are summed by one more all-reduce) -- more ranks than i tiles included; its loss agrees to rounding."""
@@ -631,7 +641,8 @@ def test_sharded_step_enqueues_the_announced_collectives(world, case, recompute,
     assert not errors, errors
     rec = 1 if (recompute != 0 and L > 1) else 0
     tail = d in (64, 128, 256)
-    steady = ((2 * L - 2 - rec) + max(0, 2 * L - 3), (1 if (tail or L == 1) else 2) + (1 if slab == 1 else 0), 1)
+    tloc = 1 if (rec and L == 2) else 0          # two layers: the last backward hop on A_hat's shard transposed in place, no exchange of u
+    steady = ((2 * L - 2 - rec) + max(0, 2 * L - 3) - tloc, (1 if (tail or L == 1) else 2) + (1 if slab == 1 else 0), 1)
     for res in results:
         for k, (loss, emb, stats) in enumerate(res):
             if k == 0:     # one forward: a row's result does not depend on the shard, nor on who computed a boundary row
