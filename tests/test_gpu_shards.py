@@ -479,7 +479,10 @@ def test_lazy_halo_fetches_only_what_the_batch_rows_read(world, case, relabel, s
             comms = local_comms(world)
 
             def fn(rank):
-                shard = build_shard(ScipySource(adj), comms[rank], need_transpose=True, device="cuda:0", relabel=relabel, split=split)
+                # (local_transpose=False: at two layers the default runs the last backward hop without any exchange of u -- here its
+                #  subset exchange is what is under test)
+                shard = build_shard(ScipySource(adj), comms[rank], need_transpose=True, device="cuda:0", relabel=relabel, split=split,
+                                    local_transpose=False)
                 eng = shard_engine(shard, shard_rows(shard, X), p0, comms[rank], **kw)
                 lo, hi = shard.part.rows(rank)
                 indptr, col = shard.a.h_indptr, shard.a.col.cpu().numpy()[:shard.a.nnz]
@@ -543,7 +546,8 @@ def test_subset_exchanges_at_a_halo_of_several_compaction_trips():
             comms = local_comms(world)
 
             def fn(rank):
-                shard = build_shard(RmatSource(n, m, seed=4, device="cuda:0"), comms[rank], need_transpose=True, device="cuda:0", split=False)
+                shard = build_shard(RmatSource(n, m, seed=4, device="cuda:0"), comms[rank], need_transpose=True, device="cuda:0", split=False,
+                                    local_transpose=False)
                 lo, hi = shard.part.rows(rank)
                 eng = shard_engine(shard, gaussian_rows(lo, hi, d, 5), p, comms[rank], num_layers=L, layer_decay=0.3, alpha=1.0, lr=1e-3, max_batch=B)
                 losses, moved = [], []
