@@ -412,7 +412,11 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
   {
     const int knob = K().halo_recompute;
     p->recompute = P > 1 && desc->num_layers > 1 && knob != 0;   // (automatic = on: what it trades is priced below)
-    if (p->recompute && desc->num_layers == 2 && shard->a_loc_t) {
+    // (used where the hop it replaces would move a WHOLE halo: graphs below 262,144 nodes -- a latency-bound collective -- and big graphs
+    //  without the subset exchange of u (RCCL's default).  Where the subset exchange is on, u's few MB are cheaper than the boundary
+    //  rows' share of the bottom layer's weight gradient: RMAT 10M, world 8, all ranks on one GPU: 119.6 -> 128.0 ms per step with it)
+    const bool tloc_pays = n_global < 262144 || !p->lzt.on;
+    if (p->recompute && desc->num_layers == 2 && shard->a_loc_t && tloc_pays) {
       const gss_csr *t = shard->a_loc_t;
       if (!(t->n_rows == desc->n + ha && t->n_cols == desc->n && t->nnz == a->nnz)) {
         const int r_ = t->n_rows, c_ = t->n_cols;

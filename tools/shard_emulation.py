@@ -71,7 +71,7 @@ def worker(rank):
             t_lazy = (time.perf_counter() - t2) / steps * 1e3
             coll_lazy = [c / steps for c in eng.comm_stats()]
             fetched, sent, _, u_fetched, u_sent, u_halo = eng.lazy_halo_rows()
-            if recompute != 0 and L == 2 and shard.layout.a_loc_t is not None:
+            if recompute != 0 and L == 2 and coll_full[0] < 1.5:   # one boundary-row exchange per full step = M_1's: the plan took the exchange-free last hop
                 u_fetched = u_sent = u_halo = 0       # the last backward hop runs on A_hat's shard transposed in place: u is not exchanged
             fa, ft = shard.layout.halo_fraction()
             out[rank] = dict(rank=rank, rows=hi - lo, nnz=shard.a.nnz, halo_rows_a=shard.layout.halo_a.n_halo, halo_rows_at=shard.layout.halo_at.n_halo,
@@ -89,7 +89,7 @@ def worker(rank):
                              u_rows_fetched=(u_fetched if u_fetched >= 0 else u_halo), u_rows_sent=(u_sent if u_sent >= 0 else int(shard.layout.halo_at.send_off[-1])),
                              u_mb_fetched=round((u_fetched if u_fetched >= 0 else u_halo) * d * 4 / 2 ** 20, 2), lazy_halo=fetched >= 0,
                              # what a step moves INTO this rank: the hops' boundary rows (X_1 only without halo_recompute) + the batch rows
-                             halo_recompute=recompute != 0, exchange_free_last_hop=bool(recompute != 0 and L == 2 and shard.layout.a_loc_t is not None),
+                             halo_recompute=recompute != 0, exchange_free_last_hop=bool(u_halo == 0),
                              x1_mb_fetched_per_step=0.0 if recompute != 0 else round(shard.layout.halo_a.n_halo * d * 4 / 2 ** 20, 1),
                              collectives_per_full_step=dict(boundary_row_exchanges=coll_full[0], batch_row_allreduces=coll_full[1], weight_gradient_allreduces=coll_full[2]),
                              collectives_per_lazy_step=dict(boundary_row_exchanges=coll_lazy[0], batch_row_allreduces=coll_lazy[1], weight_gradient_allreduces=coll_lazy[2]))
