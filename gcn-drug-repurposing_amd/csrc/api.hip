@@ -127,6 +127,10 @@ int gss_debug_set_option(const char *name, int value) {
     g_knobs.loss_dgrad = value ? 1 : 0;
     return GSS_OK;
   }
+  if (strcmp(name, "prep_side") == 0) {
+    g_knobs.prep_side = value ? 1 : 0;
+    return GSS_OK;
+  }
   if (strcmp(name, "loss_slab") == 0) {
     GSS_REQUIRE(value >= -1 && value <= 1, "loss_slab must be -1 (by batch size), 0 or 1");
     g_knobs.loss_slab = value;   // read at every step of a sharded plan created afterwards; every rank of a job must use the same value

@@ -42,6 +42,8 @@ struct Knobs {
   int lazy_halo = -1;        // sharded lazy step: fetch only the boundary rows of the top layer's M that the batch rows read (-1 = graphs of >= 262,144 nodes, 0 = never, 1 = always)
   int ppr_fused = 1;         // diffusion profiles: the update and the column errors in the SpMM's epilogue (0 = separate update pass)
   int loss_dgrad = 1;        // finish + normalise' / ELU' + the batch rows' input gradient in one launch (0 = two launches); d in {64, 128, 256}
+  int prep_side = 1;         // one GPU: a step's batch preparation as a side job of its first forward SpMM, E_B out of the top layer's projection
+                             // (0 = the launches of their own: batch_prepare in lazy steps, the gather in full steps)
   int loss_slab = -1;        // sharded plans: the B x B loss sweep as row slabs (rank r: i tiles r, r + P, ...) + one more all-reduce, instead of
                              // replicated on every rank (-1 = from B = 8192 on, 0 = never, 1 = always; every rank of a job must use the same value)
   int halo_recompute = -1;   // sharded plans: layer 2's boundary input rows recomputed from layer 1's constant AX / AM instead of exchanged

@@ -44,6 +44,8 @@ struct GemmArgs {
   // EPI_SPLIT
   const int32_t *rows;  // scatter map for the output row (nullable)
   float *inv_den;       // EPI_FWD_NORM: 1 / max(||x_row||, eps) per node (x_next then receives the unit-norm rows)
+  const int32_t *rows_out_pos;   // EPI_FWD_NORM without a row list, with rows_out: node row r's unit-norm row also goes to
+                                 // rows_out[rows_out_pos[r]] where that is >= 0 (the batch-position map: E_B of a FULL step)
   float *rows_out;      // EPI_FWD_NORM over a row list (nullable): the unit-norm row of tile row t ALSO goes to rows_out[t] -- the lazy step's
                         // tile rows are the batch positions, so this IS E_B = emb[idx] (model.py:216-217) without a gather launch
   int xcd_remap;        // renumber the workgroups so that those sharing input rows sit on one XCD (xcd_ids below)
@@ -192,12 +194,15 @@ __device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&ac
     inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
   }
   if (!live) return;
+  // E_B (EPI_FWD_NORM, rows_out): with a row list the tile rows are the batch positions; without one the position comes from the map
+  int out_row = -1;
+  if (EPI == EPI_FWD_NORM && g.rows_out) out_row = g.rows_out_pos ? g.rows_out_pos[ndc] : nd;
 #pragma unroll
   for (int u = 0; u < NT; ++u) {
     const size_t off = (size_t)ndc * g.ld_out0 + j0 + 16 * u + 4 * q;   // ndc == nd for a live row without a row list
     st4(g.out0 + off, pv[u]);
     st4(g.x_next + off, EPI == EPI_FWD_NORM ? scale4(inv, o[u]) : o[u]);
-    if (EPI == EPI_FWD_NORM && g.rows_out) st4(g.rows_out + (size_t)nd * g.ld_out0 + j0 + 16 * u + 4 * q, scale4(inv, o[u]));
+    if (EPI == EPI_FWD_NORM && g.rows_out && out_row >= 0) st4(g.rows_out + (size_t)out_row * g.ld_out0 + j0 + 16 * u + 4 * q, scale4(inv, o[u]));
   }
   if (EPI == EPI_FWD_NORM && q == 0) g.inv_den[ndc] = inv;
 }
@@ -629,7 +634,7 @@ bool dense_row_list_available() { return K().gemm_variant >= 2; }   // the proje
 
 int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
                    const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream, const int32_t *row_list,
-                   float *rows_out) {
+                   float *rows_out, const int32_t *rows_out_pos) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(n >= 0 && ax && am && w1 && b1 && w2 && b2 && p && e && inv_den, "dense_fwd_norm: null operand");
   GSS_REQUIRE(dense_fwd_norm_available(d), "dense_fwd_norm: needs d in {16, 32, 64, 128} and the LDS-staged GEMM");
@@ -654,8 +659,9 @@ int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const
   g.decay = decay;
   g.inv_den = inv_den;
   g.rows = row_list;
-  GSS_REQUIRE(!rows_out || row_list, "dense_fwd_norm: rows_out goes with a row list");
+  GSS_REQUIRE(!rows_out || (row_list != nullptr) != (rows_out_pos != nullptr), "dense_fwd_norm: rows_out goes with a row list or with a position map");
   g.rows_out = rows_out;
+  g.rows_out_pos = rows_out_pos;
   return launch_gemm<EPI_FWD_NORM>(g, d, as_stream(stream));
 }
 

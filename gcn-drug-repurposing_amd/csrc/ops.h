@@ -40,6 +40,19 @@ struct gss_comm {
 };
 
 namespace gss {
+// What batch_prepare does, as a SIDE JOB of a forward SpMM launch (round 4): one extra workgroup of the launch translates the batch ids
+// and sets the batch-position map while the other workgroups multiply -- a launch of ~5 us (two dependent round trips around 2048
+// integers) disappears from the step's chain.  Nothing in that SpMM or before the top layer's projection reads what it writes.
+struct BatchPrep {
+  const int32_t *idx;        // NULL: no side job
+  int32_t b;
+  const int32_t *node_map;
+  int32_t lo, nl;
+  const int32_t *gid2op;
+  int32_t *rloc, *pid;
+  float *keep;
+  int32_t *pos, *rlist;
+};
 // nnz-balanced segment descriptors of a CSR for 2^gpw_log2 lane groups per wave (spmm.hip; cached in the handle)
 int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks);
 // Two-pass products (a shard's hop overlapped with its halo exchange, plan.hip): the rows' entries are split over two CSRs of the
@@ -49,7 +62,8 @@ int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float 
              const int32_t *row_pos = nullptr,    // plain product only: compute rows with row_pos[row] >= 0 only
              const uint32_t *row_bits = nullptr,  // Hadamard-fused product only: compute rows whose bit is set only
              const float *y_in = nullptr,
-             const uint32_t *gather_bits = nullptr);  // plain product only: neighbours whose bit is clear are skipped (their rows are zero)
+             const uint32_t *gather_bits = nullptr,   // plain product only: neighbours whose bit is clear are skipped (their rows are zero)
+             const BatchPrep *prep = nullptr);        // balanced SpMM only: the batch preparation as a side job of this launch
 int mark_rows_and_neighbours(const gss_csr *a, const int32_t *rows, int32_t b, uint32_t *bits, void *stream);
 int spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
               float *u, float *t, void *stream, const float *y_in = nullptr);
@@ -63,7 +77,9 @@ bool dense_fwd_norm_available(int32_t d);
 bool dense_row_list_available();
 int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
                    const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream,
-                   const int32_t *row_list = nullptr, float *rows_out = nullptr);   // rows_out: tile row t's unit-norm row also to rows_out[t]
+                   const int32_t *row_list = nullptr, float *rows_out = nullptr,    // rows_out: tile row t's unit-norm row also to rows_out[t]
+                   const int32_t *rows_out_pos = nullptr);   // without a row list: node row r's unit-norm row also to rows_out[rows_out_pos[r]]
+                                                             // where that is >= 0 (the batch-position map: E_B without a gather launch)
 float *loss_workspace_e_b(int32_t d, int32_t b, void *ws);   // where loss_gather_rows* would put E_B for a batch of b rows
 int dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t, const float *w2t, const int32_t *rows,
                     float *g_ax, float *g_am, void *stream);

@@ -89,6 +89,9 @@ struct gss_plan {
   bool recompute;
   bool l0h_ready;          // the boundary rows of AX_0 / AM_0 have been fetched
   int64_t n_coll[3];       // collectives enqueued since the last gss_plan_comm_stats: halo exchanges / batch-row / weight-gradient
+  const gss::BatchPrep *prep_pending;   // gss_plan_step on one GPU: the batch preparation rides in the step's first forward SpMM (consumed there)
+  int32_t eb_scatter_b;    // > 0 (a full step whose batch was prepared that way): the top layer's projection also scatters the unit-norm
+                           // rows of the batch members into E_B through the batch-position map -- no gather launch
   int32_t eb_rows;         // > 0: this step's lazy forward already wrote E_B for a batch of that many rows into the loss workspace (one GPU:
                            // the row-list projection's tile rows are the batch positions), so the loss needs no gather launch
   // overlapped hops (gss_shard_desc a_own / a_halo / at_own / at_halo): the boundary rows of a hop travel on `xs` while the entries
@@ -430,6 +433,8 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
     p->l0h_ready = false;
     p->n_coll[0] = p->n_coll[1] = p->n_coll[2] = 0;
     p->eb_rows = 0;
+    p->prep_pending = nullptr;
+    p->eb_scatter_b = 0;
   }
   // slices of the shared weight-gradient partial buffer: the top layer's batch rows + every layer below over its rows (the bottom layer
   // over own + boundary rows with tloc)
@@ -741,7 +746,9 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
         const uint32_t *rbits = (lazy_l && p->needbits) ? p->needbits : nullptr;
         auto full = [&]() {
           PROF(GSS_PROF_SPMM_FWD_HAD);
-          return spmm_fwd(p->a, D.d, xl, p->ax[l], xl, m, stream, nullptr, rbits);
+          const BatchPrep *prep = p->prep_pending;     // the step's batch preparation as a side job of its first forward SpMM
+          p->prep_pending = nullptr;
+          return spmm_fwd(p->a, D.d, xl, p->ax[l], xl, m, stream, nullptr, rbits, nullptr, nullptr, prep);
         };
         if (l == 0 || (l == 1 && p->recompute)) {
           // the boundary rows of X_0 are constants, fetched once by plan_x0; those of X_1 were computed by layer 1's projection
@@ -802,8 +809,13 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
         p->eb_rows = e_b ? lazy_b : 0;
         return GSS_OK;
       }
-      return dense_fwd_norm(D.n, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr, D.layer_decay,
-                            p->p[l], p->emb, p->inv_den, stream);
+      // a full step whose batch was prepared by the first SpMM's side job: the batch members' unit-norm rows also go to E_B
+      float *e_b = (p->eb_scatter_b > 0 && p->pos) ? loss_workspace_e_b(D.d, p->eb_scatter_b, p->loss_ws) : nullptr;
+      if (int rc = dense_fwd_norm(D.n, D.d, p->ax[l], p->am[l], p->w1, p->b1, p->w2, p->b2, l > 0 ? p->p[l - 1] : nullptr, D.layer_decay,
+                                  p->p[l], p->emb, p->inv_den, stream, nullptr, e_b, e_b ? p->pos : nullptr))
+        return rc;
+      p->eb_rows = e_b ? p->eb_scatter_b : 0;
+      return GSS_OK;
     }
 
     float *xn = (l == L - 1) ? p->x_last : p->xin[l + 1];
@@ -1227,10 +1239,27 @@ int gss_plan_step_lazy(gss_plan *p, const int32_t *idx, int32_t b, float beta, v
 static int plan_step_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream, bool lazy) {
   GSS_REQUIRE(p, "plan_step: null plan");
   const bool pipe = p->desc.pipeline_layer1 && p->side && !p->prof_on && !p->desc.cache_layer1;
+  // One GPU: the batch preparation (id translation, batch-position map) does not get a launch of its own where the step's first
+  // forward SpMM can carry it as a side job (spmm.hip BatchPrep): always in a full step with two or more layers; in a lazy step unless
+  // that first SpMM is the top layer's with a needed-row bitmap, which is derived from the prepared lists (huge graphs, layer 1 kept).
+  const gss_plan_desc &D0 = p->desc;
+  const bool mapped0 = plan_batch_mapped(p);
+  const bool sparse0 = D0.num_layers > 1 && spmm_sparse_available() && p->pos;
+  const bool l0_runs = !(D0.cache_layer1 && p->layer1_valid) && !p->prefetched;
+  const bool host_prep = p->P == 1 && sparse0 && K().prep_side != 0 && idx && b >= 1 && b <= D0.max_batch &&
+                         (l0_runs || !(lazy && p->needbits));
+  BatchPrep prep{idx, b, D0.node_map, p->lo, D0.n, p->gid2op_t, mapped0 ? p->rloc : nullptr, mapped0 ? p->pid : nullptr, p->keep, p->pos, p->rlist};
+  bool prepared = lazy;
+  if (host_prep) {
+    p->prep_pending = &prep;
+    prepared = true;
+    // (a full step: E_B comes out of the top layer's projection through the map the side job sets)
+    p->eb_scatter_b = (!lazy && dense_fwd_norm_available(D0.d)) ? b : 0;
+  }
   if (lazy) {
     GSS_REQUIRE(idx && b >= 1 && b <= p->desc.max_batch, "plan_step_lazy: batch %d out of [1, %d]", b, p->desc.max_batch);
     const bool mapped = plan_batch_mapped(p);   // a relabelled graph and / or a shard: translated ids in rloc / pid (/ keep)
-    {
+    if (!host_prep) {
       PROF(GSS_PROF_ELEMENTWISE);
       if (int rc = batch_prepare(idx, b, p->desc.node_map, p->lo, p->desc.n, p->gid2op_t, mapped ? p->rloc : nullptr, mapped ? p->pid : nullptr,
                                  p->keep, p->pos, stream, p->rlist))
@@ -1239,15 +1268,23 @@ static int plan_step_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta
     // a shard lists the batch members it OWNS (rlist: -1 for the others, whose tile rows compute on row 0's operands and store
     // nothing): every listed row has one writer, no row outside the batch is touched; an empty shard has no top layer to evaluate
     const int32_t *rows = p->rlist ? p->rlist : (mapped ? p->rloc : idx);
-    if (int rc = plan_forward_impl(p, stream, rows, p->desc.n > 0 ? b : 0)) return rc;
-  } else if (int rc = plan_forward_impl(p, stream)) {
-    return rc;
+    const int rc_f = plan_forward_impl(p, stream, rows, p->desc.n > 0 ? b : 0);
+    p->prep_pending = nullptr;
+    p->eb_scatter_b = 0;
+    if (rc_f) return rc_f;
+  } else {
+    const int rc_f = plan_forward_impl(p, stream);
+    const bool hosted = host_prep && p->prep_pending == nullptr;
+    p->prep_pending = nullptr;
+    p->eb_scatter_b = 0;
+    if (rc_f) return rc_f;
+    GSS_REQUIRE(!host_prep || hosted, "plan_step: internal error, no forward SpMM carried the batch preparation");
   }
   if (pipe)  // the side stream starts when this stream reaches the loss kernel (MFMA-bound, 1 MB working set)
     if (int rc = plan_prefetch_layer1(p, stream)) return rc;
   int slices = 0;
   BatchView bv{};
-  if (int rc = plan_loss_backward_impl(p, idx, b, beta, p->wt_valid, stream, bv, &slices, lazy)) return rc;
+  if (int rc = plan_loss_backward_impl(p, idx, b, beta, p->wt_valid, stream, bv, &slices, prepared)) return rc;
   const gss_plan_desc &D = p->desc;
   const bool wt = D.num_layers > 1;
   const bool sparse_top = wt && spmm_sparse_available();

@@ -49,6 +49,8 @@ struct SpmmEpi {
                                 // first pass of a two-pass SPMM_BWD2S, whose second pass carries the same bitmap as posbits)
   const uint32_t *rowbits;      // SPMM_PLAIN, optional: only rows whose bit is set are computed (the first pass of a two-pass SPMM_FWD1
                                 // under a row bitmap, whose second pass carries the same bitmap as posbits)
+  BatchPrep prep;               // SPMM_FWD1, prep.idx != NULL: the launch has one workgroup more than segment blocks (prep_block), which
+  int prep_block;               // prepares the batch (see BatchPrep) instead of multiplying
   int pos_row_limit;            // SPMM_BWD2S, > 0: pos_row is defined for output rows below it only (a shard's own rows; the rows behind
                                 // them -- the boundary rows of the in-place transposed A_hat -- are never batch rows of this shard)
 };
@@ -283,6 +285,24 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   // only ever gathers slice k % pin_ns and its L2 holds 1/pin_ns of the operand
   const int sblk = pin_ns > 0 ? (int)blockIdx.x / pin_ns : (int)blockIdx.x;
   const int sidx = pin_ns > 0 ? (int)blockIdx.x % pin_ns : (int)blockIdx.y;
+  if (MODE == SPMM_FWD1 && ep.prep.idx && sblk >= ep.prep_block) {
+    // the side job (workgroup-uniform branch): batch_prepare_kernel's body for the whole batch
+    if (sidx == 0) {
+      const BatchPrep &q = ep.prep;
+      for (int i = threadIdx.x; i < q.b; i += kBalThreads) {
+        const int id = q.node_map ? q.node_map[q.idx[i]] : q.idx[i];
+        const int rel = id - q.lo;
+        const bool mine = rel >= 0 && rel < q.nl;
+        const int op = q.gid2op ? q.gid2op[id] : (mine ? rel : -1);
+        if (q.rloc) q.rloc[i] = min(max(rel, 0), max(q.nl - 1, 0));
+        if (q.pid) q.pid[i] = op;
+        if (q.keep) q.keep[i] = mine ? 1.f : 0.f;
+        if (q.rlist) q.rlist[i] = mine ? rel : -1;
+        if (op >= 0) q.pos[op] = i;
+      }
+    }
+    return;
+  }
   constexpr int LPR = 1 << LPR_LOG2;
   constexpr int GPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
@@ -567,26 +587,30 @@ int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks
 // with a manual "spmm_slices": slices pinned to XCDs (1) or time-separated (0)   [knob spmm_pin, common.h Knobs]
 
 template <int MODE, int LPR_LOG2, int VPL>
-static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool pin, const float *x, const SpmmEpi &ep, hipStream_t st) {
+static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool pin, const float *x, const SpmmEpi &ep_in, hipStream_t st) {
   const int4 *segs = nullptr;
   int nblk = 0;
   if (int rc = csr_segments(a, 6 - LPR_LOG2, &segs, &nblk)) return rc;
-  if (nblk == 0) return GSS_OK;
+  if (nblk == 0 && !(MODE == SPMM_FWD1 && ep_in.prep.idx)) return GSS_OK;
   CsrView v{a->rowptr, a->col, a->val, a->n_rows};
   const size_t lds = (size_t)kBalWaves * d4_slice * sizeof(float4);
+  SpmmEpi ep = ep_in;
+  const bool prep = MODE == SPMM_FWD1 && ep.prep.idx != nullptr;
+  ep.prep_block = nblk;
+  const int gx = nblk + (prep ? 1 : 0);       // the batch preparation rides as one more workgroup (per slice; slice 0's does the work)
   int3 hot = make_int3(a->hot_own, a->hot_halo0, a->hot_halo1);
   if (K().spmm_hot >= 0) hot = K().spmm_hot > 0 ? make_int3(K().spmm_hot, 0, 0) : make_int3(-1, 0, 0);
   // the hot / cold split pays where the table is far beyond the caches; below that every row is "hot"
   if ((double)a->n_cols * d4_slice * nslices * 16.0 < 256.0 * 1024 * 1024 && K().spmm_hot < 0) hot = make_int3(-1, 0, 0);
   const bool narrow = (double)a->n_cols * d4_slice * nslices * 16.0 < 4.0e9 && a->n_cols < (1 << 24) && hot.x < 0 && K().spmm_fly == 4;
   if (narrow)
-    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, true>), pin ? dim3(nblk * nslices) : dim3(nblk, nslices), dim3(kBalThreads),
+    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, true>), pin ? dim3(gx * nslices) : dim3(gx, nslices), dim3(kBalThreads),
                        lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, make_int3(-1, 0, 0));
   else if (K().spmm_fly == 8)
-    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, false, 8>), pin ? dim3(nblk * nslices) : dim3(nblk, nslices), dim3(kBalThreads),
+    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, false, 8>), pin ? dim3(gx * nslices) : dim3(gx, nslices), dim3(kBalThreads),
                        lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, hot);
   else
-    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, false>), pin ? dim3(nblk * nslices) : dim3(nblk, nslices), dim3(kBalThreads),
+    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, false>), pin ? dim3(gx * nslices) : dim3(gx, nslices), dim3(kBalThreads),
                        lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, hot);
   GSS_LAUNCH_CHECK("spmm_balanced_kernel");
   return GSS_OK;
@@ -644,8 +668,9 @@ static int launch_spmm(const gss_csr *a, int32_t d, const float *x, const SpmmEp
 
 // internal entry points shared with plan.hip
 int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream, const int32_t *row_pos,
-             const uint32_t *row_bits, const float *y_in, const uint32_t *gather_bits) {
+             const uint32_t *row_bits, const float *y_in, const uint32_t *gather_bits, const BatchPrep *prep) {
   GSS_REQUIRE(y, "spmm: y is null");
+  GSS_REQUIRE(!prep || (m && K().spmm_variant == 2 && prep->idx && prep->pos && prep->b > 0), "spmm: the batch-preparation side job goes with the Hadamard-fused product of the balanced SpMM");
   GSS_REQUIRE(!row_pos || (!m && K().spmm_variant == 2), "spmm: a row map goes with the plain product of the balanced SpMM only");
   GSS_REQUIRE(!row_bits || K().spmm_variant == 2, "spmm: a row bitmap needs the balanced SpMM (spmm_variant 2)");
   GSS_REQUIRE((!y_in && !gather_bits) || K().spmm_variant == 2, "spmm: a two-pass product needs the balanced SpMM (spmm_variant 2)");
@@ -654,6 +679,7 @@ int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float 
     GSS_REQUIRE(h, "spmm: m given without h");
     SpmmEpi ep{h, nullptr, nullptr, y, m, 0.f, nullptr, nullptr, row_bits};
     ep.y_in = y_in;
+    if (prep) ep.prep = *prep;
     return launch_spmm<SPMM_FWD1>(a, d, x, ep, stream);
   }
   SpmmEpi ep{nullptr, nullptr, nullptr, y, nullptr, 0.f, row_pos, nullptr, nullptr};
