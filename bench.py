@@ -610,7 +610,7 @@ def main():
         allv = all_ranks(mine)
         # (halo_recompute: layer 2's boundary input rows are computed, not fetched; two layers: the last backward hop runs on A_hat's shard
         #  transposed in place and fetches nothing)
-        tloc = L == 2 and getattr(shard.layout, "a_loc_t", None) is not None and (n < 262144 or engine.lazy_halo_rows()[3] < 0)
+        tloc = L >= 2 and getattr(shard.layout, "a_loc_t", None) is not None and (n < 262144 or engine.lazy_halo_rows()[3] < 0)
         hops_a, hops_t = max(0, 2 * L - 2 - (1 if L > 1 else 0)), max(0, 2 * L - 3 - (1 if tloc else 0))
         # a hop is done when its most loaded pair is: every pair has its own xGMI link (8 GPUs fully connected), so the floor per hop
         # is max over pairs of bytes / link rate; the all-reduces (B d, 2 B d and 2 (d^2 + d) floats) are latency-bound and not priced

@@ -68,7 +68,8 @@ int mark_rows_and_neighbours(const gss_csr *a, const int32_t *rows, int32_t b, u
 int spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax, const float *x_in, const float *ax,
               float *u, float *t, void *stream, const float *y_in = nullptr);
 int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
-              float *dp, float *gx_out, void *stream, const float *y_in = nullptr);
+              float *dp, float *gx_out, void *stream, const float *y_in = nullptr,
+              int32_t own_row_limit = 0);   // > 0: t and res exist for output rows below it only (the in-place transposed shard, plan.hip)
 int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
               const float *b2, const float *p_prev, float decay, float *p, float *x_next, void *stream,
               const int32_t *row_list = nullptr);  // row_list: the n tile rows are node rows row_list[0..n) of every operand; a negative

@@ -419,7 +419,7 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
     //  without the subset exchange of u (RCCL's default).  Where the subset exchange is on, u's few MB are cheaper than the boundary
     //  rows' share of the bottom layer's weight gradient: RMAT 10M, world 8, all ranks on one GPU: 119.6 -> 128.0 ms per step with it)
     const bool tloc_pays = n_global < 262144 || !p->lzt.on;
-    if (p->recompute && desc->num_layers == 2 && shard->a_loc_t && tloc_pays) {
+    if (p->recompute && desc->num_layers >= 2 && shard->a_loc_t && tloc_pays) {
       const gss_csr *t = shard->a_loc_t;
       if (!(t->n_rows == desc->n + ha && t->n_cols == desc->n && t->nnz == a->nnz)) {
         const int r_ = t->n_rows, c_ = t->n_cols;
@@ -1077,11 +1077,15 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
         // touch, own and boundary (T_loc u_own), applies c * (t + .) (.) ELU'(P_0) there (t exists on own rows; P_0 of the boundary
         // rows is what layer 1's projection over own + boundary rows left behind) and sums the weight gradient over own + boundary
         // rows below.  Every (entry, u row) pair is counted once, at the owner of the u row: no exchange.
-        use_tloc = fold_res && lp == 0 && p->tloc != nullptr;
+        use_tloc = lp == 0 && p->tloc != nullptr;
         if (use_tloc) {
           PROF(GSS_PROF_SPMM_BWD2);
-          if (int rc = spmm_bwd2_sparse_res(p->tloc, D.d, p->u, p->t, p->p[0], c, p->dx_b, pos_row, p->dp, nullptr, stream, p->nzbits, nullptr, D.n))
-            return rc;
+          if (fold_res) {
+            if (int rc = spmm_bwd2_sparse_res(p->tloc, D.d, p->u, p->t, p->p[0], c, p->dx_b, pos_row, p->dp, nullptr, stream, p->nzbits, nullptr, D.n))
+              return rc;
+          } else if (int rc = spmm_bwd2(p->tloc, D.d, p->u, p->t, p->p[0], c, res, p->dp, nullptr, stream, nullptr, D.n)) {
+            return rc;    // (deeper nets: the residual of layer 2 lives on own rows; the phase-wise entry points: the batch rows' residual is
+          }               //  scattered onto own rows below)
         } else if (int rc = plan_hop(p, p->halo_t, split_t, p->u, stream, full, own, rest, nullptr, 0, subset ? p->nzbits : nullptr)) {
           return rc;
         }
@@ -1099,7 +1103,8 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
                                           0, p->wgrad_ws, p->wg_total, &wg_n, &n_top, stream))
             return rc;
         } else {
-          if (int rc = wgrad_partial(D.n, D.d, p->dp, p->ax[lp], p->am[lp], nullptr, p->wgrad_ws, p->wg_total, wg_used, &wg_n, stream))
+          const int32_t n_w = use_tloc ? (int32_t)p->rows_a : D.n;
+          if (int rc = wgrad_partial(n_w, D.d, p->dp, p->ax[lp], p->am[lp], nullptr, p->wgrad_ws, p->wg_total, wg_used, &wg_n, stream))
             return rc;
         }
         wg_used += wg_n;

@@ -49,10 +49,10 @@ struct SpmmEpi {
                                 // first pass of a two-pass SPMM_BWD2S, whose second pass carries the same bitmap as posbits)
   const uint32_t *rowbits;      // SPMM_PLAIN, optional: only rows whose bit is set are computed (the first pass of a two-pass SPMM_FWD1
                                 // under a row bitmap, whose second pass carries the same bitmap as posbits)
-  BatchPrep prep;               // SPMM_FWD1, prep.idx != NULL: the launch has one workgroup more than segment blocks (prep_block), which
+  BatchPrep prep;               // SPMM_FWD1, prep.idx != NULL: the launch has one workgroup more than segment blocks -- its first --, which
   int prep_block;               // prepares the batch (see BatchPrep) instead of multiplying
-  int pos_row_limit;            // SPMM_BWD2S, > 0: pos_row is defined for output rows below it only (a shard's own rows; the rows behind
-                                // them -- the boundary rows of the in-place transposed A_hat -- are never batch rows of this shard)
+  int pos_row_limit;            // SPMM_BWD2S / SPMM_BWD2, > 0: t, the residual and pos_row are defined for output rows below it only (a shard's
+                                // own rows; the rows behind them -- the boundary rows of the in-place transposed A_hat -- have none)
 };
 
 struct CsrView {
@@ -154,10 +154,10 @@ __device__ __forceinline__ void row_epilogue(const SpmmEpi &ep, size_t off, floa
     st4(ep.o0 + off, dp);
     if (ep.o1) st4(ep.o1 + off, gx);
   } else {
-    // gx = t + A u ; dp = c * gx (.) elu'(p) (+ res)
-    const float4 gx = add4(ld4(ep.a0 + off), acc);
+    // gx = t + A u ; dp = c * gx (.) elu'(p) (+ res)      (t_zero: a row behind pos_row_limit -- neither t nor a residual there)
+    const float4 gx = t_zero ? acc : add4(ld4(ep.a0 + off), acc);
     float4 dp = scale4(ep.c, mul4(gx, elu_grad4(ld4(ep.a1 + off))));
-    if (ep.a2) dp = add4(dp, ld4(ep.a2 + off));
+    if (ep.a2 && !t_zero) dp = add4(dp, ld4(ep.a2 + off));
     st4(ep.o0 + off, dp);
     if (ep.o1) st4(ep.o1 + off, gx);
   }
@@ -259,7 +259,7 @@ __device__ __forceinline__ long compact_off(const SpmmEpi &ep, int row, int d4, 
 // SPMM_BWD2S with a bitmap: a clear bit says row `row` of t is zero
 template <int MODE>
 __device__ __forceinline__ bool row_t_zero(const SpmmEpi &ep, int row) {
-  if (MODE == SPMM_BWD2S && ep.pos_row_limit > 0 && row >= ep.pos_row_limit) return true;   // a boundary row: t exists on own rows only
+  if ((MODE == SPMM_BWD2S || MODE == SPMM_BWD2) && ep.pos_row_limit > 0 && row >= ep.pos_row_limit) return true;   // a boundary row: t (and the residual) exist on own rows only
   if (MODE != SPMM_BWD2S || !ep.posbits) return false;
   return ((ep.posbits[(unsigned)row >> 5] >> (row & 31)) & 1u) == 0u;
 }
@@ -283,11 +283,15 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   float4 *part = reinterpret_cast<float4 *>(smem);  // [16 waves][d4]
   // pin_ns > 0: 1-D grid, slice = blockIdx.x % pin_ns.  Workgroups go to the XCDs round-robin by linear id, so XCD k
   // only ever gathers slice k % pin_ns and its L2 holds 1/pin_ns of the operand
-  const int sblk = pin_ns > 0 ? (int)blockIdx.x / pin_ns : (int)blockIdx.x;
-  const int sidx = pin_ns > 0 ? (int)blockIdx.x % pin_ns : (int)blockIdx.y;
-  if (MODE == SPMM_FWD1 && ep.prep.idx && sblk >= ep.prep_block) {
+  // (a launch that carries the batch preparation has ONE workgroup more, dispatched FIRST: as the last one it would start when the
+  //  others are about to finish and lengthen the launch by its own chain of loads -- measured +2.9 us on the 31.9 us kernel)
+  const bool has_prep = MODE == SPMM_FWD1 && ep.prep.idx != nullptr;
+  const int bx = (int)blockIdx.x - (has_prep ? 1 : 0);
+  const int sblk = pin_ns > 0 ? bx / pin_ns : bx;
+  const int sidx = pin_ns > 0 ? bx % pin_ns : (int)blockIdx.y;
+  if (has_prep && blockIdx.x == 0) {
     // the side job (workgroup-uniform branch): batch_prepare_kernel's body for the whole batch
-    if (sidx == 0) {
+    if (blockIdx.y == 0) {
       const BatchPrep &q = ep.prep;
       for (int i = threadIdx.x; i < q.b; i += kBalThreads) {
         const int id = q.node_map ? q.node_map[q.idx[i]] : q.idx[i];
@@ -596,21 +600,21 @@ static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool p
   const size_t lds = (size_t)kBalWaves * d4_slice * sizeof(float4);
   SpmmEpi ep = ep_in;
   const bool prep = MODE == SPMM_FWD1 && ep.prep.idx != nullptr;
-  ep.prep_block = nblk;
-  const int gx = nblk + (prep ? 1 : 0);       // the batch preparation rides as one more workgroup (per slice; slice 0's does the work)
+  ep.prep_block = 0;
+  const int extra = prep ? 1 : 0;             // the batch preparation rides as one more workgroup, the first of the launch
   int3 hot = make_int3(a->hot_own, a->hot_halo0, a->hot_halo1);
   if (K().spmm_hot >= 0) hot = K().spmm_hot > 0 ? make_int3(K().spmm_hot, 0, 0) : make_int3(-1, 0, 0);
   // the hot / cold split pays where the table is far beyond the caches; below that every row is "hot"
   if ((double)a->n_cols * d4_slice * nslices * 16.0 < 256.0 * 1024 * 1024 && K().spmm_hot < 0) hot = make_int3(-1, 0, 0);
   const bool narrow = (double)a->n_cols * d4_slice * nslices * 16.0 < 4.0e9 && a->n_cols < (1 << 24) && hot.x < 0 && K().spmm_fly == 4;
   if (narrow)
-    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, true>), pin ? dim3(gx * nslices) : dim3(gx, nslices), dim3(kBalThreads),
+    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, true>), pin ? dim3(nblk * nslices + extra) : dim3(nblk + extra, nslices), dim3(kBalThreads),
                        lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, make_int3(-1, 0, 0));
   else if (K().spmm_fly == 8)
-    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, false, 8>), pin ? dim3(gx * nslices) : dim3(gx, nslices), dim3(kBalThreads),
+    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, false, 8>), pin ? dim3(nblk * nslices + extra) : dim3(nblk + extra, nslices), dim3(kBalThreads),
                        lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, hot);
   else
-    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, false>), pin ? dim3(gx * nslices) : dim3(gx, nslices), dim3(kBalThreads),
+    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, false>), pin ? dim3(nblk * nslices + extra) : dim3(nblk + extra, nslices), dim3(kBalThreads),
                        lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, hot);
   GSS_LAUNCH_CHECK("spmm_balanced_kernel");
   return GSS_OK;
@@ -745,11 +749,13 @@ int mark_rows_and_neighbours(const gss_csr *a, const int32_t *rows, int32_t b, u
 }
 
 int spmm_bwd2(const gss_csr *at, int32_t d, const float *u, const float *t, const float *p, float c, const float *res,
-              float *dp, float *gx_out, void *stream, const float *y_in) {
+              float *dp, float *gx_out, void *stream, const float *y_in, int32_t own_row_limit) {
   GSS_REQUIRE(u && t && p && dp, "spmm_bwd2: null operand");
   GSS_REQUIRE(!y_in || K().spmm_variant == 2, "spmm_bwd2: a two-pass product needs the balanced SpMM (spmm_variant 2)");
   SpmmEpi ep{t, p, res, dp, gx_out, c, nullptr, nullptr, nullptr, nullptr};
   ep.y_in = y_in;
+  ep.pos_row_limit = own_row_limit;
+  GSS_REQUIRE(own_row_limit == 0 || K().spmm_variant == 2, "spmm_bwd2: a row limit needs the balanced SpMM (spmm_variant 2)");
   return launch_spmm<SPMM_BWD2>(at, d, u, ep, stream);
 }
 

@@ -15,7 +15,7 @@ the data layout and the order of the exchange points, line by line:
   ONE batch collective: [E_B | P_B | inv_B] = sum over shards of (own rows | 0)                           C3, plan_loss_backward_impl
   batch maps: rloc / keep / pid = gid2op_t[node_map[idx]]                 loss.hip gather_batch_kernel
   finish + input gradient of EVERY member on every rank (no second collective), sparse first hop         loss.hip tail, plan_backward_impl
-  halo of u (A_hat^T's halo) before every second hop -- except the LAST one at two layers, which runs in scatter-by-owner form over
+  halo of u (A_hat^T's halo) before every second hop -- except the LAST one (the bottom layer's), which runs in scatter-by-owner form over
       A_hat's shard transposed in place (gss_shard_desc.a_loc_t): no exchange                           plan_backward_impl (use_tloc)
   four weight gradients summed over the shards, then Adam                 plan_step_impl (P > 1 branch)
 
@@ -61,7 +61,7 @@ class ShardStepMirror:
         self.slab = slab and self.P > 1                 # knob loss_slab (automatic: batches of >= 8192 rows)
         # gss_shard_desc.a_loc_t: A_hat's shard transposed in place -- two layers + halo_recompute: the last backward hop without an exchange
         t_loc = getattr(lay, "a_loc_t", None)
-        self.tloc = t_loc.m if (t_loc is not None and self.recompute and self.L == 2) else None
+        self.tloc = t_loc.m if (t_loc is not None and self.recompute and self.L >= 2) else None
         self.ax0op = self.am0op = None
         self.loss = None
         self.emb = None
@@ -233,7 +233,9 @@ class ShardStepMirror:
                     g_ext = self.tloc @ u_own.astype(np.float64)
                     g_ext[:n] += t.astype(np.float64)
                     dp_ext = c * g_ext * _elu_grad(lay["p_op"].astype(np.float64))
-                    if n > 0:
+                    if lp + 2 <= L - 1:                                # deeper nets: the residual gradient of layer lp + 2 lives on own rows
+                        dp_ext[:n] += gx[(lp + 2) & 1]
+                    if lp + 2 == L and n > 0:
                         np.add.at(dp_ext, rloc[mine], dx_b[mine].astype(np.float64))
                     assert dp_ext.shape[0] == rows_a
                     wgrad(_f32(dp_ext), self.ax0op, self.am0op)

@@ -108,10 +108,10 @@ def test_product_shards_as_gloo_processes_match_reference_trajectory(tmp_path, w
         assert np.abs(outs[0][k] - g["final_" + k]).max() < T.TRAJ_WEIGHT_LR * float(g["lr"])
     # what the step moves is what the halo layout announces (include/gssgcn.h, gss_plan_create_sharded): per step 2L - 2 exchanges of
     # A_hat's halo -- one less with halo_recompute (these graphs: layer 2's boundary input rows are computed, not fetched) -- + 2L - 3
-    # of A_hat^T's (none at two layers: gss_shard_desc.a_loc_t); the first step also fetches the constant boundary rows of X_0 and M_0 and, with halo_recompute, of AX_0 and AM_0
+    # of A_hat^T's, less the last one (gss_shard_desc.a_loc_t); the first step also fetches the constant boundary rows of X_0 and M_0 and, with halo_recompute, of AX_0 and AM_0
     rec = 1 if L > 1 else 0
     hops_a = 2 * L - 2 - rec
-    hops_t = max(0, 2 * L - 3) - (1 if L == 2 else 0)      # two layers: the last backward hop runs on A_hat's shard transposed in place
+    hops_t = max(0, 2 * L - 3) - (1 if L >= 2 else 0)      # the last backward hop runs on A_hat's shard transposed in place: no exchange
     steady = hops_a + hops_t
     for o in outs:
         assert o["ex"][0] == steady + 2 + 2 * rec and all(int(e) == steady for e in o["ex"][1:])

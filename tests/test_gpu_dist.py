@@ -641,7 +641,7 @@ def test_sharded_step_enqueues_the_announced_collectives(world, case, recompute,
     assert not errors, errors
     rec = 1 if (recompute != 0 and L > 1) else 0
     tail = d in (64, 128, 256)
-    tloc = 1 if (rec and L == 2) else 0          # two layers: the last backward hop on A_hat's shard transposed in place, no exchange of u
+    tloc = 1 if (rec and L >= 2) else 0          # the last backward hop on A_hat's shard transposed in place, no exchange of u
     steady = ((2 * L - 2 - rec) + max(0, 2 * L - 3) - tloc, (1 if (tail or L == 1) else 2) + (1 if slab == 1 else 0), 1)
     for res in results:
         for k, (loss, emb, stats) in enumerate(res):
