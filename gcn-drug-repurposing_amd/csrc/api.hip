@@ -124,7 +124,8 @@ int gss_debug_set_option(const char *name, int value) {
     return GSS_OK;
   }
   if (strcmp(name, "loss_dgrad") == 0) {
-    g_knobs.loss_dgrad = value ? 1 : 0;
+    GSS_REQUIRE(value >= -1 && value <= 1, "loss_dgrad must be -1 (shards only), 0 or 1");
+    g_knobs.loss_dgrad = value;
     return GSS_OK;
   }
   if (strcmp(name, "prep_side") == 0) {

@@ -41,7 +41,8 @@ struct Knobs {
   int gemm_lds_kb = 0, wgrad_lds_kb = 0, loss_lds_kb = 0;
   int lazy_halo = -1;        // sharded lazy step: fetch only the boundary rows of the top layer's M that the batch rows read (-1 = graphs of >= 262,144 nodes, 0 = never, 1 = always)
   int ppr_fused = 1;         // diffusion profiles: the update and the column errors in the SpMM's epilogue (0 = separate update pass)
-  int loss_dgrad = 1;        // finish + normalise' / ELU' + the batch rows' input gradient in one launch (0 = two launches); d in {64, 128, 256}
+  int loss_dgrad = -1;       // finish + normalise' / ELU' + the batch rows' input gradient in one launch, d in {64, 128, 256}: -1 = on shards only
+                             // (it spares a collective there; on one GPU two launches are 1.9 us faster), 0 = never, 1 = always
   int prep_side = 1;         // one GPU: a step's batch preparation as a side job of its first forward SpMM, E_B out of the top layer's projection
                              // (0 = the launches of their own: batch_prepare in lazy steps, the gather in full steps)
   int loss_slab = -1;        // sharded plans: the B x B loss sweep as row slabs (rank r: i tiles r, r + P, ...) + one more all-reduce, instead of

@@ -763,11 +763,14 @@ int loss_fused_gathered(int32_t d, int32_t b, float beta, float alpha, float *lo
   return loss_step(s, ws, stream, &dgrad_done);
 }
 
-// debug knob "loss_dgrad": 1 (default) = finish + the batch rows' input gradient in one launch (loss_finish_dgrad_kernel), 0 = two
-bool loss_dgrad_available(int32_t d, int32_t b) {
+// debug knob "loss_dgrad": finish + the batch rows' input gradient in one launch (loss_finish_dgrad_kernel): -1 (default) = on a shard
+// only -- there it is what spares the second batch all-reduce; on one GPU the two stand-alone launches are 1.9 us faster (in-process
+// A/B, tools/ab_inproc.py: 0.3043 vs 0.3063 ms per step) --, 0 = never, 1 = always
+bool loss_dgrad_available(int32_t d, int32_t b, bool sharded) {
   int ni, js, nz, ng;
   loss_geometry(b, d, ni, js, nz, ng);
-  return K().loss_dgrad != 0 && d == 64 * ng && nz == 1 && ng <= 4;
+  const int knob = K().loss_dgrad;
+  return (knob == 1 || (knob < 0 && sharded)) && d == 64 * ng && nz == 1 && ng <= 4;
 }
 
 // Row-slab form of the sweep for a shard (LossStep.slab_parts > 1), first half: this rank's i tiles (rank, rank + parts, ...), then
@@ -810,7 +813,7 @@ int loss_step(const LossStep &s, void *ws, void *stream, bool *dgrad_done) {
   const int32_t *pos_ids = s.pos_ids ? s.pos_ids : s.rows;
   const int nloss = s.de_x ? 0 : L.ni * L.js;      // loss partials for the finish to sum (none: the loss came with de_x)
   *dgrad_done = false;
-  if (s.w1t && loss_dgrad_available(d, b)) {
+  if (s.w1t) {   // (the caller asked loss_dgrad_available before it handed the weights over)
     FinishDgrad T{b, d, L.js, nloss, L.de_part, L.loss_part, s.alpha, e_b, s.rows, pos_ids, s.pos_set, s.keep, s.inv_den, s.p, s.c,
                   s.dx_b, s.dp_b, s.loss_out, s.w1t, s.w2t, s.gax_b, s.gam_b, s.dgrad_all ? 1 : 0};
     dim3 grid(L.ni), block(256);

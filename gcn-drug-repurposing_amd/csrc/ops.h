@@ -176,7 +176,7 @@ struct LossStep {
 };
 int loss_step(const LossStep &s, void *ws, void *stream, bool *dgrad_done);
 int loss_step_slab_sweep(const LossStep &s, void *ws, float *de_x, void *stream);
-bool loss_dgrad_available(int32_t d, int32_t b);
+bool loss_dgrad_available(int32_t d, int32_t b, bool sharded);
 int transpose2(int32_t dim, const float *a, const float *b, float *at, float *bt, void *stream);
 size_t loss_workspace_bytes(int32_t b, int32_t d, int parts = 1);
 size_t loss_workspace_bytes_max(int32_t b_max, int32_t d, int parts = 1);   // enough for every batch of 1..b_max rows (the size is not monotone in b);

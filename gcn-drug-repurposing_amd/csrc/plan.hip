@@ -862,7 +862,7 @@ int plan_loss_backward_impl(gss_plan *p, const int32_t *idx, int32_t b, float be
   GSS_REQUIRE(p->P == 1 || L == 1 || sparse_top, "a sharded plan needs the balanced SpMM (spmm_variant 2)");
   const bool mapped = plan_batch_mapped(p);
   // the batch rows' input gradient shares the launch of the loss's finish where the width allows: it needs the transposed weights now
-  const bool want_dgrad = sparse_top && loss_dgrad_available(D.d, b);
+  const bool want_dgrad = sparse_top && loss_dgrad_available(D.d, b, p->P > 1);
   if (want_dgrad && !wt_ok) {
     PROF(GSS_PROF_ELEMENTWISE);
     if (int rc = transpose2(D.d, p->w1, p->w2, p->w1t, p->w2t, stream)) return rc;

@@ -466,8 +466,8 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
  * by four waves per 16 rows that split the features / by one wave; "lazy_halo" = -1 (default: graphs of >= 262,144 nodes) / 0 / 1: sharded plans fetch subsets of the
  * boundary rows where a hop reads a subset (gss_plan_lazy_halo_rows; every rank of a job must use the same value; over RCCL the
  * automatic choice is "never" until a multi-GPU run has priced its host round trip); "halo_recompute" = -1 (default: on) / 0 / 1: sharded plans recompute layer 2's boundary input rows from layer 1's constant AX / AM (fetched once)
- * instead of exchanging them every step (same bits; every rank of a job must use the same value); "loss_dgrad" = 1 (default) / 0: the
- * loss finish and the batch rows' input gradient in one launch / in two (same bits); "prep_side" = 1 (default) / 0: on one GPU a step's batch preparation rides in its
+ * instead of exchanging them every step (same bits; every rank of a job must use the same value); "loss_dgrad" = -1 (default: on shards only) / 0 / 1: the
+ * loss finish and the batch rows' input gradient in one launch instead of two (same bits; on a shard it spares a collective); "prep_side" = 1 (default) / 0: on one GPU a step's batch preparation rides in its
  * first forward SpMM launch and E_B comes out of the top layer's projection (no batch_prepare / gather launch; same bits);
  * "loss_slab" = -1 (default: batches of >= 8192
  * rows) / 0 / 1: sharded plans sweep the B x B loss as row slabs (rank r the i tiles r, r + P, ...; one more all-reduce of B d + 1
