@@ -1,0 +1,3 @@
+for spec in "loss_wgs 256 192" "loss_wgs 256 320" "loss_wgs 256 512" "wgrad_wgs 256 192" "wgrad_wgs 256 320" "wgrad_wgs 256 384" "gemm_small_nt 2 1" "gemm_small_nt 2 4" "gemm_small_nt 2 0" "xcd_remap 1 0" "spmm_fly 4 8" "gemm_variant 2 3" "wgrad_variant 1 2" "spmm_slices 0 2" "spmm_slices 0 4"; do
+  python3 tools/ab_inproc.py $spec full 8 200 2>&1 | grep -E "difference|mean" | grep -v amdgpu
+done
