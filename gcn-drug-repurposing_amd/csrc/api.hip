@@ -105,6 +105,10 @@ int gss_debug_set_option(const char *name, int value) {
     g_knobs.wgrad_variant = value;
     return GSS_OK;
   }
+  if (strcmp(name, "gemm_hoist") == 0) {
+    g_knobs.gemm_hoist = value ? 1 : 0;
+    return GSS_OK;
+  }
   if (strcmp(name, "gemm_stagger") == 0) {
     GSS_REQUIRE(value >= 0 && value <= 256, "gemm_stagger must be in [0, 256] (units of 512 cycles)");
     g_knobs.gemm_stagger = value;

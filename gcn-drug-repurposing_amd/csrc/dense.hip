@@ -50,6 +50,7 @@ struct GemmArgs {
                         // tile rows are the batch positions, so this IS E_B = emb[idx] (model.py:216-217) without a gather launch
   int xcd_remap;        // renumber the workgroups so that those sharing input rows sit on one XCD (xcd_ids below)
   int prio_cut;         // > 0: workgroups whose linear id is below it raise their wave priority (debug knob "gemm_prio")
+  int hoist;            // the epilogue's operands are requested ahead of the K loop (knob "gemm_hoist", default 1)
   int stagger;          // > 0: workgroups of the second generation (linear id >= 256) start this many x 512 cycles late (knob "gemm_stagger")
   unsigned long long *stamps;  // diagnostic (gss_debug_set_stamp_buffer, NULL in production): per wave {start, loop begin, loop end, end} in
                                // 100 MHz wall-clock ticks + {linear workgroup id, HW_ID}; tools/gemm_stamps.py reads it
@@ -158,31 +159,48 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 // in acc[u].  All loads (biases, previous layer's P) are issued before the first store: the stores may alias them as
 // far as the compiler knows, so a load placed after a store waits for that store (vmcnt counts both) -- written the
 // naive way this was 3 NT serialised memory round trips per tile and most of the kernel's time.
+// What the epilogue reads besides the accumulators -- biases, the previous layer's P, the batch-position map --, fetched AHEAD of the K
+// loop (round 4): none of it depends on the loop, and at its end it used to be one more dependent round trip (~1 us with the L2s cold)
+// in front of the exp / store phase that every workgroup of the launch enters at the same time.  The K loop's counted vmcnt waits stay
+// sound: these loads are older than every LDS-DMA load and loads return in order.
+template <int NT>
+struct FwdPre {
+  float4 bb[NT], pp[NT];
+  int ndc, out_row;
+  bool live;
+};
 template <int NT, int EPI>
-__device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&acc)[NT], int nd, int j0, int q) {
-  bool live = nd < g.n;
-  int ndc = min(nd, g.n - 1);
+__device__ __forceinline__ void fwd_prefetch(const GemmArgs &g, int nd, int j0, int q, FwdPre<NT> &f) {
+  f.live = nd < g.n;
+  f.ndc = min(nd, g.n - 1);
   if (g.rows) {   // forward over a row list (gss_plan_step_lazy): tile row -> node row, inputs and outputs alike
-    ndc = g.rows[ndc];
-    if (ndc < 0) {   // a batch member another shard owns: computed from row 0's operands, never stored
-      live = false;
-      ndc = 0;
+    f.ndc = g.rows[f.ndc];
+    if (f.ndc < 0) {   // a batch member another shard owns: computed from row 0's operands, never stored
+      f.live = false;
+      f.ndc = 0;
     }
   }
-  float4 bb[NT], pp[NT];
 #pragma unroll
   for (int u = 0; u < NT; ++u) {
     const int j = j0 + 16 * u + 4 * q;
-    bb[u] = add4(ld4(g.b1 + j), ld4(g.b2 + j));
-    pp[u] = g.p_prev ? ld4(g.p_prev + (size_t)ndc * g.ld_out0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    f.bb[u] = add4(ld4(g.b1 + j), ld4(g.b2 + j));
+    f.pp[u] = g.p_prev ? ld4(g.p_prev + (size_t)f.ndc * g.ld_out0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // E_B (EPI_FWD_NORM, rows_out): with a row list the tile rows are the batch positions; without one the position comes from the map
+  f.out_row = -1;
+  if (EPI == EPI_FWD_NORM && g.rows_out) f.out_row = g.rows_out_pos ? g.rows_out_pos[f.ndc] : nd;
+}
+
+template <int NT, int EPI>
+__device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&acc)[NT], const FwdPre<NT> &f, int j0, int q) {
+  const int ndc = f.ndc;
   float4 pv[NT], o[NT];
   float ss = 0.f;
 #pragma unroll
   for (int u = 0; u < NT; ++u) {
-    pv[u] = add4(make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]), bb[u]);
+    pv[u] = add4(make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]), f.bb[u]);
     o[u] = make_float4(elu1(pv[u].x), elu1(pv[u].y), elu1(pv[u].z), elu1(pv[u].w));
-    if (g.p_prev) o[u] = add4(pp[u], scale4(g.decay, o[u]));
+    if (g.p_prev) o[u] = add4(f.pp[u], scale4(g.decay, o[u]));
     ss += o[u].x * o[u].x + o[u].y * o[u].y + o[u].z * o[u].z + o[u].w * o[u].w;
   }
   float inv = 1.f;
@@ -193,10 +211,8 @@ __device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&ac
     ss += __shfl_xor(ss, 32, 64);
     inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
   }
-  if (!live) return;
-  // E_B (EPI_FWD_NORM, rows_out): with a row list the tile rows are the batch positions; without one the position comes from the map
-  int out_row = -1;
-  if (EPI == EPI_FWD_NORM && g.rows_out) out_row = g.rows_out_pos ? g.rows_out_pos[ndc] : nd;
+  if (!f.live) return;
+  const int out_row = f.out_row;
 #pragma unroll
   for (int u = 0; u < NT; ++u) {
     const size_t off = (size_t)ndc * g.ld_out0 + j0 + 16 * u + 4 * q;   // ndc == nd for a live row without a row list
@@ -205,6 +221,14 @@ __device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&ac
     if (EPI == EPI_FWD_NORM && g.rows_out && out_row >= 0) st4(g.rows_out + (size_t)out_row * g.ld_out0 + j0 + 16 * u + 4 * q, scale4(inv, o[u]));
   }
   if (EPI == EPI_FWD_NORM && q == 0) g.inv_den[ndc] = inv;
+}
+
+// (the stand-alone form: everything fetched right in front of the arithmetic -- kernels that do not hoist it)
+template <int NT, int EPI>
+__device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&acc)[NT], int nd, int j0, int q) {
+  FwdPre<NT> f;
+  fwd_prefetch<NT, EPI>(g, nd, j0, q, f);
+  fwd_epilogue<NT, EPI>(g, acc, f, j0, q);
 }
 
 // ---- LDS-staged variant (default) -----------------------------------------------------------------------
@@ -344,6 +368,11 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
 #pragma unroll
     for (int u = 0; u < NT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // the epilogue's own operands, requested before the first chunk (one 16-node tile per wave; with two the registers are better spent)
+  constexpr bool HOIST = EPI != EPI_SPLIT && MT == 1;
+  FwdPre<NT> pre;
+  if (HOIST && g.hoist) fwd_prefetch<NT, EPI>(g, node_base + 16 * (MT * w) + r, j0, q, pre);
+
   for (int c = 0; c < PF && c < nchunk; ++c) stage(c);
   if (STAMP && stamp && lane == 0) stamp[1] = wall_clock64();
   for (int ci = 0; ci < nchunk; ++ci) {
@@ -395,6 +424,9 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
         else
           st4(g.out1 + (size_t)orow * g.ld_out1 + (j - g.jsplit), v);
       }
+    } else if (HOIST) {
+      if (!g.hoist) fwd_prefetch<NT, EPI>(g, nd, j0, q, pre);      // (knob gemm_hoist = 0: fetched here, as until round 4)
+      fwd_epilogue<NT, EPI>(g, acc[t], pre, j0, q);
     } else {
       fwd_epilogue<NT, EPI>(g, acc[t], nd, j0, q);
     }
@@ -450,6 +482,9 @@ __global__ __launch_bounds__(256) void gemm_rows_split_kernel(GemmArgs g) {
   f32x4 acc[NTW];
 #pragma unroll
   for (int u = 0; u < NTW; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // wave 0 runs the whole row's epilogue: its operands are requested now (see FwdPre)
+  FwdPre<NT> pre;
+  if (w == 0 && g.hoist) fwd_prefetch<NT, EPI>(g, node_base + r, 0, q, pre);
   for (int c = 0; c < PF && c < nchunk; ++c) stage(c);
   for (int ci = 0; ci < nchunk; ++ci) {
     const int younger = min(PF - 1, nchunk - 1 - ci);
@@ -490,7 +525,8 @@ __global__ __launch_bounds__(256) void gemm_rows_split_kernel(GemmArgs g) {
     const float4 v = dump[u * 64 + lane];
     row[u] = (f32x4){v.x, v.y, v.z, v.w};
   }
-  fwd_epilogue<NT, EPI>(g, row, node_base + r, 0, q);
+  if (!g.hoist) fwd_prefetch<NT, EPI>(g, node_base + r, 0, q, pre);
+  fwd_epilogue<NT, EPI>(g, row, pre, 0, q);
 }
 
 // Measured dead end, for the record: a weights-resident variant for d <= 128 ([W1|W2] = 128 KB DMA'd into LDS once per
@@ -521,6 +557,7 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
   g.xcd_remap = K().xcd_remap;
   g.prio_cut = K().gemm_prio;
   g.stagger = K().gemm_stagger;
+  g.hoist = K().gemm_hoist;
   g.stamps = g_gemm_stamps;
   if (K().gemm_variant >= 2) {
     int nt = (d % 128 == 0) ? 8 : (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
