@@ -105,6 +105,10 @@ int gss_debug_set_option(const char *name, int value) {
     g_knobs.wgrad_variant = value;
     return GSS_OK;
   }
+  if (strcmp(name, "wgrad_deep") == 0) {
+    g_knobs.wgrad_deep = value ? 1 : 0;
+    return GSS_OK;
+  }
   if (strcmp(name, "gemm_hoist") == 0) {
     g_knobs.gemm_hoist = value ? 1 : 0;
     return GSS_OK;

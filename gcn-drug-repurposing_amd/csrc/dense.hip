@@ -975,7 +975,7 @@ __device__ __forceinline__ float adam_update(float p, float g, float &m, float &
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int d, int nslices, const float *__restrict__ part_w,
                                                             const float *__restrict__ part_b, float *__restrict__ gw1,
                                                             float *__restrict__ gw2, float *__restrict__ gb, float *__restrict__ gb2,
-                                                            int accumulate, FusedAdam ad) {
+                                                            int accumulate, FusedAdam ad, int deep) {
   // 64 consecutive outputs per workgroup; wave w sums slices w, w+4, ... (4 loads in flight), LDS adds the 4
   // wave sums in wave order -> fixed summation order
   __shared__ float red[4][64];
@@ -984,10 +984,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int d, int nslices, c
   const int nw = d * 2 * d;
   const int total = nw + d;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  // (round 4) the launch is a chain of dependent round trips around 33 MB of partial slabs: Adam's state of this output is requested
+  // first (it does not depend on the sums), and the slabs are fetched eight at a time instead of four -- added in the same order
+  float am0 = 0.f, av0 = 0.f, ap0 = 0.f;
+  const bool adam_w = deep && ad.enabled && w == 0 && idx < nw;
+  if (adam_w) {
+    const int f = idx / (2 * d), k = idx % (2 * d);
+    const int which = k < d ? 0 : 2;
+    const size_t e = (size_t)f * d + (k < d ? k : k - d);
+    am0 = ad.m[which][e];
+    av0 = ad.v[which][e];
+    ap0 = ad.param[which][e];
+  }
   if (idx < total) {
     const float *src = idx < nw ? part_w + idx : part_b + (idx - nw);
     const size_t stride = idx < nw ? (size_t)nw : (size_t)d;
     int sl = w;
+    for (; deep && sl + 28 < nslices; sl += 32) {
+      const float a0 = src[(size_t)sl * stride], a1 = src[(size_t)(sl + 4) * stride], a2 = src[(size_t)(sl + 8) * stride],
+                  a3 = src[(size_t)(sl + 12) * stride], a4 = src[(size_t)(sl + 16) * stride], a5 = src[(size_t)(sl + 20) * stride],
+                  a6 = src[(size_t)(sl + 24) * stride], a7 = src[(size_t)(sl + 28) * stride];
+      s0 += a0;
+      s1 += a1;
+      s2 += a2;
+      s3 += a3;
+      s0 += a4;
+      s1 += a5;
+      s2 += a6;
+      s3 += a7;
+    }
     for (; sl + 12 < nslices; sl += 16) {
       s0 += src[(size_t)sl * stride];
       s1 += src[(size_t)(sl + 4) * stride];
@@ -1008,8 +1033,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int d, int nslices, c
       const float gval = accumulate ? *dst + s : s;
       *dst = gval;
       if (ad.enabled) {  // torch.optim.Adam on this element, in the same launch (train.py:184)
-        float m = ad.m[which][e], v = ad.v[which][e];
-        const float pn = adam_update(ad.param[which][e], gval, m, v, ad);
+        float m = deep ? am0 : ad.m[which][e], v = deep ? av0 : ad.v[which][e];
+        const float pn = adam_update(deep ? ap0 : ad.param[which][e], gval, m, v, ad);
         ad.m[which][e] = m;
         ad.v[which][e] = v;
         ad.param[which][e] = pn;
@@ -1129,7 +1154,7 @@ static int wgrad_reduce_launch(int32_t d, void *ws, int total_slices, int nslice
   int nblk = ceil_div((int64_t)d * 2 * d + d, 64);
   if (ad.enabled && ad.pos_clear) nblk = std::max(nblk, ceil_div(ad.b, 256));
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), d, nslices, pw, pb, gw1, gw2, gb, gb2,
-                     accumulate, ad);
+                     accumulate, ad, K().wgrad_deep);
   GSS_LAUNCH_CHECK("wgrad_reduce_kernel");
   return GSS_OK;
 }
