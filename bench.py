@@ -572,16 +572,18 @@ def main():
                                                   if prof.get(k, (0, 0))[1] and class_us(k)}
         # fp32-MFMA kernels: achieved TFLOP/s against the 157.3 TF dense fp32-matrix peak
         mf = {}
+        dgrad_own = prof.get("dgrad", (0, 0))[1] > 0     # one GPU: finish and input gradient are two launches (knob loss_dgrad)
         for cls, name, fl in (("dense_fwd", "projection (gemm_nt)", 2.0 * n * (2 * d) * d),
                               ("wgrad", "weight gradients (wgrad_tn: L - 1 launches over N rows, the top layer's B rows merged into the first)",
                                2.0 * (n * (L - 1) + B) * d * (2 * d)),
-                              ("loss", "loss: sweep with the gather in its prologue and finish + batch-row input gradient in its tail, 4 B^2 d + 4 B d^2",
-                               4.0 * B * B * d + 4.0 * B * d * d)):
+                              ("loss", ("loss: B x B sweep + finish (two launches), 4 B^2 d; the batch rows' input gradient is a launch of its own (class dgrad)"
+                                        if dgrad_own else "loss: B x B sweep + finish with the batch rows' input gradient in the same launch, 4 B^2 d + 4 B d^2"),
+                               4.0 * B * B * d + (0.0 if dgrad_own else 4.0 * B * d * d))):
             cnt = prof[cls][1]
             if not cnt or class_us(cls) is None:
                 continue
             per_step = cnt / args.steps
-            # several launches of a class per step (L projections; L - 1 full weight gradients; the loss's three launches): flops of all
+            # several launches of a class per step (L projections; L - 1 full weight gradients; the loss's two launches): flops of all
             # of them over the time of all of them
             mult = {"dense_fwd": L, "wgrad": 1, "loss": 1}[cls]
             t = class_us(cls) * 1e-6 * per_step

@@ -106,7 +106,7 @@ int gss_debug_set_option(const char *name, int value) {
     return GSS_OK;
   }
   if (strcmp(name, "wgrad_deep") == 0) {
-    g_knobs.wgrad_deep = value ? 1 : 0;
+    g_knobs.wgrad_deep = value < 0 ? 0 : (value > 2 ? 2 : value);
     return GSS_OK;
   }
   if (strcmp(name, "gemm_hoist") == 0) {

@@ -987,6 +987,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int d, int nslices, c
   // (round 4) the launch is a chain of dependent round trips around 33 MB of partial slabs: Adam's state of this output is requested
   // first (it does not depend on the sums), and the slabs are fetched eight at a time instead of four -- added in the same order
   float am0 = 0.f, av0 = 0.f, ap0 = 0.f;
+  int clear_id = -1;
+  if (deep && ad.enabled && ad.pos_clear && blockIdx.x * 256 + threadIdx.x < ad.b) clear_id = ad.idx[blockIdx.x * 256 + threadIdx.x];
   const bool adam_w = deep && ad.enabled && w == 0 && idx < nw;
   if (adam_w) {
     const int f = idx / (2 * d), k = idx % (2 * d);
@@ -1000,6 +1002,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int d, int nslices, c
     const float *src = idx < nw ? part_w + idx : part_b + (idx - nw);
     const size_t stride = idx < nw ? (size_t)nw : (size_t)d;
     int sl = w;
+    for (; deep >= 2 && sl + 60 < nslices; sl += 64) {   // sixteen at a time: one round trip for the 64 slabs of config 2
+      float a[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a[j] = src[(size_t)(sl + 4 * j) * stride];
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) {
+        s0 += a[j];
+        s1 += a[j + 1];
+        s2 += a[j + 2];
+        s3 += a[j + 3];
+      }
+    }
     for (; deep && sl + 28 < nslices; sl += 32) {
       const float a0 = src[(size_t)sl * stride], a1 = src[(size_t)(sl + 4) * stride], a2 = src[(size_t)(sl + 8) * stride],
                   a3 = src[(size_t)(sl + 12) * stride], a4 = src[(size_t)(sl + 16) * stride], a5 = src[(size_t)(sl + 20) * stride],
@@ -1058,7 +1072,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int d, int nslices, c
     }
   }
   // reset the batch-position map for the next step (it was last read by the backward SpMM before this kernel)
-  if (ad.enabled && ad.pos_clear) {
+  if (clear_id >= 0) ad.pos_clear[clear_id] = -1;
+  else if (!deep && ad.enabled && ad.pos_clear) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < ad.b) ad.pos_clear[ad.idx[i]] = -1;
   }
