@@ -44,4 +44,8 @@ for blk in range(blocks):
 for k, v in enumerate((va, vb)):
     a = np.array(t[k])
     print(f"{knob}={v} ({mode} step): mean {a.mean():.4f} ms, median {np.median(a):.4f}, min {a.min():.4f}, max {a.max():.4f} over {blocks} blocks of {steps} steps; loss {engs[k].loss.item():.8f}")
+for e in engs:
+    e.forward()
+torch.cuda.synchronize()
+print("embeddings of the two plans after the same steps bit-identical:", bool(torch.equal(engs[0].emb, engs[1].emb)))
 print(f"difference of the means: {(np.mean(t[0]) - np.mean(t[1])) * 1e3:+.2f} us per step ({knob}={va} minus {knob}={vb})")
