@@ -20,6 +20,9 @@ n = adj.shape[0]
 X = np.random.RandomState(2).randn(n, d).astype(np.float32)
 w = np.random.RandomState(7).randn(d, d) * 1e-5; np.fill_diagonal(w, 1.0)
 p = {"W1": w.astype(np.float32), "b1": np.zeros(d, np.float32), "W2": w.astype(np.float32).copy(), "b2": np.zeros(d, np.float32)}
+for kv in filter(None, os.environ.get("GSS_AB_FIXED", "").split(",")):      # knobs held fixed for both plans, e.g. GSS_AB_FIXED=spmm_pin=1
+    name, _, val = kv.partition("=")
+    assert lib.gss_debug_set_option(name.encode(), int(val)) == 0, kv
 comm = local_comms(1)[0]
 shard = build_shard(ScipySource(adj), comm, need_transpose=True)
 engs = []
