@@ -168,9 +168,131 @@ struct FwdPre {
   float4 bb[NT], pp[NT];
   int ndc, out_row;
   bool live;
+  // whole-line form (GemmArgs::lines): the lane serves TWO rows (ndc, ndc1), NT / 2 column blocks each -- bb[m] their biases,
+  // pp[m] / pp[NT / 2 + m] the previous layer's P of the first / second row
+  int ndc1, out_row1;
+  bool live1;
 };
+
+// x^2 + y^2 + z^2 + w^2 in ONE stated order (no contraction left to the compiler): both forms of the epilogue add a row's squares
+// through it, block by block, so that F.normalize gives the same bits whichever form wrote the row
+__device__ __forceinline__ float sumsq4(const float4 &o) { return __fmaf_rn(o.w, o.w, __fmaf_rn(o.z, o.z, __fmaf_rn(o.y, o.y, __fmul_rn(o.x, o.x)))); }
+__device__ __forceinline__ float swap_neighbour(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }
+
+// lanes 2k and 2k + 1 exchange a float4 (DPP quad_perm [1, 0, 3, 2]: no LDS)
+__device__ __forceinline__ float4 swap_neighbour(const float4 &v) {
+  float4 o;
+  o.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.x), 0xB1, 0xF, 0xF, true));
+  o.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.y), 0xB1, 0xF, 0xF, true));
+  o.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.z), 0xB1, 0xF, 0xF, true));
+  o.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.w), 0xB1, 0xF, 0xF, true));
+  return o;
+}
+
+// Whole-line form of the epilogue (round 4).  In the MFMA's layout lane (r, q) holds features 16 u + 4 q .. + 3 of node r, so a load or
+// store instruction touches 16 rows x 64 B: half cache lines, and a row's line is completed by the NEXT instruction.  The same bytes in
+// whole lines move 16 % faster at this size (tools/micro/store_pattern.hip: 9.4 -> 7.85 us for the epilogue's 46 MB alone).  So the
+// lanes of an even / odd node pair swap one block of every block pair (u, u + 1): afterwards the even lane holds columns 32 m + 4 q of
+// BOTH rows of the pair and the odd lane columns 32 m + 16 + 4 q of both -- 8 lanes cover one row's 128-B line, an instruction 8 rows x
+// 128 B.  Biases, P_prev and outputs are addressed in that layout; the row norm adds the pair's halves with one more shuffle.
 template <int NT, int EPI>
+__device__ __forceinline__ void fwd_prefetch_lines(const GemmArgs &g, int nd, int j0, int q, FwdPre<NT> &f) {
+  const int odd = (int)(threadIdx.x & 1);
+  const int row0 = nd - odd, row1 = row0 + 1;
+  f.live = row0 < g.n;
+  f.live1 = row1 < g.n;
+  f.ndc = min(row0, g.n - 1);
+  f.ndc1 = min(row1, g.n - 1);
+  if (g.rows) {
+    f.ndc = g.rows[f.ndc];
+    f.ndc1 = g.rows[f.ndc1];
+    if (f.ndc < 0) {
+      f.live = false;
+      f.ndc = 0;
+    }
+    if (f.ndc1 < 0) {
+      f.live1 = false;
+      f.ndc1 = 0;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < NT / 2; ++m) {
+    const int j = j0 + 32 * m + 16 * odd + 4 * q;
+    f.bb[m] = add4(ld4(g.b1 + j), ld4(g.b2 + j));
+    f.pp[m] = g.p_prev ? ld4(g.p_prev + (size_t)f.ndc * g.ld_out0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    f.pp[NT / 2 + m] = g.p_prev ? ld4(g.p_prev + (size_t)f.ndc1 * g.ld_out0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  f.out_row = f.out_row1 = -1;
+  if (EPI == EPI_FWD_NORM && g.rows_out) {
+    f.out_row = g.rows_out_pos ? g.rows_out_pos[f.ndc] : row0;
+    f.out_row1 = g.rows_out_pos ? g.rows_out_pos[f.ndc1] : row1;
+  }
+}
+
+template <int NT, int EPI>
+__device__ __forceinline__ void fwd_epilogue_lines(const GemmArgs &g, const f32x4 (&acc)[NT], const FwdPre<NT> &f, int j0, int q) {
+  const bool odd = (threadIdx.x & 1) != 0;
+  float4 pv0[NT / 2], pv1[NT / 2], o0[NT / 2], o1[NT / 2];
+#pragma unroll
+  for (int m = 0; m < NT / 2; ++m) {
+    const float4 lo = make_float4(acc[2 * m][0], acc[2 * m][1], acc[2 * m][2], acc[2 * m][3]);
+    const float4 hi = make_float4(acc[2 * m + 1][0], acc[2 * m + 1][1], acc[2 * m + 1][2], acc[2 * m + 1][3]);
+    const float4 got = swap_neighbour(odd ? lo : hi);     // even lane: the odd row's lower block; odd lane: the even row's upper block
+    pv0[m] = add4(odd ? got : lo, f.bb[m]);
+    pv1[m] = add4(odd ? hi : got, f.bb[m]);
+    o0[m] = make_float4(elu1(pv0[m].x), elu1(pv0[m].y), elu1(pv0[m].z), elu1(pv0[m].w));
+    o1[m] = make_float4(elu1(pv1[m].x), elu1(pv1[m].y), elu1(pv1[m].z), elu1(pv1[m].w));
+    if (g.p_prev) {
+      o0[m] = add4(f.pp[m], scale4(g.decay, o0[m]));
+      o1[m] = add4(f.pp[NT / 2 + m], scale4(g.decay, o1[m]));
+    }
+  }
+  float inv0 = 1.f, inv1 = 1.f;
+  if (EPI == EPI_FWD_NORM) {
+    // F.normalize (modules/model.py:205).  The even lane collects the squares of the pair's first row, the odd lane those of the second
+    // (its neighbour's come by one swap per block), added in block order u = 0 .. NT - 1 like the MFMA-layout form does; then the same
+    // two shuffles over q
+    float ss = 0.f;
+#pragma unroll
+    for (int m = 0; m < NT / 2; ++m) {
+      const float t0 = sumsq4(o0[m]), t1 = sumsq4(o1[m]);
+      const float got = swap_neighbour(odd ? t0 : t1);
+      ss = __fadd_rn(ss, odd ? got : t0);      // block 2 m     of the lane's row
+      ss = __fadd_rn(ss, odd ? t1 : got);      // block 2 m + 1
+    }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float mine = 1.f / fmaxf(sqrtf(ss), 1e-12f), other = swap_neighbour(mine);
+    inv0 = odd ? other : mine;
+    inv1 = odd ? mine : other;
+  }
+#pragma unroll
+  for (int m = 0; m < NT / 2; ++m) {
+    const int j = j0 + 32 * m + 16 * (odd ? 1 : 0) + 4 * q;
+    if (f.live) {
+      const size_t off = (size_t)f.ndc * g.ld_out0 + j;
+      st4(g.out0 + off, pv0[m]);
+      st4(g.x_next + off, EPI == EPI_FWD_NORM ? scale4(inv0, o0[m]) : o0[m]);
+      if (EPI == EPI_FWD_NORM && g.rows_out && f.out_row >= 0) st4(g.rows_out + (size_t)f.out_row * g.ld_out0 + j, scale4(inv0, o0[m]));
+    }
+    if (f.live1) {
+      const size_t off = (size_t)f.ndc1 * g.ld_out0 + j;
+      st4(g.out0 + off, pv1[m]);
+      st4(g.x_next + off, EPI == EPI_FWD_NORM ? scale4(inv1, o1[m]) : o1[m]);
+      if (EPI == EPI_FWD_NORM && g.rows_out && f.out_row1 >= 0) st4(g.rows_out + (size_t)f.out_row1 * g.ld_out0 + j, scale4(inv1, o1[m]));
+    }
+  }
+  if (EPI == EPI_FWD_NORM && q == 0) {
+    if (!odd && f.live) g.inv_den[f.ndc] = inv0;
+    if (odd && f.live1) g.inv_den[f.ndc1] = inv1;
+  }
+}
+template <int NT, int EPI, bool LINES = false>
 __device__ __forceinline__ void fwd_prefetch(const GemmArgs &g, int nd, int j0, int q, FwdPre<NT> &f) {
+  if constexpr (LINES && NT % 2 == 0) {
+    fwd_prefetch_lines<NT, EPI>(g, nd, j0, q, f);
+    return;
+  }
   f.live = nd < g.n;
   f.ndc = min(nd, g.n - 1);
   if (g.rows) {   // forward over a row list (gss_plan_step_lazy): tile row -> node row, inputs and outputs alike
@@ -191,8 +313,12 @@ __device__ __forceinline__ void fwd_prefetch(const GemmArgs &g, int nd, int j0, 
   if (EPI == EPI_FWD_NORM && g.rows_out) f.out_row = g.rows_out_pos ? g.rows_out_pos[f.ndc] : nd;
 }
 
-template <int NT, int EPI>
+template <int NT, int EPI, bool LINES = false>
 __device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&acc)[NT], const FwdPre<NT> &f, int j0, int q) {
+  if constexpr (LINES && NT % 2 == 0) {
+    fwd_epilogue_lines<NT, EPI>(g, acc, f, j0, q);
+    return;
+  }
   const int ndc = f.ndc;
   float4 pv[NT], o[NT];
   float ss = 0.f;
@@ -201,7 +327,7 @@ __device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&ac
     pv[u] = add4(make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]), f.bb[u]);
     o[u] = make_float4(elu1(pv[u].x), elu1(pv[u].y), elu1(pv[u].z), elu1(pv[u].w));
     if (g.p_prev) o[u] = add4(f.pp[u], scale4(g.decay, o[u]));
-    ss += o[u].x * o[u].x + o[u].y * o[u].y + o[u].z * o[u].z + o[u].w * o[u].w;
+    ss = __fadd_rn(ss, sumsq4(o[u]));
   }
   float inv = 1.f;
   if (EPI == EPI_FWD_NORM) {
@@ -224,11 +350,11 @@ __device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&ac
 }
 
 // (the stand-alone form: everything fetched right in front of the arithmetic -- kernels that do not hoist it)
-template <int NT, int EPI>
+template <int NT, int EPI, bool LINES = false>
 __device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&acc)[NT], int nd, int j0, int q) {
   FwdPre<NT> f;
-  fwd_prefetch<NT, EPI>(g, nd, j0, q, f);
-  fwd_epilogue<NT, EPI>(g, acc, f, j0, q);
+  fwd_prefetch<NT, EPI, LINES>(g, nd, j0, q, f);
+  fwd_epilogue<NT, EPI, LINES>(g, acc, f, j0, q);
 }
 
 // ---- LDS-staged variant (default) -----------------------------------------------------------------------
@@ -289,7 +415,7 @@ __device__ __forceinline__ XcdIds xcd_ids(int L, int n_spread, int n_share, bool
 // few rows spread over 4 x as many CUs; a row's MFMA chain is the same, its result has the same bits
 // STAMP: the diagnostic instantiation of tools/gemm_stamps.py (per-wave wall-clock stamps); production launches use STAMP = false,
 // whose code carries none of it
-template <int NT, int MT, int EPI, int WAVES = 4, bool STAMP = false>
+template <int NT, int MT, int EPI, int WAVES = 4, bool STAMP = false, bool LINES = false>
 __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BN = 16 * NT;
@@ -371,7 +497,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
   // the epilogue's own operands, requested before the first chunk (one 16-node tile per wave; with two the registers are better spent)
   constexpr bool HOIST = EPI != EPI_SPLIT && MT == 1;
   FwdPre<NT> pre;
-  if (HOIST && g.hoist) fwd_prefetch<NT, EPI>(g, node_base + 16 * (MT * w) + r, j0, q, pre);
+  if (HOIST && g.hoist) fwd_prefetch<NT, EPI, LINES>(g, node_base + 16 * (MT * w) + r, j0, q, pre);
 
   for (int c = 0; c < PF && c < nchunk; ++c) stage(c);
   if (STAMP && stamp && lane == 0) stamp[1] = wall_clock64();
@@ -412,7 +538,23 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int nd = node_base + 16 * (MT * w + t) + r;
-    if (EPI == EPI_SPLIT) {
+    if (EPI == EPI_SPLIT && LINES && NT % 2 == 0) {
+      // whole 128-B lines, as fwd_epilogue_lines: the lanes of an even / odd node pair swap one block of every block pair
+      const bool odd = (lane & 1) != 0;
+      const int row0 = nd - (odd ? 1 : 0), row1 = row0 + 1;
+      float *dst = jh == 0 ? g.out0 : g.out1;
+      const int ldo = jh == 0 ? g.ld_out0 : g.ld_out1;
+      const int jb = j0 - (jh ? g.jsplit : 0);
+#pragma unroll
+      for (int m = 0; m < NT / 2; ++m) {
+        const float4 lo = make_float4(acc[t][2 * m][0], acc[t][2 * m][1], acc[t][2 * m][2], acc[t][2 * m][3]);
+        const float4 hi = make_float4(acc[t][2 * m + 1][0], acc[t][2 * m + 1][1], acc[t][2 * m + 1][2], acc[t][2 * m + 1][3]);
+        const float4 got = swap_neighbour(odd ? lo : hi);
+        const int j = jb + 32 * m + (odd ? 16 : 0) + 4 * q;
+        if (row0 < g.n) st4(dst + (size_t)row0 * ldo + j, odd ? got : lo);
+        if (row1 < g.n) st4(dst + (size_t)row1 * ldo + j, odd ? hi : got);
+      }
+    } else if (EPI == EPI_SPLIT) {
       if (nd >= g.n) continue;
       const int orow = g.rows ? g.rows[nd] : nd;
 #pragma unroll
@@ -425,10 +567,10 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
           st4(g.out1 + (size_t)orow * g.ld_out1 + (j - g.jsplit), v);
       }
     } else if (HOIST) {
-      if (!g.hoist) fwd_prefetch<NT, EPI>(g, nd, j0, q, pre);      // (knob gemm_hoist = 0: fetched here, as until round 4)
-      fwd_epilogue<NT, EPI>(g, acc[t], pre, j0, q);
+      if (!g.hoist) fwd_prefetch<NT, EPI, LINES>(g, nd, j0, q, pre);      // (knob gemm_hoist = 0: fetched here, as until round 4)
+      fwd_epilogue<NT, EPI, LINES>(g, acc[t], pre, j0, q);
     } else {
-      fwd_epilogue<NT, EPI>(g, acc[t], nd, j0, q);
+      fwd_epilogue<NT, EPI, LINES>(g, acc[t], nd, j0, q);
     }
   }
   if (STAMP && stamp) {
@@ -602,6 +744,27 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
     if (g.stamps && EPI == EPI_FWD && nt == 8 && mt == 1) {   // diagnostic twin (tools/gemm_stamps.py): the d = 128 projection only
       hipLaunchKernelGGL((gemm_nt_lds_kernel<8, 1, EPI_FWD, 4, true>), grid, dim3(256), lds, st, g);
       GSS_LAUNCH_CHECK("gemm_nt_lds_kernel (stamped)");
+      return GSS_OK;
+    }
+    // passes without a row list write whole 128-B lines (fwd_epilogue_lines; a row list keeps the MFMA layout: its rows are
+    // scattered, and the lazy step's contract -- the bits of the full pass -- holds because both forms add a row's squares in one order)
+    if (!g.rows && K().gemm_lines && nt >= 2) {
+      constexpr int E = EPI;
+#define GSS_GEMM_LINES(NTV)                                                                             \
+  case NTV:                                                                                             \
+    if (mt == 2)                                                                                        \
+      hipLaunchKernelGGL((gemm_nt_lds_kernel<NTV, 2, E, 4, false, true>), grid, dim3(256), lds, st, g); \
+    else                                                                                                \
+      hipLaunchKernelGGL((gemm_nt_lds_kernel<NTV, 1, E, 4, false, true>), grid, dim3(256), lds, st, g); \
+    break;
+      switch (nt) {
+        GSS_GEMM_LINES(8)
+        GSS_GEMM_LINES(4)
+        default:
+          GSS_GEMM_LINES(2)
+      }
+#undef GSS_GEMM_LINES
+      GSS_LAUNCH_CHECK("gemm_nt_lds_kernel (whole lines)");
       return GSS_OK;
     }
 #define GSS_GEMM_CASE(NTV)                                                                              \
