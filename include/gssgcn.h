@@ -469,6 +469,11 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
  * instead of exchanging them every step (same bits; every rank of a job must use the same value); "loss_dgrad" = -1 (default: on shards only) / 0 / 1: the
  * loss finish and the batch rows' input gradient in one launch instead of two (same bits; on a shard it spares a collective); "prep_side" = 1 (default) / 0: on one GPU a step's batch preparation rides in its
  * first forward SpMM launch and E_B comes out of the top layer's projection (no batch_prepare / gather launch; same bits);
+ * "gemm_lines" = 1 (default) / 0: projections without a row list read and write their epilogue in whole 128-B cache lines (the lanes of an
+ * even / odd node pair swap feature blocks first; same bits); "loss_lines" = 1 (default) / 0: the loss sweep fetches the fragments of its
+ * first product in whole lines (same bits); "wgrad_deep" = 2 (default) / 1 / 0: the weight-gradient reduce fetches its partial slabs
+ * sixteen / eight / four at a time and requests Adam's state first (same bits); "gemm_hoist" = 1 (default) / 0: the forward projection
+ * requests its epilogue operands ahead of the K loop (same bits);
  * "loss_slab" = -1 (default: batches of >= 8192
  * rows) / 0 / 1: sharded plans sweep the B x B loss as row slabs (rank r the i tiles r, r + P, ...; one more all-reduce of B d + 1
  * floats) instead of replicating it on every rank (every rank of a job must use the same value; results agree to rounding).  Every setting computes the same results (some in a different summation order); the defaults are
