@@ -159,7 +159,7 @@ int gss_debug_set_option(const char *name, int value) {
     return GSS_OK;
   }
   if (strcmp(name, "gemm_variant") == 0) {
-    GSS_REQUIRE(value >= 1 && value <= 4, "gemm_variant must be 1..4");
+    GSS_REQUIRE(value >= 1 && value <= 5, "gemm_variant must be 1..5");
     g_knobs.gemm_variant = value;
     return GSS_OK;
   }

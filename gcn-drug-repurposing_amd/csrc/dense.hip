@@ -415,8 +415,8 @@ __device__ __forceinline__ XcdIds xcd_ids(int L, int n_spread, int n_share, bool
 // few rows spread over 4 x as many CUs; a row's MFMA chain is the same, its result has the same bits
 // STAMP: the diagnostic instantiation of tools/gemm_stamps.py (per-wave wall-clock stamps); production launches use STAMP = false,
 // whose code carries none of it
-template <int NT, int MT, int EPI, int WAVES = 4, bool STAMP = false, bool LINES = false>
-__global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
+template <int NT, int MT, int EPI, int WAVES = 4, bool STAMP = false, bool LINES = false, int MINW = 1>
+__global__ __launch_bounds__(64 * WAVES, MINW) void gemm_nt_lds_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BN = 16 * NT;
   constexpr int BM = 16 * WAVES * MT;      // nodes per workgroup (MT 16-node tiles per wave)
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_nt_lds_kernel(GemmArgs g) {
     for (int u = 0; u < NT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // the epilogue's own operands, requested before the first chunk (one 16-node tile per wave; with two the registers are better spent)
-  constexpr bool HOIST = EPI != EPI_SPLIT && MT == 1;
+  constexpr bool HOIST = EPI != EPI_SPLIT && MT == 1 && WAVES <= 4;
   FwdPre<NT> pre;
   if (HOIST && g.hoist) fwd_prefetch<NT, EPI, LINES>(g, node_base + 16 * (MT * w) + r, j0, q, pre);
 
@@ -744,6 +744,18 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
     if (g.stamps && EPI == EPI_FWD && nt == 8 && mt == 1) {   // diagnostic twin (tools/gemm_stamps.py): the d = 128 projection only
       hipLaunchKernelGGL((gemm_nt_lds_kernel<8, 1, EPI_FWD, 4, true>), grid, dim3(256), lds, st, g);
       GSS_LAUNCH_CHECK("gemm_nt_lds_kernel (stamped)");
+      return GSS_OK;
+    }
+    if ((K().gemm_variant == 5 || (K().gemm_variant == 2 && d == 128)) && nt == 8 && !g.rows && K().gemm_lines && EPI != EPI_SPLIT) {
+      // 128-node tiles as EIGHT waves of 16 nodes (round 4): the weights are staged once per 128 nodes as with MT = 2, but a wave keeps
+      // the 16-node tile's 104-110 registers (no hoisted operands, the whole-line epilogue), so two such workgroups share a CU: 16
+      // waves per CU instead of 8.  Same MFMA order per output, same bits.  d = 128 (tools/gemm_w8_ab.py): 28.0 vs 30.2 us (64-node
+      // tiles) at N = 29,960, 188 vs 197 us (128-node, 4 waves) at 250k, equal from 1M on; in the step -1.75 us (full), -1.1 us (the
+      // trainer's).  gemm_variant 5 forces it for other widths, 3 / 4 force the 4-wave tiles.
+      dim3 grid8(ceil_div(g.n, 128), g.J / (16 * nt));
+      const size_t lds8 = 4 * (size_t)(128 * 16 + 16 * nt * 16) * sizeof(float);
+      hipLaunchKernelGGL((gemm_nt_lds_kernel<8, 1, EPI, 8, false, true, 4>), grid8, dim3(512), lds8, st, g);
+      GSS_LAUNCH_CHECK("gemm_nt_lds_kernel (8 waves)");
       return GSS_OK;
     }
     // passes without a row list write whole 128-B lines (fwd_epilogue_lines; a row list keeps the MFMA layout: its rows are
