@@ -31,6 +31,10 @@ int gss_debug_set_option(const char *name, int value) {
     g_knobs.spmm_variant = value;
     return GSS_OK;
   }
+  if (strcmp(name, "spmm_pair") == 0) {
+    g_knobs.spmm_pair = value ? 1 : 0;
+    return GSS_OK;
+  }
   if (strcmp(name, "spmm_pin") == 0) {
     GSS_REQUIRE(value == 0 || value == 1, "spmm_pin must be 0 or 1");
     g_knobs.spmm_pin = value;

@@ -19,6 +19,7 @@ constexpr int kWave = 64;
 struct Knobs {
   int spmm_variant = 2;      // 1 = row per wave, 2 = nnz-balanced segments (default; shards and the lazy step need it)
   int spmm_slices = 0;       // 0 = automatic feature slicing (launch_balanced)
+  int spmm_pair = 1;         // balanced SpMM, lane groups of <= 16 lanes: (col, val) pairs two per lane and trip (whole-line index loads)
   int spmm_pin = 0;          // with a manual spmm_slices: slices pinned to XCDs (1) or time-separated (0)
   int spmm_hot = -1;         // overrides every CSR's hot set with rows [0, value) (-1 = the CSR's own, 0 = none)
   int spmm_fly = 4;          // row gathers in flight per lane group on the large-table path (4 or 8)

@@ -50,6 +50,7 @@ struct SpmmEpi {
   const uint32_t *rowbits;      // SPMM_PLAIN, optional: only rows whose bit is set are computed (the first pass of a two-pass SPMM_FWD1
                                 // under a row bitmap, whose second pass carries the same bitmap as posbits)
   BatchPrep prep;               // SPMM_FWD1, prep.idx != NULL: the launch has one workgroup more than segment blocks -- its first --, which
+  int pair_index;               // narrow lane groups take their (col, val) pairs two per lane and trip: whole-line index loads (knob "spmm_pair")
   int prep_block;               // prepares the batch (see BatchPrep) instead of multiplying
   int pos_row_limit;            // SPMM_BWD2S / SPMM_BWD2, > 0: t, the residual and pos_row are defined for output rows below it only (a shard's
                                 // own rows; the rows behind them -- the boundary rows of the in-place transposed A_hat -- have none)
@@ -349,6 +350,90 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   float4 acc[VPL];
 #pragma unroll
   for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // one row gather of this lane group: slice of row cc of the operand, zeros when !ok
+  auto gather_row = [&](int cc, bool ok, float4 (&dst)[VPL]) __attribute__((always_inline)) {
+    if (NARROW) {
+      // operand < 4 GB, < 2^24 rows: 32-bit byte offsets from the (uniform) base, one full-rate 24-bit multiply-add per gather
+      const unsigned off = __umul24((unsigned)cc, (unsigned)(rowstride_f * 4)) + (unsigned)li * 16u;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const int f4 = li + v * 64;
+        dst[v] = (ok && (VPL == 1 || f4 < d4)) ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(x) + (off + v * 1024u))
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return;
+    }
+    const float *xr = x + (size_t)cc * rowstride;
+    // a CSR with a declared hot set (gss_csr_set_hot: nodes relabelled hub-first; operand rows [0, hot.x) and
+    // [hot.y, hot.z) belong to the hubs): every other row is fetched with the non-temporal policy, so that the
+    // once-read cold rows do not evict the hubs' rows from L2 / the Infinity Cache
+    const bool cold = hot.x >= 0 && !(cc < hot.x || (cc >= hot.y && cc < hot.z));
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int f4 = li + v * 64;
+      const float *src = xr + (size_t)f4 * 4;
+      float4 got = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok && (VPL == 1 || f4 < d4)) {
+        if (cold) {
+          const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src));
+          got = make_float4(t[0], t[1], t[2], t[3]);
+        } else {
+          got = ld4(src);
+        }
+      }
+      dst[v] = got;
+    }
+  };
+  // (round 4) narrow lane groups (LPR <= 16: the XCD-pinned 256-B slices of config 2) took their (col, val) pairs 16 at a time: 64 B per
+  // group and load -- half cache lines, 6 % of the launch's L2 requests in a kernel that sits at the L2s' request ceiling.  Here a lane
+  // takes TWO consecutive pairs with one 8-byte load each (dword-aligned: a segment starts anywhere), 2 LPR entries per trip; entry
+  // t of the trip lives in lane t >> 1, component t & 1.  The entries are walked in the same order: same sums, same bits.
+  typedef int int2u __attribute__((ext_vector_type(2), aligned(4)));
+  typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
+  const bool sparse_walk = MODE == SPMM_BWD1S || (MODE == SPMM_BWD2S && ep.posbits) || (MODE == SPMM_PLAIN && ep.gather_bits);
+  if (LPR <= 16 && FLY == 4 && ep.pair_index && !sparse_walk) {
+    auto load2 = [&](int idx, int &c0, int &c1, float &w0, float &w1) __attribute__((always_inline)) {
+      c0 = c1 = 0;
+      w0 = w1 = 0.f;
+      if (idx + 1 < e1) {
+        const int2u cv = *reinterpret_cast<const int2u *>(a.col + idx);
+        const float2u wv = *reinterpret_cast<const float2u *>(a.val + idx);
+        c0 = cv[0];
+        c1 = cv[1];
+        w0 = wv[0];
+        w1 = wv[1];
+      } else if (idx < e1) {
+        c0 = a.col[idx];
+        w0 = a.val[idx];
+      }
+    };
+    int cn0, cn1;
+    float wn0, wn1;
+    load2(e0 + 2 * li, cn0, cn1, wn0, wn1);
+    for (int base = e0; __any(base < e1); base += 2 * LPR) {
+      const int c0 = cn0, c1 = cn1;
+      const float w0 = wn0, w1 = wn1;
+      load2(base + 2 * LPR + 2 * li, cn0, cn1, wn0, wn1);
+      const int cnt = min(2 * LPR, e1 - base);  // <= 0 once this group is done
+      for (int t = 0; __any(t < cnt); t += 4) {
+        float4 xv[4][VPL];
+        float wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int src = (g << LPR_LOG2) + (((t + u) >> 1) & (LPR - 1));
+          const int cc = __shfl((u & 1) ? c1 : c0, src, 64);      // t is a multiple of 4: entry t + u sits in component u & 1
+          wv[u] = __shfl((u & 1) ? w1 : w0, src, 64);
+          const bool ok = (t + u < cnt) && col_ok;
+          if (!ok) wv[u] = 0.f;
+          gather_row(cc, ok, xv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int v = 0; v < VPL; ++v) acc[v] = fma4(wv[u], xv[u][v], acc[v]);
+      }
+    }
+  } else {
   // the (col, val) pairs of the next LPR entries are requested before the gathers of the current ones
   int c_next = 0;
   float w_next = 0.f;
@@ -368,40 +453,6 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
     }
     const int ce = base + li;
     const int cnt = min(LPR, e1 - base);  // <= 0 once this group is done
-    // one row gather of this lane group: slice of row cc of the operand, zeros when !ok
-    auto gather_row = [&](int cc, bool ok, float4 (&dst)[VPL]) __attribute__((always_inline)) {
-      if (NARROW) {
-        // operand < 4 GB, < 2^24 rows: 32-bit byte offsets from the (uniform) base, one full-rate 24-bit multiply-add per gather
-        const unsigned off = __umul24((unsigned)cc, (unsigned)(rowstride_f * 4)) + (unsigned)li * 16u;
-#pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          const int f4 = li + v * 64;
-          dst[v] = (ok && (VPL == 1 || f4 < d4)) ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(x) + (off + v * 1024u))
-                                               : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        return;
-      }
-      const float *xr = x + (size_t)cc * rowstride;
-      // a CSR with a declared hot set (gss_csr_set_hot: nodes relabelled hub-first; operand rows [0, hot.x) and
-      // [hot.y, hot.z) belong to the hubs): every other row is fetched with the non-temporal policy, so that the
-      // once-read cold rows do not evict the hubs' rows from L2 / the Infinity Cache
-      const bool cold = hot.x >= 0 && !(cc < hot.x || (cc >= hot.y && cc < hot.z));
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        const int f4 = li + v * 64;
-        const float *src = xr + (size_t)f4 * 4;
-        float4 got = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && (VPL == 1 || f4 < d4)) {
-          if (cold) {
-            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src));
-            got = make_float4(t[0], t[1], t[2], t[3]);
-          } else {
-            got = ld4(src);
-          }
-        }
-        dst[v] = got;
-      }
-    };
     constexpr int kFly = FLY;
     if (MODE == SPMM_BWD1S || (MODE == SPMM_BWD2S && ep.posbits) || (MODE == SPMM_PLAIN && ep.gather_bits)) {
       // row-sparse operand.  BWD1S: only neighbours that are batch rows contribute (about B/N of the entries): look the neighbour up in
@@ -460,6 +511,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
         for (int v = 0; v < VPL; ++v) acc[v] = fma4(wv[u], xv[u][v], acc[v]);
     }
   }
+  }   // (one pair per lane and trip)
   // combine the groups of a row inside the wave (aligned power-of-two block of groups)
   const int pcount = 1 << plog;
 #pragma unroll
@@ -601,6 +653,7 @@ static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool p
   SpmmEpi ep = ep_in;
   const bool prep = MODE == SPMM_FWD1 && ep.prep.idx != nullptr;
   ep.prep_block = 0;
+  ep.pair_index = K().spmm_pair;
   const int extra = prep ? 1 : 0;             // the batch preparation rides as one more workgroup, the first of the launch
   int3 hot = make_int3(a->hot_own, a->hot_halo0, a->hot_halo1);
   if (K().spmm_hot >= 0) hot = K().spmm_hot > 0 ? make_int3(K().spmm_hot, 0, 0) : make_int3(-1, 0, 0);

@@ -469,6 +469,8 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
  * instead of exchanging them every step (same bits; every rank of a job must use the same value); "loss_dgrad" = -1 (default: on shards only) / 0 / 1: the
  * loss finish and the batch rows' input gradient in one launch instead of two (same bits; on a shard it spares a collective); "prep_side" = 1 (default) / 0: on one GPU a step's batch preparation rides in its
  * first forward SpMM launch and E_B comes out of the top layer's projection (no batch_prepare / gather launch; same bits);
+ * "spmm_pair" = 1 (default) / 0: lane groups of <= 16 lanes (XCD-pinned 256-B slices) take their (col, val) pairs two per lane and trip, whole-line
+ * index loads (same bits);
  * "gemm_lines" = 1 (default) / 0: projections without a row list read and write their epilogue in whole 128-B cache lines (the lanes of an
  * even / odd node pair swap feature blocks first; same bits); "loss_lines" = 1 (default) / 0: the loss sweep fetches the fragments of its
  * first product in whole lines (same bits); "wgrad_deep" = 2 (default) / 1 / 0: the weight-gradient reduce fetches its partial slabs
