@@ -50,8 +50,8 @@ struct SpmmEpi {
   const uint32_t *rowbits;      // SPMM_PLAIN, optional: only rows whose bit is set are computed (the first pass of a two-pass SPMM_FWD1
                                 // under a row bitmap, whose second pass carries the same bitmap as posbits)
   BatchPrep prep;               // SPMM_FWD1, prep.idx != NULL: the launch has one workgroup more than segment blocks -- its first --, which
-  int pair_index;               // narrow lane groups take their (col, val) pairs two per lane and trip: whole-line index loads (knob "spmm_pair")
   int prep_block;               // prepares the batch (see BatchPrep) instead of multiplying
+  int pair_index;               // narrow lane groups take their (col, val) pairs two per lane and trip: whole-line index loads (knob "spmm_pair")
   int pos_row_limit;            // SPMM_BWD2S / SPMM_BWD2, > 0: t, the residual and pos_row are defined for output rows below it only (a shard's
                                 // own rows; the rows behind them -- the boundary rows of the in-place transposed A_hat -- have none)
 };
