@@ -223,7 +223,7 @@ def test_spmm_backward_epilogues(G, spmm_variant):
 
 
 # ---------------------------------------------------------------- K3 / K4 / K8
-@pytest.fixture(params=[1, 2, 3, 4])
+@pytest.fixture(params=[1, 2, 3, 4, 5])
 def gemm_variant(request, G):
     G._lib.check(G.lib.gss_debug_set_option(b"gemm_variant", request.param))
     yield request.param
