@@ -129,6 +129,7 @@ SIGNATURES = {
     "gss_plan_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), _P]),
     "gss_debug_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "gss_debug_set_stamp_buffer": (C.c_int, [_P]),
+    "gss_plan_debug_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "gss_memcpy_d2d": (C.c_int, [_P, _P, _SZ, _P]),
     "gss_ppr_create": (C.c_int, [C.POINTER(_P), C.POINTER(PprDesc)]),
     "gss_ppr_destroy": (None, [_P]),

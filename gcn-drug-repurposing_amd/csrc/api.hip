@@ -117,10 +117,6 @@ int gss_debug_set_option(const char *name, int value) {
     g_knobs.gemm_lines = value ? 1 : 0;
     return GSS_OK;
   }
-  if (strcmp(name, "loss_lines") == 0) {
-    g_knobs.loss_lines = value ? 1 : 0;
-    return GSS_OK;
-  }
   if (strcmp(name, "gemm_hoist") == 0) {
     g_knobs.gemm_hoist = value ? 1 : 0;
     return GSS_OK;

@@ -30,7 +30,6 @@ struct Knobs {
   int gemm_rows_split = 1;   // forward projection over a short row list: 4 waves per 16 listed rows that split the features (0 = one wave per tile)
   int gemm_prio = 0;         // static wave priority experiment of the projection (0 = off; see dense.hip)
   int wgrad_deep = 2;        // weight-gradient reduce: Adam's state / the batch ids requested first, slabs fetched sixteen at a time (1 = eight; 0 = four, state fetched late)
-  int loss_lines = 1;        // loss sweep: the first product's E_j fragments fetched in whole 128-B lines (lane pairs swap)
   int gemm_lines = 1;        // forward projection's epilogue in whole 128-B lines (neighbouring lanes swap feature blocks first; 0 = the MFMA layout's half lines)
   int gemm_hoist = 1;        // forward projection: biases / previous layer's P / batch-position map requested ahead of the K loop (0 = in the epilogue)
   int gemm_stagger = 0;      // second-generation projection workgroups start this many x 512 cycles late (0 = off)

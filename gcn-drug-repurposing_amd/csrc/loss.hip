@@ -160,41 +160,6 @@ __device__ __forceinline__ void finish_row(bool ok, int r, int li, int lpr, int 
   }
 }
 
-// Whole-line fetch of a 16-row operand tile in the MFMA layout (round 4; the projection's epilogue has the same story, dense.hip
-// fwd_epilogue_lines).  Lane (c, q) needs, of row c, the float4 at k = 16 kk + 4 q for kk = 0 .. NCH - 1: fetched that way an
-// instruction reads 16 rows x 64 B, half cache lines.  Here the lanes of an even / odd row pair read 32 m + 16 (c & 1) + 4 q of the
-// EVEN row, then of the ODD row -- 8 lanes per 128-B line -- and hand the block that belongs to the neighbour over with one swap
-// (raw[2 m] = the even row's piece, raw[2 m + 1] = the odd row's; swap_tile16 turns them into the lane's own chunks 2 m, 2 m + 1).
-__device__ __forceinline__ float4 swap_neighbour4(const float4 &v) {   // lanes 2k <-> 2k + 1 (DPP quad_perm [1, 0, 3, 2])
-  float4 o;
-  o.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.x), 0xB1, 0xF, 0xF, true));
-  o.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.y), 0xB1, 0xF, 0xF, true));
-  o.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.z), 0xB1, 0xF, 0xF, true));
-  o.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.w), 0xB1, 0xF, 0xF, true));
-  return o;
-}
-template <int NCH>
-__device__ __forceinline__ void load_tile16_lines(const float *e, int B, int d, int row0, int c, int q, float4 (&raw)[NCH]) {
-  const int odd = c & 1, ce = c & ~1;
-  const float *pe = e + (size_t)min(B - 1, row0 + ce) * d + 16 * odd + 4 * q;
-  const float *po = e + (size_t)min(B - 1, row0 + ce + 1) * d + 16 * odd + 4 * q;
-#pragma unroll
-  for (int m = 0; m < NCH / 2; ++m) {
-    raw[2 * m] = ld4(pe + 32 * m);
-    raw[2 * m + 1] = ld4(po + 32 * m);
-  }
-}
-template <int NCH>
-__device__ __forceinline__ void swap_tile16(int c, const float4 (&raw)[NCH], float4 (&out)[NCH]) {
-  const bool odd = (c & 1) != 0;
-#pragma unroll
-  for (int m = 0; m < NCH / 2; ++m) {
-    const float4 got = swap_neighbour4(odd ? raw[2 * m] : raw[2 * m + 1]);
-    out[2 * m] = odd ? got : raw[2 * m];
-    out[2 * m + 1] = odd ? raw[2 * m + 1] : got;
-  }
-}
-
 // EXACT: d == 64 NG, no feature masking anywhere.  From d = 256 on the operand fragments + accumulators need more than the 256
 // registers two workgroups per CU leave a lane (372 B/lane of scratch at NG = 4): one workgroup per CU with the full 512
 // (accumulators in AGPRs), and at NG = 4 no register prefetch of the next j tile, measured at B = 2048, d = 256:
@@ -204,7 +169,7 @@ __device__ __forceinline__ void swap_tile16(int c, const float4 (&raw)[NCH], flo
 // the second product's operand loads removed altogether (wrong results, timing only) 30.6 us -- the sweep is bound by neither its
 // loads nor their waits; 1024 MFMAs per SIMD are 13.7 us at 2.4 GHz and ~16.5 us at the ~2.0 GHz an MFMA-saturated loop sustains
 // (tools/micro/mfma_lds.hip: 126-131 of 157 TFLOP/s), the rest is the fixed start (i-tile fragments) and end (wave tree, partial store).
-template <int NG, bool EXACT, bool LN = false, bool PF = (NG <= 2), int OCC = (NG >= 4 ? 1 : 2)>
+template <int NG, bool EXACT, bool PF = (NG <= 2), int OCC = (NG >= 4 ? 1 : 2)>
 __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *red = reinterpret_cast<float4 *>(smem);  // [2 slots][NG*4 tiles][64 lanes]
@@ -240,17 +205,10 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
   float lacc = 0.f;
 
   float4 aj[HOLD_I ? NCH : 1];
-  constexpr bool lines = LN && EXACT && HOLD_I && PF;    // compile-time: a branch here would break the straight-line load / MFMA schedule below
   if (HOLD_I && PF && slot < nj) {
-    if constexpr (lines) {
-      float4 raw[HOLD_I ? NCH : 1];
-      load_tile16_lines<HOLD_I ? NCH : 1>(g.e, B, d, slot * 16, c, q, raw);
-      swap_tile16<HOLD_I ? NCH : 1>(c, raw, aj);
-    } else {
-      const float *ej0 = g.e + (size_t)min(B - 1, slot * 16 + c) * d + 4 * q;
+    const float *ej0 = g.e + (size_t)min(B - 1, slot * 16 + c) * d + 4 * q;
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) aj[k] = (EXACT || 16 * k < d) ? ld4(ej0 + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int k = 0; k < NCH; ++k) aj[k] = (EXACT || 16 * k < d) ? ld4(ej0 + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int jt = slot; jt < nj; jt += nslots) {
     const int j0 = jt * 16;
@@ -290,13 +248,9 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
     } else if (HOLD_I) {
       float4 an[NCH];
       const int jn = jt + nslots;
-      if constexpr (lines) {
-        load_tile16_lines<NCH>(g.e, B, d, (jn < nj ? jn : jt) * 16, c, q, an);   // raw pieces: swapped after this tile's MFMAs
-      } else {
-        const float *ejn = g.e + (size_t)min(B - 1, (jn < nj ? jn : jt) * 16 + c) * d + 4 * q;
+      const float *ejn = g.e + (size_t)min(B - 1, (jn < nj ? jn : jt) * 16 + c) * d + 4 * q;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) an[k] = (EXACT || 16 * k < d) ? ld4(ejn + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      for (int k = 0; k < NCH; ++k) an[k] = (EXACT || 16 * k < d) ? ld4(ejn + 16 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
       __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks every load next to its first use (one exposed
                                           // round trip per 4 MFMAs); issue them all here, consume them later
 #pragma unroll
@@ -306,14 +260,8 @@ __global__ __launch_bounds__(64 * kLossWaves, OCC) void loss_fused_kernel(LossAr
         s0 = mfma16l(aj[k].z, bi[k].z, s0);
         s1 = mfma16l(aj[k].w, bi[k].w, s1);
       }
-      if constexpr (HOLD_I) {
-        if constexpr (lines) {
-          swap_tile16<NCH>(c, an, aj);
-        } else {
 #pragma unroll
-          for (int k = 0; k < NCH; ++k) aj[k] = an[k];
-        }
-      }
+      for (int k = 0; k < NCH; ++k) aj[k] = an[k];
     } else {
       for (int kc = 0; kc < d; kc += 16) {
         const float4 a4 = ld4(ej + kc);
@@ -714,9 +662,7 @@ static int loss_sweep(int32_t d, int32_t b, float beta, float alpha, const float
   const bool exact = (d == 64 * L.ng) && L.nz == 1;
 #define GSS_LOSS_CASE(NGV)                                                              \
   case NGV:                                                                             \
-    if (exact && NGV <= 2 && K().loss_lines)                                            \
-      hipLaunchKernelGGL((loss_fused_kernel<NGV, true, true>), grid, block, lds_request(loss_fused_kernel<NGV, true, true>, lds, K().loss_lds_kb), st, g); \
-    else if (exact)                                                                     \
+    if (exact)                                                                          \
       hipLaunchKernelGGL((loss_fused_kernel<NGV, true>), grid, block, lds_request(loss_fused_kernel<NGV, true>, lds, K().loss_lds_kb), st, g);      \
     else                                                                                \
       hipLaunchKernelGGL((loss_fused_kernel<NGV, false>), grid, block, lds_request(loss_fused_kernel<NGV, false>, lds, K().loss_lds_kb), st, g);     \

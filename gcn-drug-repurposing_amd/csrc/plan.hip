@@ -1192,6 +1192,24 @@ void gss_plan_destroy(gss_plan *p) {
   delete p;
 }
 
+// Measurement aid (tools/ab_live.py): change ONE kernel-selection knob in a LIVE plan's snapshot.  Only knobs that pick between kernels
+// over the same buffers are accepted -- nothing that sizes a workspace or steers the plan's own bookkeeping -- so the plan's memory
+// layout stays what it was.  Two plans in one process differ by up to +-3.4 us per step in identical settings (their buffers sit at
+// different addresses); the same plan under alternating settings does not.
+int gss_plan_debug_set_option(gss_plan *p, const char *name, int value) {
+  GSS_REQUIRE(p && name, "plan_debug_set_option: null argument");
+  static const char *const kLive[] = {"gemm_lines", "spmm_pair", "wgrad_deep", "gemm_hoist", "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "spmm_slices", "spmm_pin", "spmm_fly"};
+  bool ok = false;
+  for (const char *k : kLive) ok = ok || strcmp(k, name) == 0;
+  GSS_REQUIRE(ok, "plan_debug_set_option: only kernel-selection knobs can change on a live plan");
+  const gss::Knobs saved = gss::g_knobs;     // (the setter validates and writes the process defaults: borrow them for the plan's copy)
+  gss::g_knobs = p->knobs;
+  const int rc = gss_debug_set_option(name, value);
+  if (rc == GSS_OK) p->knobs = gss::g_knobs;
+  gss::g_knobs = saved;
+  return rc;
+}
+
 // ---- public entry points.  The separate phases make no assumption about who changed the weights in between, so
 // they always re-transpose; gss_plan_step owns the whole iteration and reuses the transposes its own Adam wrote.
 int gss_plan_forward(gss_plan *p, void *stream) {

@@ -43,6 +43,11 @@ int gss_abi_version(void);
  * (gss_dense_fwd) stores its wall-clock stamps {start, loop begin, loop end, end} + {workgroup id, HW_ID} there (6 x 8 bytes per wave).
  * NULL (the default) switches it off; no production path sets it. */
 int gss_debug_set_stamp_buffer(void *device_buffer);
+/* measurement aid (tools/ab_live.py): changes one KERNEL-SELECTION knob ("gemm_lines", "spmm_pair", "wgrad_deep", "gemm_hoist",
+ * "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "spmm_slices", "spmm_pin", "spmm_fly") in a live plan's snapshot, so that one plan -- the same buffers at the same addresses --
+ * can be timed under alternating settings; knobs that size a workspace or steer the plan's bookkeeping are refused (GSS_EINVAL).
+ * Not thread-safe against gss_debug_set_option on another thread. */
+int gss_plan_debug_set_option(gss_plan *plan, const char *name, int value);
 const char *gss_last_error(void);
 
 /* ---- K11  preprocess_graph, helpers/helper.py:82-89 (+ fp32 cast helper.py:95) ----------
@@ -472,8 +477,7 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
  * "spmm_pair" = 1 (default) / 0: lane groups of <= 16 lanes (XCD-pinned 256-B slices) take their (col, val) pairs two per lane and trip, whole-line
  * index loads (same bits);
  * "gemm_lines" = 1 (default) / 0: projections without a row list read and write their epilogue in whole 128-B cache lines (the lanes of an
- * even / odd node pair swap feature blocks first; same bits); "loss_lines" = 1 (default) / 0: the loss sweep fetches the fragments of its
- * first product in whole lines (same bits); "wgrad_deep" = 2 (default) / 1 / 0: the weight-gradient reduce fetches its partial slabs
+ * even / odd node pair swap feature blocks first; same bits); "wgrad_deep" = 2 (default) / 1 / 0: the weight-gradient reduce fetches its partial slabs
  * sixteen / eight / four at a time and requests Adam's state first (same bits); "gemm_hoist" = 1 (default) / 0: the forward projection
  * requests its epilogue operands ahead of the K loop (same bits);
  * "loss_slab" = -1 (default: batches of >= 8192
