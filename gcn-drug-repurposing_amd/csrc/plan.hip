@@ -1198,7 +1198,7 @@ void gss_plan_destroy(gss_plan *p) {
 // different addresses); the same plan under alternating settings does not.
 int gss_plan_debug_set_option(gss_plan *p, const char *name, int value) {
   GSS_REQUIRE(p && name, "plan_debug_set_option: null argument");
-  static const char *const kLive[] = {"gemm_lines", "spmm_pair", "wgrad_deep", "gemm_hoist", "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "spmm_slices", "spmm_pin", "spmm_fly"};
+  static const char *const kLive[] = {"gemm_lines", "spmm_pair", "wgrad_deep", "gemm_hoist", "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "spmm_slices", "spmm_pin", "spmm_fly", "gemm_prio", "gemm_stagger", "wgrad_prio", "gemm_lds_kb", "wgrad_lds_kb", "loss_lds_kb", "gemm_rows_split"};
   bool ok = false;
   for (const char *k : kLive) ok = ok || strcmp(k, name) == 0;
   GSS_REQUIRE(ok, "plan_debug_set_option: only kernel-selection knobs can change on a live plan");
