@@ -12,7 +12,6 @@ echo "# the kept changes, old value minus new value (positive = the change is a 
 run gemm_lines 0 1 full 12 300
 run gemm_variant 4 2 full 12 300
 run spmm_pair 0 1 full 12 300
-run loss_lines 0 1 full 12 300
 run wgrad_deep 0 2 full 12 300
 run gemm_hoist 0 1 full 12 300
 echo "# the trainer's step"
