@@ -504,7 +504,8 @@ def test_bench_sharded_path_over_rccl_single_rank(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GSS_FORCE_SHARDED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+           "--spinup-time", "0", "--min-time", "0"]     # (both runs must take the SAME number of steps: no time-based spin-up / long run)
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -514,7 +515,7 @@ def test_bench_sharded_path_over_rccl_single_rank(tmp_path):
     for key in ("roofline", "xgmi", "comm_share", "kernel_ms_per_step", "value_executed", "event_overhead_us_per_launch"):
         assert key in sharded, key
     assert sharded["roofline"]["bound"] == "hbm" and 0 < sharded["roofline"]["frac"] < 1
-    ref = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+    ref = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--spinup-time", "0", "--min-time", "0"],
                          capture_output=True, text=True, timeout=600)
     assert ref.returncode == 0, ref.stderr[-2000:]
     single = json.loads([l for l in ref.stdout.splitlines() if l.startswith("{")][-1])
