@@ -9,7 +9,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgssgcn.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GSS_ABI_VERSION 3
+#define GSS_ABI_VERSION 4   /* 4 (round 4): gss_shard_desc gained a_loc_t; gss_plan_comm_stats, gss_knn_topk_rows, gss_plan_debug_set_option */
 
 #define GSS_OK 0
 #define GSS_EINVAL (-22)   /* bad argument (shape, null pointer, unsupported d) */

@@ -36,7 +36,7 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_abi_version_and_error_text(lib):
-    assert lib.gss_abi_version() == 3
+    assert lib.gss_abi_version() == 4
     assert isinstance(lib.gss_last_error(), bytes)
 
 
