@@ -20,149 +20,175 @@ int gss_debug_set_stamp_buffer(void *device_buffer) {
 }
 int gss_abi_version(void) { return GSS_ABI_VERSION; }
 const char *gss_last_error(void) { return gss::g_err; }
+}   // extern "C"
 
+namespace gss {
 // Every knob selects between implementations that all produce correct results (the tests run them all).  The values are process-wide
 // DEFAULTS: a plan snapshots them at creation (common.h Knobs / KnobScope) and keeps running under its snapshot, so a knob changed here
 // reaches per-op calls and plans created afterwards, never a live plan -- not this thread's, not another rank thread's.
-int gss_debug_set_option(const char *name, int value) {
+int set_knob(Knobs &k, const char *name, int value) {
   GSS_REQUIRE(name, "debug_set_option: null name");
   if (strcmp(name, "spmm_variant") == 0) {
     GSS_REQUIRE(value == 1 || value == 2, "spmm_variant must be 1 (row per wave) or 2 (nnz-balanced segments)");
-    g_knobs.spmm_variant = value;
+    k.spmm_variant = value;
     return GSS_OK;
   }
   if (strcmp(name, "spmm_pair") == 0) {
-    g_knobs.spmm_pair = value ? 1 : 0;
+    k.spmm_pair = value ? 1 : 0;
     return GSS_OK;
   }
   if (strcmp(name, "spmm_pin") == 0) {
     GSS_REQUIRE(value == 0 || value == 1, "spmm_pin must be 0 or 1");
-    g_knobs.spmm_pin = value;
+    k.spmm_pin = value;
     return GSS_OK;
   }
   if (strcmp(name, "spmm_fly") == 0) {
     GSS_REQUIRE(value == 4 || value == 8, "spmm_fly must be 4 or 8");
-    g_knobs.spmm_fly = value;
+    k.spmm_fly = value;
     return GSS_OK;
   }
   if (strcmp(name, "spmm_hot_rows") == 0) {
     GSS_REQUIRE(value >= -1, "spmm_hot_rows must be >= -1");
-    g_knobs.spmm_hot = value;
+    k.spmm_hot = value;
     return GSS_OK;
   }
   if (strcmp(name, "spmm_slices") == 0) {
     GSS_REQUIRE(value >= 0 && value <= 8, "spmm_slices must be in [0, 8] (0 = automatic)");
-    g_knobs.spmm_slices = value;
+    k.spmm_slices = value;
     return GSS_OK;
   }
   if (strcmp(name, "spmm_seg_edges") == 0) {
     GSS_REQUIRE(value >= 4 && value <= 1024, "spmm_seg_edges must be in [4, 1024]");
-    g_knobs.seg_edges = value;
+    k.seg_edges = value;
     return GSS_OK;
   }
   if (strcmp(name, "loss_wgs") == 0) {
     GSS_REQUIRE(value >= 64 && value <= 4096, "loss_wgs must be in [64, 4096]");
-    g_knobs.loss_wgs = value;
+    k.loss_wgs = value;
     return GSS_OK;
   }
   if (strcmp(name, "sparse_bits_rows") == 0) {
     GSS_REQUIRE(value >= 1, "sparse_bits_rows must be >= 1");
-    g_knobs.sparse_bits_rows = value;
+    k.sparse_bits_rows = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_nt_cap") == 0) {
     GSS_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "gemm_nt_cap must be 0, 1, 2, 4 or 8");
-    g_knobs.gemm_nt_cap = value;
+    k.gemm_nt_cap = value;
     return GSS_OK;
   }
   if (strcmp(name, "wgrad_wgs") == 0) {
     GSS_REQUIRE(value >= 8 && value <= 4096, "wgrad_wgs must be in [8, 4096]");
-    g_knobs.wgrad_wgs = value;   // before any plan is created: the plan sizes its partial buffer with it
+    k.wgrad_wgs = value;   // before any plan is created: the plan sizes its partial buffer with it
     return GSS_OK;
   }
   if (strcmp(name, "xcd_remap") == 0) {
-    g_knobs.xcd_remap = value ? 1 : 0;
+    k.xcd_remap = value ? 1 : 0;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_small_nt") == 0) {
     GSS_REQUIRE(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "gemm_small_nt must be 0, 1, 2, 4 or 8");
-    g_knobs.gemm_small_nt = value;
+    k.gemm_small_nt = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_prio") == 0) {
     GSS_REQUIRE(value >= -1, "gemm_prio must be >= -1 (0 = off, -1 = by wave slot)");
-    g_knobs.gemm_prio = value;
+    k.gemm_prio = value;
     return GSS_OK;
   }
   if (strcmp(name, "wgrad_prio") == 0) {
     GSS_REQUIRE(value >= 0 && value <= 2, "wgrad_prio must be 0, 1 or 2");
-    g_knobs.wgrad_prio = value;
+    k.wgrad_prio = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_lds_kb") == 0 || strcmp(name, "wgrad_lds_kb") == 0 || strcmp(name, "loss_lds_kb") == 0) {
     GSS_REQUIRE(value >= 0 && value <= 160, "%s must be in [0, 160] (KB of dynamic LDS per workgroup, 0 = what the kernel needs)", name);
-    (name[0] == 'g' ? g_knobs.gemm_lds_kb : name[0] == 'w' ? g_knobs.wgrad_lds_kb : g_knobs.loss_lds_kb) = value;
+    (name[0] == 'g' ? k.gemm_lds_kb : name[0] == 'w' ? k.wgrad_lds_kb : k.loss_lds_kb) = value;
     return GSS_OK;
   }
   if (strcmp(name, "wgrad_variant") == 0) {
     GSS_REQUIRE(value == 1 || value == 2, "wgrad_variant must be 1 (direct loads) or 2 (LDS-DMA ring)");
-    g_knobs.wgrad_variant = value;
+    k.wgrad_variant = value;
     return GSS_OK;
   }
   if (strcmp(name, "wgrad_deep") == 0) {
-    g_knobs.wgrad_deep = value < 0 ? 0 : (value > 2 ? 2 : value);
+    k.wgrad_deep = value < 0 ? 0 : (value > 2 ? 2 : value);
     return GSS_OK;
   }
   if (strcmp(name, "gemm_lines") == 0) {
-    g_knobs.gemm_lines = value ? 1 : 0;
+    k.gemm_lines = value ? 1 : 0;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_hoist") == 0) {
-    g_knobs.gemm_hoist = value ? 1 : 0;
+    k.gemm_hoist = value ? 1 : 0;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_stagger") == 0) {
     GSS_REQUIRE(value >= 0 && value <= 256, "gemm_stagger must be in [0, 256] (units of 512 cycles)");
-    g_knobs.gemm_stagger = value;
+    k.gemm_stagger = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_rows_split") == 0) {
-    g_knobs.gemm_rows_split = value ? 1 : 0;
+    k.gemm_rows_split = value ? 1 : 0;
     return GSS_OK;
   }
   if (strcmp(name, "lazy_halo") == 0) {
     GSS_REQUIRE(value >= -1 && value <= 1, "lazy_halo must be -1 (by graph size), 0 or 1");
-    g_knobs.lazy_halo = value;   // sharded plans created afterwards; every rank of a job must use the same value
+    k.lazy_halo = value;   // sharded plans created afterwards; every rank of a job must use the same value
     return GSS_OK;
   }
   if (strcmp(name, "ppr_fused") == 0) {
-    g_knobs.ppr_fused = value ? 1 : 0;   // handles created afterwards
+    k.ppr_fused = value ? 1 : 0;   // handles created afterwards
     return GSS_OK;
   }
   if (strcmp(name, "loss_dgrad") == 0) {
     GSS_REQUIRE(value >= -1 && value <= 1, "loss_dgrad must be -1 (shards only), 0 or 1");
-    g_knobs.loss_dgrad = value;
+    k.loss_dgrad = value;
     return GSS_OK;
   }
   if (strcmp(name, "prep_side") == 0) {
-    g_knobs.prep_side = value ? 1 : 0;
+    k.prep_side = value ? 1 : 0;
     return GSS_OK;
   }
   if (strcmp(name, "loss_slab") == 0) {
     GSS_REQUIRE(value >= -1 && value <= 1, "loss_slab must be -1 (by batch size), 0 or 1");
-    g_knobs.loss_slab = value;   // read at every step of a sharded plan created afterwards; every rank of a job must use the same value
+    k.loss_slab = value;   // read at every step of a sharded plan created afterwards; every rank of a job must use the same value
     return GSS_OK;
   }
   if (strcmp(name, "halo_recompute") == 0) {
     GSS_REQUIRE(value >= -1 && value <= 1, "halo_recompute must be -1 (automatic: on), 0 or 1");
-    g_knobs.halo_recompute = value;   // sharded plans created afterwards; every rank of a job must use the same value
+    k.halo_recompute = value;   // sharded plans created afterwards; every rank of a job must use the same value
     return GSS_OK;
   }
   if (strcmp(name, "gemm_variant") == 0) {
     GSS_REQUIRE(value >= 1 && value <= 5, "gemm_variant must be 1..5");
-    g_knobs.gemm_variant = value;
+    k.gemm_variant = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "gemm_ws") == 0) {
+    k.gemm_ws = value ? 1 : 0;
+    return GSS_OK;
+  }
+  if (strcmp(name, "gemm_ws_wgs") == 0) {
+    GSS_REQUIRE(value >= 1 && value <= 4096, "gemm_ws_wgs must be in [1, 4096]");
+    k.gemm_ws_wgs = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "gemm_ws_mode") == 0) {
+    GSS_REQUIRE(value >= 0 && value <= 3, "gemm_ws_mode must be in [0, 3]");
+    k.gemm_ws_mode = value;
+    return GSS_OK;
+  }
+  if (strcmp(name, "gemm_ws_stagger") == 0) {
+    GSS_REQUIRE(value >= 0 && value <= 64, "gemm_ws_stagger must be in [0, 64] (units of 512 cycles)");
+    k.gemm_ws_stagger = value;
     return GSS_OK;
   }
   return fail(GSS_EINVAL, "unknown option %s", name);
 }
+}  // namespace gss
+
+extern "C" {
+// process-wide defaults: per-op entry points and plans created afterwards (a live plan keeps its snapshot)
+int gss_debug_set_option(const char *name, int value) { return gss::set_knob(gss::g_knobs, name, value); }
 }

@@ -33,6 +33,10 @@ struct Knobs {
   int gemm_lines = 1;        // forward projection's epilogue in whole 128-B lines (neighbouring lanes swap feature blocks first; 0 = the MFMA layout's half lines)
   int gemm_hoist = 1;        // forward projection: biases / previous layer's P / batch-position map requested ahead of the K loop (0 = in the epilogue)
   int gemm_stagger = 0;      // second-generation projection workgroups start this many x 512 cycles late (0 = off)
+  int gemm_ws = 0;           // d = 128 forward projection without a row list: weight-stationary persistent kernel (proj_ws_kernel; 0 = the staged tiles)
+  int gemm_ws_wgs = 256;     // its persistent workgroups (one per CU)
+  int gemm_ws_mode = 1;      // bit 0: its L2 warm-up pass, bit 1: its weights fetched in whole 128-B lines (lanes trade halves afterwards)
+  int gemm_ws_stagger = 0;   // its second generation of workgroups (linear id >= 256) starts this many x 512 cycles late (0 = together)
   int wgrad_prio = 0;        // the same for the weight gradient
   int wgrad_variant = 1;     // 1 = operands by direct loads from L2, 2 = by LDS-DMA into a per-wave ring, one trip ahead (same bits)
   int wgrad_wgs = 256;       // workgroups of a full-size weight-gradient launch (sizes the plan's partial buffer)
@@ -62,6 +66,7 @@ inline size_t lds_request(F kernel, size_t need, int knob_kb) {
   return lds;
 }
 extern Knobs g_knobs;
+int set_knob(Knobs &k, const char *name, int value);   // api.hip: validate and set one knob of a Knobs value (the process defaults or a plan's snapshot)
 extern thread_local const Knobs *t_knobs;
 inline const Knobs &K() { return t_knobs ? *t_knobs : g_knobs; }
 struct KnobScope {

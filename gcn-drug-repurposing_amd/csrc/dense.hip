@@ -671,6 +671,244 @@ __global__ __launch_bounds__(256) void gemm_rows_split_kernel(GemmArgs g) {
   fwd_epilogue<NT, EPI>(g, row, pre, 0, q);
 }
 
+// ---- weight-stationary persistent projection, d = 128 (round 5) --------------------------------------------------------------
+// The one-tile-per-workgroup kernel above runs a launch as one burst of input, one of MFMA and one of output (12.5 us of
+// matrix-pipe time + ~15 us of memory phases, serialised).  Here the WEIGHTS stay put and the node rows stream past them:
+//   * a workgroup is 4 waves; wave w owns output features [32 w, 32 w + 32) and keeps its K x 32 slice of [W1 | W2] in registers for
+//     the whole launch (256 x 32 floats = 128 registers per lane), in the fragment order the staged kernel reads from LDS
+//   * a persistent workgroup walks 16-row tiles b, b + G, b + 2 G, ...; a tile's [AX | AM] rows (16 KB) arrive by LDS-DMA in a ring
+//     of three slots, two tiles ahead of the MFMAs that read them; every wave reads the same fragments (one ds_read_b128 per 16-wide
+//     K chunk) and issues 128 MFMAs per tile
+//   * the epilogue is fwd_epilogue_lines' for one block pair: the wave's 32 features are one 128-B line per row; biases are loop
+//     invariants, the previous layer's P rows and the batch-position map are requested before the tile's MFMAs
+//   * F.normalize needs a row's squares from all four waves: per (row, q) the waves leave their blocks' partial sums in LDS and every
+//     wave adds the eight blocks in block order -- the order of the one-wave-per-row forms, so the embeddings keep their bits
+//   * two such workgroups share a CU (<= 256 registers); the second generation starts half a tile late (`stagger`), so that one's
+//     epilogue and barrier bubbles fall under the other's MFMAs -- with one tile per workgroup a delay only shifted work (round 3),
+//     here it is paid once for ~4 tiles
+// Every output accumulates chunk by chunk, e = 0..3 inside, as in gemm_nt_lds_kernel: bit-identical results (tests/test_gpu_ops.py).
+// vmcnt bookkeeping: a wave's vector-memory operations complete in issue order (loads, stores and LDS-DMA alike), so "all but the 4
+// youngest" at the end of a tile's MFMAs is "everything except the DMA pieces of the tile after next", whatever stores are in flight.
+struct WsStamp {
+  unsigned long long t[24];   // [0] start, [1] weights + first tile ready, [2 + 2 i] MFMAs of tile i done, [3 + 2 i] its stores issued (i < 9),
+};                            // [20] linear id, [21] HW_ID, [22] tiles, [23] XCC_ID
+
+template <int EPI, bool STAMP, bool WLINES>
+__global__ __launch_bounds__(256, 1) void proj_ws_kernel(GemmArgs g, int stagger, WsStamp *stamps, int flags) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NCH = 16;             // 16-wide chunks of K = 2 d = 256
+  constexpr int SLOT = NCH * 256;     // floats of one tile: 16 rows x 256 k as 16 fragment blocks of 1 KB
+  constexpr int NSLOT = 3;
+  float *lds = reinterpret_cast<float *>(smem);
+  float *part = lds + NSLOT * SLOT;   // [2][16 rows][4 q][8 blocks] partial sums of squares (EPI_FWD_NORM)
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const bool odd = (lane & 1) != 0;
+  const int ntiles = (g.n + 15) >> 4;
+  const int G = (int)gridDim.x, b = (int)blockIdx.x;
+  const int my_tiles = b < ntiles ? (ntiles - b + G - 1) / G : 0;
+  WsStamp *stamp = (STAMP && stamps) ? stamps + ((size_t)b * 4 + w) : nullptr;
+  if (STAMP && stamp && lane == 0) {
+    stamp->t[0] = wall_clock64();
+    stamp->t[20] = (unsigned long long)b;
+    stamp->t[21] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));
+    stamp->t[22] = (unsigned long long)my_tiles;
+    stamp->t[23] = (unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));
+  }
+  if (my_tiles == 0) return;
+
+  // a tile's DMA: wave w stages fragment blocks w, w + 4 (AX: k < 128) and w + 8, w + 12 (AM)
+  auto stage = [&](int i) {
+    const int node = min(g.n - 1, 16 * (b + i * G) + r);
+    const float *s0 = g.in0 + (size_t)node * g.ld_in0 + 4 * q + 16 * w;
+    const float *s1 = g.in1 + (size_t)node * g.ld_in1 + 4 * q + 16 * w;
+    const unsigned dst = lds_base + (unsigned)(((i % NSLOT) * SLOT + w * 256) * 4);
+    glds16(s0, dst);
+    glds16(s0 + 64, dst + 4 * 1024);
+    glds16(s1, dst + 8 * 1024);
+    glds16(s1 + 64, dst + 12 * 1024);
+  };
+  auto stage_piece = [&](int i, int k) {   // piece k of stage(i): fragment block w + 4 k
+    const int node = min(g.n - 1, 16 * (b + i * G) + r);
+    const float *s = (k < 2 ? g.in0 + (size_t)node * g.ld_in0 : g.in1 + (size_t)node * g.ld_in1) + 4 * q + 16 * w + 64 * (k & 1);
+    glds16(s, lds_base + (unsigned)(((i % NSLOT) * SLOT + (w + 4 * k) * 256) * 4));
+  };
+  stage(0);
+  if (my_tiles > 1) stage(1);
+
+  // L2 warm-up.  A kernel starts with cold L2s, and a CU fills from beyond its L2 at ~11 B/clk (its outstanding-miss budget over the
+  // Infinity Cache's latency): every CU pulling the same 128 KB of weights that way took 5 us, with 8 workgroups on the chip as with
+  // 256.  So each wave first touches ONE KB of [W1 | W2] -- the 32 CUs x 4 waves of an XCD (workgroups b, b + 8, ... share one) a
+  // different KB each -- and waits: one round trip later the whole matrix sits in the XCD's L2 and the real loads below are L2 hits.
+  if (flags & 1) {
+    const int slice = ((b >> 3) & 31) * 4 + w;   // 0 .. 127: KB of W1 (< 64) or W2
+    const float *wp = g.w[0][slice >> 6] + (size_t)(slice & 63) * 256 + 4 * lane;
+    f32x4 sink;
+    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(sink) : "v"(wp) : "memory");
+  }
+  if (STAMP && stamp && lane == 0) stamp->t[19] = wall_clock64();
+  // the wave's slice of [W1 | W2]: block u (features 32 w + 16 u + r), chunk c (k = 16 c + 4 q .. + 3; c >= 8 is W2)
+  float4 wr[2][NCH];
+  if constexpr (WLINES) {
+    // in WHOLE 128-B lines: an instruction reads 8 rows x 128 B (lanes r < 8 chunk 2 p of row r & 7, lanes r >= 8 chunk 2 p + 1 of the
+    // same rows), a second one the block's other 8 rows, and the halves of a 16-lane row trade places (DPP row_ror:8, no LDS)
+    const bool lo8 = r < 8;
+    auto rot8 = [](const float4 &v) {
+      float4 o;
+      o.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.x), 0x128, 0xF, 0xF, true));
+      o.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.y), 0x128, 0xF, 0xF, true));
+      o.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.z), 0x128, 0xF, 0xF, true));
+      o.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.w), 0x128, 0xF, 0xF, true));
+      return o;
+    };
+    float4 la[2][NCH / 2], lb[2][NCH / 2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int pc = 0; pc < NCH / 2; ++pc) {   // pc = 4 kh + p: chunk pair (2 p, 2 p + 1) of W1 (kh = 0) / W2
+        const float *base = g.w[0][pc >> 2] + (size_t)(32 * w + 16 * u + (r & 7)) * g.ld_w + 16 * (2 * (pc & 3) + (r >> 3)) + 4 * q;
+        la[u][pc] = ld4(base);
+        lb[u][pc] = ld4(base + (size_t)8 * g.ld_w);
+      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int pc = 0; pc < NCH / 2; ++pc) {
+        const float4 ra = rot8(la[u][pc]), rb = rot8(lb[u][pc]);
+        wr[u][2 * pc] = lo8 ? la[u][pc] : rb;
+        wr[u][2 * pc + 1] = lo8 ? ra : lb[u][pc];
+      }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        wr[u][c] = ld4(g.w[0][c >> 3] + (size_t)(32 * w + 16 * u + r) * g.ld_w + 16 * (c & 7) + 4 * q);
+  }
+  const int j = 32 * w + (odd ? 16 : 0) + 4 * q;   // the lane's columns in the whole-line layout (both rows of its pair)
+  const float4 bb = add4(ld4(g.b1 + j), ld4(g.b2 + j));
+  // second-generation workgroups (those that double up on the CUs, by dispatch order: speed only) start late
+  if (stagger > 0 && b >= 256)
+    for (int k = 0; k < stagger; ++k) __builtin_amdgcn_s_sleep(8);
+  // everything requested so far is in: both tiles and the weights.  The BUILTIN form, so that hipcc's own wait-count pass sees the
+  // weight loads complete here -- with an asm wait it would put its wait for them in front of the loop's first MFMA, where it also
+  // covers the previous tile's stores on every trip
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+  __builtin_amdgcn_s_barrier();
+  if (STAMP && stamp && lane == 0) stamp->t[1] = wall_clock64();
+
+  for (int i = 0; i < my_tiles; ++i) {
+    const int T = b + i * G;
+    // the epilogue's per-tile operands, requested ahead of the tile's MFMAs
+    const int row0 = 16 * T + (r & ~1), row1 = row0 + 1;
+    const bool live0 = row0 < g.n, live1 = row1 < g.n;
+    const int nd0 = min(row0, g.n - 1), nd1 = min(row1, g.n - 1);
+    float4 pp0 = make_float4(0.f, 0.f, 0.f, 0.f), pp1 = pp0;
+    if (g.p_prev) {
+      pp0 = ld4(g.p_prev + (size_t)nd0 * g.ld_out0 + j);
+      pp1 = ld4(g.p_prev + (size_t)nd1 * g.ld_out0 + j);
+    }
+    int orow0 = -1, orow1 = -1;
+    if (EPI == EPI_FWD_NORM && g.rows_out) {
+      orow0 = g.rows_out_pos[nd0];
+      orow1 = g.rows_out_pos[nd1];
+    }
+    const bool ahead = i + 2 < my_tiles;   // tile i + 2 goes into the slot tile i - 1 was read from (every wave is past the barrier behind its MFMAs)
+
+    const float *cur = lds + (i % NSLOT) * SLOT + lane * 4;
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    // the row fragments are read two chunks (16 MFMAs = 512 pipe cycles) ahead of the MFMAs that use them
+    float4 bf[4];
+    bf[0] = *reinterpret_cast<const float4 *>(cur);
+    bf[1] = *reinterpret_cast<const float4 *>(cur + 256);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (c + 2 < NCH) bf[(c + 2) & 3] = *reinterpret_cast<const float4 *>(cur + (c + 2) * 256);
+      // the next-but-one tile's four DMA pieces go out one at a time in the shadow of the MFMAs (issued together in front of them
+      // they cost the wave ~0.3 us per tile)
+      if (c < 8 && (c & 1) && ahead) stage_piece(i + 2, c >> 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 bc = bf[c & 3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float bv = e == 0 ? bc.x : e == 1 ? bc.y : e == 2 ? bc.z : bc.w;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const float av = e == 0 ? wr[u][c].x : e == 1 ? wr[u][c].y : e == 2 ? wr[u][c].z : wr[u][c].w;
+          acc[u] = mfma16(av, bv, acc[u]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // tile i + 1 (requested a whole tile ago), this tile's operands and the previous tile's stores: all but the pieces just requested
+    if (ahead)
+      wait_vmcnt<4>();
+    else
+      wait_vmcnt<0>();
+    if (STAMP && stamp && lane == 0 && i < 9) stamp->t[2 + 2 * i] = wall_clock64();
+
+    // epilogue (fwd_epilogue_lines for the one block pair of this wave)
+    const float4 lo = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+    const float4 hi = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
+    const float4 got = swap_neighbour(odd ? lo : hi);
+    const float4 pv0 = add4(odd ? got : lo, bb);
+    const float4 pv1 = add4(odd ? hi : got, bb);
+    float4 o0 = make_float4(elu1(pv0.x), elu1(pv0.y), elu1(pv0.z), elu1(pv0.w));
+    float4 o1 = make_float4(elu1(pv1.x), elu1(pv1.y), elu1(pv1.z), elu1(pv1.w));
+    if (g.p_prev) {
+      o0 = add4(pp0, scale4(g.decay, o0));
+      o1 = add4(pp1, scale4(g.decay, o1));
+    }
+    float inv0 = 1.f, inv1 = 1.f;
+    if (EPI == EPI_FWD_NORM) {
+      // F.normalize (modules/model.py:205): this lane's two partial sums -- rows (r & ~1) and (r | 1), block 2 w + odd -- go to LDS;
+      // behind the barrier the lane adds its own row's eight blocks in block order, then the two shuffles over q of the other forms
+      float *pt = part + (i & 1) * 512;
+      pt[((r & ~1) * 4 + q) * 8 + 2 * w + (odd ? 1 : 0)] = sumsq4(o0);
+      pt[((r | 1) * 4 + q) * 8 + 2 * w + (odd ? 1 : 0)] = sumsq4(o1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const float4 s0 = *reinterpret_cast<const float4 *>(pt + (r * 4 + q) * 8);
+      const float4 s1 = *reinterpret_cast<const float4 *>(pt + (r * 4 + q) * 8 + 4);
+      float ss = 0.f;
+      ss = __fadd_rn(ss, s0.x);
+      ss = __fadd_rn(ss, s0.y);
+      ss = __fadd_rn(ss, s0.z);
+      ss = __fadd_rn(ss, s0.w);
+      ss = __fadd_rn(ss, s1.x);
+      ss = __fadd_rn(ss, s1.y);
+      ss = __fadd_rn(ss, s1.z);
+      ss = __fadd_rn(ss, s1.w);
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      const float mine = 1.f / fmaxf(sqrtf(ss), 1e-12f), other = swap_neighbour(mine);
+      inv0 = odd ? other : mine;
+      inv1 = odd ? mine : other;
+    } else {
+      __builtin_amdgcn_s_barrier();   // every wave has read this tile's slot and has the next tile's pieces in
+    }
+    if (live0) {
+      const size_t off = (size_t)nd0 * g.ld_out0 + j;
+      st4(g.out0 + off, pv0);
+      st4(g.x_next + off, EPI == EPI_FWD_NORM ? scale4(inv0, o0) : o0);
+      if (EPI == EPI_FWD_NORM && orow0 >= 0) st4(g.rows_out + (size_t)orow0 * g.ld_out0 + j, scale4(inv0, o0));
+    }
+    if (live1) {
+      const size_t off = (size_t)nd1 * g.ld_out0 + j;
+      st4(g.out0 + off, pv1);
+      st4(g.x_next + off, EPI == EPI_FWD_NORM ? scale4(inv1, o1) : o1);
+      if (EPI == EPI_FWD_NORM && orow1 >= 0) st4(g.rows_out + (size_t)orow1 * g.ld_out0 + j, scale4(inv1, o1));
+    }
+    if (EPI == EPI_FWD_NORM && w == 0 && q == 0) {
+      if (!odd && live0) g.inv_den[nd0] = inv0;
+      if (odd && live1) g.inv_den[nd1] = inv1;
+    }
+    if (STAMP && stamp && lane == 0 && i < 9) stamp->t[3 + 2 * i] = wall_clock64();
+  }
+}
+
 // Measured dead end, for the record: a weights-resident variant for d <= 128 ([W1|W2] = 128 KB DMA'd into LDS once per
 // workgroup, 8 independent waves per CU, each holding its 16-node [AX|AM] block in registers, fragment reads one chunk
 // ahead, no barrier in the loop): 32.9 us vs 31.4 us at N = 29,960, 202 vs 210 us at N = 240k.  Per-wave timestamps
@@ -738,6 +976,26 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
       }
       GSS_LAUNCH_CHECK("gemm_nt_lds_kernel (one wave)");
       return GSS_OK;
+    }
+    if constexpr (EPI != EPI_SPLIT) {
+      // d = 128, all rows: the weight-stationary persistent kernel (round 5; proj_ws_kernel above).  Same bits as the staged tiles.
+      if (K().gemm_ws && K().gemm_variant == 2 && d == 128 && g.K == 256 && g.J == 128 && !g.rows && g.in1 && (!g.rows_out || g.rows_out_pos)) {
+        const int ntiles = ceil_div(g.n, 16);
+        const int wgs = std::min(ntiles, K().gemm_ws_wgs);
+        const size_t ldsw = (size_t)(3 * 16 * 256 + 2 * 512) * sizeof(float);
+        const int mode = K().gemm_ws_mode;   // bit 0: L2 warm-up pass, bit 1: the weights in whole lines
+        WsStamp *sp = reinterpret_cast<WsStamp *>(g.stamps);   // diagnostic (gss_debug_set_stamp_buffer; tools/proj_ws_stamps.py): 24 x 8 bytes per wave
+        if (sp && (mode & 2))
+          hipLaunchKernelGGL((proj_ws_kernel<EPI, true, true>), dim3(wgs), dim3(256), ldsw, st, g, K().gemm_ws_stagger, sp, mode);
+        else if (sp)
+          hipLaunchKernelGGL((proj_ws_kernel<EPI, true, false>), dim3(wgs), dim3(256), ldsw, st, g, K().gemm_ws_stagger, sp, mode);
+        else if (mode & 2)
+          hipLaunchKernelGGL((proj_ws_kernel<EPI, false, true>), dim3(wgs), dim3(256), ldsw, st, g, K().gemm_ws_stagger, sp, mode);
+        else
+          hipLaunchKernelGGL((proj_ws_kernel<EPI, false, false>), dim3(wgs), dim3(256), ldsw, st, g, K().gemm_ws_stagger, sp, mode);
+        GSS_LAUNCH_CHECK("proj_ws_kernel");
+        return GSS_OK;
+      }
     }
     dim3 grid(ceil_div(g.n, 64 * mt), g.J / (16 * nt));
     const size_t lds = 4 * (size_t)(64 * mt * 16 + 16 * nt * 16) * sizeof(float);

@@ -1198,16 +1198,11 @@ void gss_plan_destroy(gss_plan *p) {
 // different addresses); the same plan under alternating settings does not.
 int gss_plan_debug_set_option(gss_plan *p, const char *name, int value) {
   GSS_REQUIRE(p && name, "plan_debug_set_option: null argument");
-  static const char *const kLive[] = {"gemm_lines", "spmm_pair", "wgrad_deep", "gemm_hoist", "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "spmm_slices", "spmm_pin", "spmm_fly", "gemm_prio", "gemm_stagger", "wgrad_prio", "gemm_lds_kb", "wgrad_lds_kb", "loss_lds_kb", "gemm_rows_split"};
+  static const char *const kLive[] = {"gemm_lines", "spmm_pair", "wgrad_deep", "gemm_hoist", "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "spmm_slices", "spmm_pin", "spmm_fly", "gemm_prio", "gemm_stagger", "wgrad_prio", "gemm_lds_kb", "wgrad_lds_kb", "loss_lds_kb", "gemm_rows_split", "gemm_ws", "gemm_ws_wgs", "gemm_ws_stagger", "gemm_ws_mode"};
   bool ok = false;
   for (const char *k : kLive) ok = ok || strcmp(k, name) == 0;
   GSS_REQUIRE(ok, "plan_debug_set_option: only kernel-selection knobs can change on a live plan");
-  const gss::Knobs saved = gss::g_knobs;     // (the setter validates and writes the process defaults: borrow them for the plan's copy)
-  gss::g_knobs = p->knobs;
-  const int rc = gss_debug_set_option(name, value);
-  if (rc == GSS_OK) p->knobs = gss::g_knobs;
-  gss::g_knobs = saved;
-  return rc;
+  return gss::set_knob(p->knobs, name, value);   // the plan's own snapshot: no other thread's plan or per-op call sees it
 }
 
 // ---- public entry points.  The separate phases make no assumption about who changed the weights in between, so

@@ -250,6 +250,41 @@ def test_dense_fwd(G, n, d, gemm_variant):
         assert rel_err(xn.cpu().numpy(), xref) < 3e-6
 
 
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 8200, 29960])
+def test_dense_fwd_weight_stationary_equals_the_staged_tiles(G, n):
+    """Round 5: the d = 128 forward projection as a weight-stationary persistent kernel (proj_ws_kernel: a wave keeps its K x 32 slice
+    of [W1 | W2] in registers, 16-row tiles of [AX | AM] stream through an LDS ring) accumulates every output chunk by chunk in the
+    staged kernel's order: P and x_next must not differ by a bit -- for one tile and for thousands, ragged last tiles, more
+    workgroups than tiles, few workgroups that walk hundreds of tiles, with and without the staggered start."""
+    d = 128
+    rng = np.random.RandomState(n)
+    ax, am, pprev = (cu(rng.randn(n, d).astype(np.float32)) for _ in range(3))
+    w1, w2 = (cu(np.eye(d, dtype=np.float32) + 0.1 * rng.randn(d, d).astype(np.float32)) for _ in range(2))
+    b1, b2 = (cu(0.1 * rng.randn(d).astype(np.float32)) for _ in range(2))
+
+    def run(prev, **knobs):
+        try:
+            for k, v in knobs.items():
+                G._lib.check(G.lib.gss_debug_set_option(k.encode(), v))
+            p = torch.full((n + 1, d), float("nan"), device="cuda")      # one guard row behind the outputs
+            xn = torch.full((n + 1, d), float("nan"), device="cuda")
+            G._lib.check(G.lib.gss_dense_fwd(n, d, ax.data_ptr(), am.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                             pprev.data_ptr() if prev else None, 0.3, p.data_ptr(), xn.data_ptr(), G.st()))
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(p[n]).all()) and bool(torch.isnan(xn[n]).all()), "a row behind the outputs was written"
+            return p[:n].clone(), xn[:n].clone()
+        finally:
+            for k, v in (("gemm_ws", 0), ("gemm_ws_wgs", 256), ("gemm_ws_stagger", 0), ("gemm_ws_mode", 1)):
+                G.lib.gss_debug_set_option(k.encode(), v)
+
+    for prev in (False, True):
+        ref = run(prev, gemm_ws=0)
+        assert bool(torch.isfinite(ref[0]).all())
+        for knobs in ({}, {"gemm_ws_wgs": 3, "gemm_ws_mode": 0}, {"gemm_ws_wgs": 512, "gemm_ws_mode": 3}, {"gemm_ws_wgs": 1000, "gemm_ws_stagger": 9, "gemm_ws_mode": 2}):
+            got = run(prev, gemm_ws=1, **knobs)
+            assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]), (n, prev, knobs)
+
+
 @pytest.mark.parametrize("n,d", [(700, 128), (50, 16), (333, 64)])
 def test_dense_bwd_input_dense_and_scattered(G, n, d, gemm_variant):
     rng = np.random.RandomState(n)
