@@ -9,7 +9,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgssgcn.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -56,6 +56,7 @@ SIGNATURES = {
     "gss_last_error": (C.c_char_p, []),
     "gss_normalize_adj": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P]),
     "gss_rowsum_dinv": (C.c_int, [_I32, _P, _P, _P, _P, _P]),
+    "gss_rowsum_check": (C.c_int, [_I32, _P, _P, _P, _P]),
     "gss_scale_adj_shard": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _I32, _P, _P]),
     "gss_csr_create": (C.c_int, [C.POINTER(_P), _I32, _I32, _I64, _P, _P, _P, _P]),
     "gss_csr_destroy": (None, [_P]),

@@ -56,53 +56,74 @@ static int stream_wait(hipStream_t st, double timeout_s, const char *who) {
 // is caught at the caller's synchronisation points by gss_comm_sync, which waits for the stream with a deadline and aborts.
 struct RcclComm final : gss_comm {
   // `comm` is read by every enqueue and freed by abort(), which the host may call from another thread (Python's Comm.abort, a
-  // watchdog): `mu` serialises the two.  Enqueues hold it only while they hand work to RCCL (never while waiting for the device).
+  // watchdog).  `mu` guards the POINTER only and is never held across a call into RCCL: an enqueue can stall on the host inside RCCL
+  // (lazy p2p connection setup on first use, a peer that never joins the group), and that is exactly the hang abort() exists to
+  // break -- ncclCommAbort raises the communicator's abort flag, which RCCL's host-side wait loops poll, so the stalled call returns
+  // with an error.  Enqueues snapshot the pointer under `mu` (Use), abort() takes it out under `mu` and calls ncclCommAbort outside.
   ncclComm_t comm = nullptr;
   std::mutex mu;
   std::atomic<bool> aborted{false};
   std::atomic<bool> failed{false};   // check_async has reported an error: ncclCommDestroy could wait for the dead peer
+  std::atomic<int> in_rccl{0};       // enqueues currently inside an RCCL call (the destructor waits for them, abort() does not)
+  struct Use {                       // an enqueue's hold on the communicator: pointer snapshot + in-flight count
+    RcclComm &c;
+    ncclComm_t h = nullptr;
+    explicit Use(RcclComm &c_) : c(c_) {
+      std::lock_guard<std::mutex> lk(c.mu);
+      if (!c.aborted.load()) h = c.comm;
+      if (h) c.in_rccl.fetch_add(1);
+    }
+    ~Use() {
+      if (h) c.in_rccl.fetch_sub(1);
+    }
+  };
   ~RcclComm() override {
-    std::lock_guard<std::mutex> lk(mu);
-    if (!comm) return;
+    for (int spins = 0; in_rccl.load() > 0 && spins < 5000; ++spins) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    ncclComm_t h = take();
+    if (!h) return;
     if (failed.load() || aborted.load())
-      (void)ncclCommAbort(comm);
+      (void)ncclCommAbort(h);
     else
-      (void)ncclCommDestroy(comm);
-    comm = nullptr;
+      (void)ncclCommDestroy(h);
   }
   bool device_transport() const override { return true; }
-  void abort_locked() {
-    if (aborted.exchange(true)) return;
-    if (comm) (void)ncclCommAbort(comm);   // frees the communicator
+  ncclComm_t take() {
+    std::lock_guard<std::mutex> lk(mu);
+    ncclComm_t h = comm;
     comm = nullptr;
+    return h;
   }
   void abort() override {
-    std::lock_guard<std::mutex> lk(mu);
-    abort_locked();
+    if (aborted.exchange(true)) return;
+    if (ncclComm_t h = take()) (void)ncclCommAbort(h);   // frees the communicator; a call stalled inside RCCL sees the flag and returns
   }
-  int alive_locked() const {
-    if (aborted.load() || !comm) return fail(GSS_ECOMM, "RCCL communicator of rank %d was aborted after an earlier failure", rank);
-    return GSS_OK;
-  }
-  int check_locked() {
-    if (int rc = alive_locked()) return rc;
+  int dead() const { return fail(GSS_ECOMM, "RCCL communicator of rank %d was aborted after an earlier failure", rank); }
+  int check(ncclComm_t h) {
     ncclResult_t st = ncclSuccess;
-    const ncclResult_t r = ncclCommGetAsyncError(comm, &st);
+    const ncclResult_t r = ncclCommGetAsyncError(h, &st);
     if (r == ncclSuccess && (st == ncclSuccess || st == ncclInProgress)) return GSS_OK;
+    if (aborted.load()) return dead();   // another thread aborted while this call was inside RCCL
     const ncclResult_t bad = r != ncclSuccess ? r : st;
     failed.store(true);
-    abort_locked();
+    abort();
     return fail(GSS_ECOMM, "RCCL asynchronous error on rank %d of %d: %s (communicator aborted)", rank, world, ncclGetErrorString(bad));
   }
+  // an RCCL call's own return code: after abort() from another thread it is that abort speaking
+  int rccl_rc(ncclResult_t r, const char *what) {
+    if (r == ncclSuccess) return GSS_OK;
+    if (aborted.load()) return dead();
+    return fail(GSS_ECOMM, "%s -> %s", what, ncclGetErrorString(r));
+  }
   int check_async() override {
-    std::lock_guard<std::mutex> lk(mu);
-    return check_locked();
+    Use u(*this);
+    if (!u.h) return dead();
+    return check(u.h);
   }
   int count(int32_t *out) override {
-    std::lock_guard<std::mutex> lk(mu);
-    if (int rc = alive_locked()) return rc;
+    Use u(*this);
+    if (!u.h) return dead();
     int c = 0;
-    GSS_NCCL(ncclCommCount(comm, &c));
+    if (int rc = rccl_rc(ncclCommCount(u.h, &c), "ncclCommCount")) return rc;
     *out = c;
     return GSS_OK;
   }
@@ -128,30 +149,26 @@ struct RcclComm final : gss_comm {
     }
   }
   int all_gather(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) override {
-    std::lock_guard<std::mutex> lk(mu);
-    if (int rc = alive_locked()) return rc;
+    Use u(*this);
+    if (!u.h) return dead();
     // in place when send == recv + rank * bytes_per_rank (RCCL detects it)
-    GSS_NCCL(ncclAllGather(send, recv, bytes_per_rank, ncclInt8, comm, st));
-    return check_locked();
+    if (int rc = rccl_rc(ncclAllGather(send, recv, bytes_per_rank, ncclInt8, u.h, st), "ncclAllGather")) return rc;
+    return check(u.h);
   }
   int all_reduce_sum(float *const *bufs, const size_t *counts, int nbuf, hipStream_t st) override {
-    std::lock_guard<std::mutex> lk(mu);
-    if (int rc = alive_locked()) return rc;
+    Use u(*this);
+    if (!u.h) return dead();
     // several tensors = one fused RCCL operation (one launch)
     if (nbuf > 1) GSS_NCCL(ncclGroupStart());
-    for (int k = 0; k < nbuf; ++k) {
-      const ncclResult_t r = ncclAllReduce(bufs[k], bufs[k], counts[k], ncclFloat, ncclSum, comm, st);
-      if (r != ncclSuccess) {
-        if (nbuf > 1) (void)ncclGroupEnd();
-        return fail(GSS_ECOMM, "ncclAllReduce -> %s", ncclGetErrorString(r));
-      }
-    }
-    if (nbuf > 1) GSS_NCCL(ncclGroupEnd());
-    return check_locked();
+    ncclResult_t r = ncclSuccess;
+    for (int k = 0; k < nbuf && r == ncclSuccess; ++k) r = ncclAllReduce(bufs[k], bufs[k], counts[k], ncclFloat, ncclSum, u.h, st);
+    const ncclResult_t e = nbuf > 1 ? ncclGroupEnd() : ncclSuccess;
+    if (int rc = rccl_rc(r != ncclSuccess ? r : e, "ncclAllReduce")) return rc;
+    return check(u.h);
   }
   int exchange_rows(const float *send, const int64_t *send_off, float *recv, const int64_t *recv_off, int d, hipStream_t st) override {
-    std::lock_guard<std::mutex> lk(mu);
-    if (int rc = alive_locked()) return rc;
+    Use u(*this);
+    if (!u.h) return dead();
     // halo exchange: one fused group of point-to-point transfers, each over the xGMI link of its pair; pairs with an empty
     // list are skipped
     GSS_NCCL(ncclGroupStart());
@@ -159,12 +176,12 @@ struct RcclComm final : gss_comm {
     for (int q = 0; q < world && r == ncclSuccess; ++q) {
       if (q == rank) continue;
       const int64_t ns = send_off[q + 1] - send_off[q], nr = recv_off[q + 1] - recv_off[q];
-      if (ns > 0) r = ncclSend(send + (size_t)send_off[q] * d, (size_t)ns * d, ncclFloat, q, comm, st);
-      if (nr > 0 && r == ncclSuccess) r = ncclRecv(recv + (size_t)recv_off[q] * d, (size_t)nr * d, ncclFloat, q, comm, st);
+      if (ns > 0) r = ncclSend(send + (size_t)send_off[q] * d, (size_t)ns * d, ncclFloat, q, u.h, st);
+      if (nr > 0 && r == ncclSuccess) r = ncclRecv(recv + (size_t)recv_off[q] * d, (size_t)nr * d, ncclFloat, q, u.h, st);
     }
     const ncclResult_t e = ncclGroupEnd();
-    if (r != ncclSuccess || e != ncclSuccess) return fail(GSS_ECOMM, "halo exchange (ncclSend/ncclRecv group) -> %s", ncclGetErrorString(r != ncclSuccess ? r : e));
-    return check_locked();
+    if (int rc = rccl_rc(r != ncclSuccess ? r : e, "halo exchange (ncclSend/ncclRecv group)")) return rc;
+    return check(u.h);
   }
 };
 

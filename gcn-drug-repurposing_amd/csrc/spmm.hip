@@ -828,6 +828,19 @@ __global__ __launch_bounds__(256) void rowsum_kernel(int n, const int32_t *__res
   }
 }
 
+// rows whose D_ii is not > 0 (negative, zero or NaN): their D_ii^-1/2 is NaN / inf, and so is every entry of their row and column
+__global__ __launch_bounds__(256) void rowsum_check_kernel(int n, const double *__restrict__ rowsum, unsigned long long *__restrict__ count,
+                                                           int *__restrict__ first) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  const bool bad = row < n && !(rowsum[row] > 0.0);
+  const unsigned long long m = __ballot(bad);
+  if (m == 0) return;
+  if ((threadIdx.x & 63) == __ffsll((long long)m) - 1) {   // the wave's first bad lane reports for the wave
+    atomicAdd(count, (unsigned long long)__popcll(m));
+    atomicMin(first, row);
+  }
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(int n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                     const double *__restrict__ val, const double *__restrict__ dinv,
                                                     float *__restrict__ out) {
@@ -870,6 +883,29 @@ int gss_rowsum_dinv(int32_t n, const int32_t *rowptr, const double *val, double 
   GSS_REQUIRE(n > 0 && rowptr && val && dinv_out, "rowsum_dinv: null operand");
   hipLaunchKernelGGL(rowsum_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, as_stream(stream), n, rowptr, val, dinv_out, rowsum_out);
   GSS_LAUNCH_CHECK("rowsum_kernel");
+  return GSS_OK;
+}
+
+int gss_rowsum_check(int32_t n, const double *rowsum, int64_t *h_count_out, int32_t *h_first_out, void *stream) {
+  GSS_REQUIRE(n >= 0 && (n == 0 || rowsum) && h_count_out, "rowsum_check: null operand");
+  *h_count_out = 0;
+  if (h_first_out) *h_first_out = -1;
+  if (n == 0) return GSS_OK;
+  hipStream_t st = as_stream(stream);
+  struct Res {
+    unsigned long long count;
+    int first;
+  } h{0ull, INT32_MAX};
+  Res *dres = nullptr;
+  GSS_HIP(hipMallocAsync((void **)&dres, sizeof(Res), st));
+  GSS_HIP(hipMemcpyAsync(dres, &h, sizeof(Res), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(rowsum_check_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, n, rowsum, &dres->count, &dres->first);
+  GSS_LAUNCH_CHECK("rowsum_check_kernel");
+  GSS_HIP(hipMemcpyAsync(&h, dres, sizeof(Res), hipMemcpyDeviceToHost, st));
+  GSS_HIP(hipFreeAsync(dres, st));
+  GSS_HIP(hipStreamSynchronize(st));   // a setup-time check: the answer is a host value
+  *h_count_out = (int64_t)h.count;
+  if (h_first_out) *h_first_out = h.count ? h.first : -1;
   return GSS_OK;
 }
 

@@ -16,6 +16,37 @@ import torch
 from . import _lib
 
 
+class NonPositiveRowSum(ValueError):
+    """A + I has rows whose sum D_ii is not > 0: D^-1/2 is NaN / inf there (helpers/helper.py:85 does not guard)."""
+
+    def __init__(self, count, first, n):
+        self.count, self.first, self.n = int(count), int(first), int(n)
+        super().__init__(f"{self.count} of {self.n} rows of A + I have a sum <= 0 (first: node {self.first}): D^-1/2 is NaN/inf there and the NaN "
+                         f"spreads through every hop.  Negative similarities in kNN mode do this; the reference trains on and writes NaN "
+                         f"embeddings without a word.  Pass allow_nan / --allow-nan for that behaviour.")
+
+
+def report_bad_row_sums(count, first, n, allow_nan, name_of=None):
+    """What a positive count from gss_rowsum_check leads to: an exception, or under allow_nan a warning and the reference's NaNs."""
+    if count <= 0:
+        return
+    err = NonPositiveRowSum(count, first, n)
+    if name_of is not None:
+        err.args = (err.args[0].replace(f"node {first})", f"node {first} = {name_of(first)!r})"),)
+    if not allow_nan:
+        raise err
+    import warnings
+    warnings.warn(str(err.args[0]), RuntimeWarning, stacklevel=3)
+
+
+def rowsum_check(rowsum, n):
+    """gss_rowsum_check on a device vector of fp64 row sums: (rows whose D_ii is not > 0, the first of them or -1)"""
+    count, first = C.c_int64(0), C.c_int32(-1)
+    _lib.check(_lib.load().gss_rowsum_check(int(n), rowsum.data_ptr() if n else None, C.addressof(count), C.addressof(first),
+                                            _lib.current_stream()), "gss_rowsum_check")
+    return int(count.value), int(first.value)
+
+
 def knn_descriptor_adj(X, k=5, chunk=4096):
     """helpers/helper.py:39-53 without the two dense N x N host arrays: x_sim rows are produced in
     chunks.  X: [N, d] fp64 features (the reference passes the transpose).  Returns scipy CSR fp64.
@@ -133,7 +164,9 @@ class GssGraph:
     `adj` is the raw scipy adjacency (fp64, any sparsity format).  Mirrors
     preprocess_graph + convert_sparse_matrix_to_sparse_tensor (helpers/helper.py:82-96)."""
 
-    def __init__(self, adj, device="cuda", need_transpose=True):
+    def __init__(self, adj, device="cuda", need_transpose=True, allow_nan=False, name_of=None):
+        """allow_nan: a row sum <= 0 raises NonPositiveRowSum unless set (then: a warning, and NaN / inf exactly where the reference
+        has them).  name_of: node id -> name, for the message."""
         adj = sp.csr_matrix(adj, dtype=np.float64)
         n = adj.shape[0]
         assert adj.shape[0] == adj.shape[1]
@@ -149,6 +182,8 @@ class GssGraph:
         self.rowsum = torch.empty(n, dtype=torch.float64, device=dev)
         _lib.check(lib.gss_normalize_adj(n, rowptr.data_ptr(), col.data_ptr(), val64.data_ptr(), val32.data_ptr(),
                                          self.rowsum.data_ptr(), _lib.current_stream()), "gss_normalize_adj")
+        self.bad_rows, self.first_bad_row = rowsum_check(self.rowsum, n)
+        report_bad_row_sums(self.bad_rows, self.first_bad_row, n, allow_nan, name_of)
         self.a = DeviceCSR(a_.indptr, a_.indices, val32, n, n, dev)
         self.at = None
         if need_transpose:
@@ -168,6 +203,7 @@ class GssGraph:
         dev = torch.device(device)
         self.n = n
         self.rowsum = None
+        self.bad_rows, self.first_bad_row = 0, -1
         self.a = DeviceCSR(a_hat.indptr, a_hat.indices, a_hat.data.astype(np.float32), n, n, dev)
         self.at = None
         if need_transpose:

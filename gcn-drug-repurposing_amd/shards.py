@@ -63,6 +63,10 @@ class NativeShardOps:
                    "gss_rowsum_dinv")
         return dinv, rowsum
 
+    def rowsum_check(self, nl, rowsum):
+        from .graph import rowsum_check
+        return rowsum_check(rowsum, nl)
+
     def scale_adj(self, nl, lo, rowptr, col, val, dinv, transposed, dev):
         val32 = torch.empty(max(col.numel(), 1), dtype=torch.float32, device=dev)
         _lib.check(self.lib.gss_scale_adj_shard(nl, lo, rowptr.data_ptr(), _lib.ptr(col), _lib.ptr(val), dinv.data_ptr(), transposed,
@@ -349,7 +353,9 @@ class KnnSource:
 class EdgelistSource:
     """--adj-file: the directed weighted edgelist (embio.read_edgelist: src, dst, w over the .embs.txt rows) as a row source.  A rank
     keeps the entries of its own rows of A + I and of (A + I)^T only; a repeated (u, v) keeps the last weight (DiGraph.add_edge),
-    a self loop in the file adds to the diagonal's 1 (graph.edgelist_adj + helper.py:83)."""
+    a self loop in the file adds to the diagonal's 1, and an entry whose final value is 0 -- a zero weight in the file, a self loop of
+    weight -1 -- is not stored, as scipy's `adj + eye` drops it (graph.edgelist_adj + helper.py:83): the same stored entries, nnz(A_hat),
+    row work and partition as ScipySource(edgelist_adj(...))."""
 
     def __init__(self, src, dst, w, n, device="cuda"):
         self.n = int(n)
@@ -359,12 +365,20 @@ class EdgelistSource:
         order = np.argsort(key, kind="stable")
         ks = key[order]
         last = order[np.r_[ks[1:] != ks[:-1], True]] if len(ks) else order
-        self._src, self._dst, self._w = src[last], dst[last], w[last]                    # distinct (u, v), sorted by (u, v)
-        diag = self._src == self._dst
-        self.nnz = int(len(self._src) - diag.sum() + self.n)
+        src, dst, w = src[last], dst[last], w[last]                                      # distinct (u, v), sorted by (u, v)
+        diag = src == dst
+        self._loop = np.zeros(self.n, dtype=bool)                                        # rows with a self loop in the file: their diagonal
+        self._loop[src[diag]] = True                                                     # entry is w + 1 (or nothing), not the inserted 1
+        w = w + diag                                                                     # A + I
+        keep = w != 0
+        self._src, self._dst, self._w = src[keep], dst[keep], w[keep]
+        diag = diag[keep]
+        has_diag = ~self._loop
+        has_diag[self._src[diag]] = True
+        self.nnz = int(len(self._src) - diag.sum() + has_diag.sum())
         deg_out = np.bincount(self._src[~diag], minlength=self.n)
         deg_in = np.bincount(self._dst[~diag], minlength=self.n)
-        self._work = (deg_out + deg_in + 2).astype(np.int64)
+        self._work = (deg_out + deg_in + 2 * has_diag).astype(np.int64)                  # entries of the node's row of A + I and of its transpose
 
     def work(self, comm, device):
         return self._work
@@ -375,12 +389,7 @@ class EdgelistSource:
         m = (r_new >= lo) & (r_new < hi)
         rr, cc_old, vv = r_new[m] - lo, cols_of[m], self._w[m]
         d_old = np.arange(lo, hi) if relabel is None else relabel.perm[lo:hi]
-        # A + I: the diagonal's 1 is ADDED to a self loop of the file (adj + eye)
-        self_loop = cc_old == d_old[rr]
-        vv = vv + self_loop
-        have = np.zeros(hi - lo, dtype=bool)
-        have[rr[self_loop]] = True
-        miss = np.flatnonzero(~have)
+        miss = np.flatnonzero(~self._loop[d_old])                                        # rows without a self loop in the file: the inserted 1
         rr = np.concatenate([rr, miss])
         cc_old = np.concatenate([cc_old, d_old[miss]])
         vv = np.concatenate([vv, np.ones(len(miss))])
@@ -503,7 +512,7 @@ def transpose_in_place(rowptr, col_local, val32, nl, n_cols, device):
 
 
 def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="auto", row_weight=ROW_WEIGHT, ops=None, split="auto",
-                local_transpose="auto") -> Shard:
+                local_transpose="auto", allow_nan=False, name_of=None) -> Shard:
     """relabel: True / False / "auto" (hub-first node order when the graph has >= RELABEL_MIN_NODES nodes; the non-temporal
     treatment of the cold rows additionally needs an operand far beyond the caches, gss_csr_set_hot).  Relabelling is invisible in
     the results: a row's entries keep their original
@@ -513,7 +522,9 @@ def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="a
     overlaps each hop with its halo exchange (gss_shard_desc.a_own ...; results then differ from the single-GPU plan by rounding,
     not bit for bit).  "auto": when a hop fetches >= SPLIT_MIN_HALO_ROWS boundary rows on some rank (RMAT scale), never on one rank.
     local_transpose: True / False / "auto" (on unless GSS_LOCAL_TRANSPOSE=0) -- also keep A_hat's shard transposed in place, so that the
-    plan's last backward hop needs no exchange of u (gss_shard_desc.a_loc_t)."""
+    plan's last backward hop needs no exchange of u (gss_shard_desc.a_loc_t).
+    allow_nan / name_of: as GssGraph -- a row sum <= 0 anywhere in the graph raises NonPositiveRowSum on EVERY rank (the ranks
+    exchange their counts) unless allow_nan is set."""
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     ops = ops or NativeShardOps()
     P, rank = comm.world, comm.rank
@@ -536,6 +547,15 @@ def build_shard(source, comm: Comm, need_transpose=True, device=None, relabel="a
 
     rowptr, col, val = source.rows(lo, hi, dev, relabel=rl)
     dinv_local, rowsum = ops.rowsum_dinv(nl, rowptr, val, dev)
+    # the guard helper.py:85 lacks: every rank learns how many rows of the WHOLE graph have D_ii <= 0 and which comes first
+    bad, first = ops.rowsum_check(nl, rowsum)
+    first_orig = -1
+    if bad:
+        first_orig = int(rl.perm[lo + first]) if rl is not None else lo + first
+    every = allgather_host(comm, np.array([bad, first_orig], dtype=np.int64), dev).reshape(-1, 2) if P > 1 else np.array([[bad, first_orig]])
+    if every[:, 0].sum() > 0:
+        from .graph import report_bad_row_sums
+        report_bad_row_sums(int(every[:, 0].sum()), int(every[every[:, 0] > 0, 1].min()), n, allow_nan, name_of)
     dinv = allgather_ranges(comm, dinv_local[:nl], part.bounds, dev).contiguous()            # D^-1/2 of every node
 
     def finish(rowptr, col, val, transposed):

@@ -55,6 +55,9 @@ def build_parser():
     # additions
     p.add_argument('--adj-file', type=str, default=None,
                    help="weighted edgelist ('u v w') or .sif adjacency over the nodes of --emb-file; replaces the kNN graph")
+    p.add_argument('--allow-nan', action='store_true',
+                   help="train on when A + I has a row sum <= 0 (negative similarities): NaN embeddings, as the reference writes "
+                        "them (helpers/helper.py:85 does not guard); without it such a graph is an error that names the node")
     p.add_argument('--out', type=str, default='graph_embs.txt', help='output file (reference: ./graph_embs.txt)')
     p.add_argument('--cache-layer1', dest='cache_layer1', action='store_true', default=True,
                    help="keep layer 1's two SpMM results across steps (their inputs, A_hat and X, never change; bitwise neutral): the default")
@@ -165,7 +168,8 @@ def main(argv=None):
             adj = edgelist_adj(src, dst, w, n)
         else:
             adj = knn_descriptor_adj_device(X, args.k, device=dev)   # train.py:93 -> helper.py:39-53, similarity + top-k on device
-        graph = GssGraph(adj, device=dev, need_transpose=args.num_layers > 1)   # train.py:100-101
+        graph = GssGraph(adj, device=dev, need_transpose=args.num_layers > 1, allow_nan=args.allow_nan,
+                         name_of=lambda i: names[i])                              # train.py:100-101
         print('Created G with [k={}] [shape=[{}, {}]] [nnz(A_hat)={}] in {:.2f}s'.format(args.k, n, n, graph.nnz, time.time() - t0))
 
     # the kernels want a feature width that is a multiple of 16; the reference takes any --hidden-units.  Zero
@@ -192,7 +196,7 @@ def main(argv=None):
         from .dist import job_comm, local_comms
         from .shards import build_shard, shard_engine, shard_rows
         comm = job_comm(world, rank) if sharded else local_comms(1)[0]
-        shard = build_shard(source, comm, need_transpose=args.num_layers > 1, device=dev)
+        shard = build_shard(source, comm, need_transpose=args.num_layers > 1, device=dev, allow_nan=args.allow_nan, name_of=lambda i: names[i])
         engine = shard_engine(shard, shard_rows(shard, X32), host_params, comm, num_layers=args.num_layers, layer_decay=args.layer_decay,
                               alpha=args.alpha, lr=args.lr, max_batch=min(bsz, n), cache_layer1=args.cache_layer1)
         if rank == 0:

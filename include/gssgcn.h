@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GSS_ABI_VERSION 4   /* 4 (round 4): gss_shard_desc gained a_loc_t; gss_plan_comm_stats, gss_knn_topk_rows, gss_plan_debug_set_option */
+#define GSS_ABI_VERSION 5   /* 5 (round 5): gss_rowsum_check; 4 (round 4): gss_shard_desc gained a_loc_t, gss_plan_comm_stats, gss_knn_topk_rows */
 
 #define GSS_OK 0
 #define GSS_EINVAL (-22)   /* bad argument (shape, null pointer, unsupported d) */
@@ -65,6 +65,12 @@ int gss_normalize_adj(int32_t n, const int32_t *rowptr, const int32_t *col, cons
 int gss_rowsum_dinv(int32_t n, const int32_t *rowptr, const double *val, double *dinv_out, double *rowsum_out, void *stream);
 int gss_scale_adj_shard(int32_t n, int32_t row0, const int32_t *rowptr, const int32_t *col, const double *val, const double *dinv_global,
                         int32_t transposed, float *val_out, void *stream);
+/* The guard the reference lacks (helpers/helper.py:85, SURVEY a3's hazard): counts the rows whose D_ii is not > 0 -- negative
+ * similarities in kNN mode can do that -- i.e. the rows whose D_ii^-1/2 is NaN / inf and poisons every entry of their row and column.
+ * rowsum = the fp64 row sums gss_normalize_adj / gss_rowsum_dinv wrote (device); *h_count_out and *h_first_out (nullable; the lowest
+ * such row, -1 if none) are HOST values: the call waits for the stream.  The normalisation itself stays the reference's arithmetic; what
+ * to do about a positive count is the caller's decision (trainer.py refuses to train unless --allow-nan). */
+int gss_rowsum_check(int32_t n, const double *rowsum, int64_t *h_count_out, int32_t *h_first_out, void *stream);
 
 /* ---- CSR handle ---------------------------------------------------------------------------
  * Borrows d_rowptr/d_col/d_val (caller keeps them alive).  h_rowptr is a HOST copy of rowptr used

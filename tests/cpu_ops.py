@@ -122,6 +122,10 @@ class NumpyShardOps:
             dinv = np.power(rowsum, -0.5)
         return torch.from_numpy(dinv), torch.from_numpy(rowsum)
 
+    def rowsum_check(self, nl, rowsum):
+        bad = np.flatnonzero(~(_np(rowsum)[:nl] > 0))
+        return len(bad), (int(bad[0]) if len(bad) else -1)
+
     def scale_adj(self, nl, lo, rowptr, col, val, dinv, transposed, dev):
         rp, c, v, di = rowptr.numpy().astype(np.int64), col.numpy().astype(np.int64), val.numpy(), dinv.numpy()
         row = np.repeat(np.arange(nl, dtype=np.int64), np.diff(rp[:nl + 1])) + lo

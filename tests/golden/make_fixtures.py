@@ -191,7 +191,48 @@ def case_train_py():
           f"-> {os.path.getsize(path)/1e6:.2f} MB")
 
 
+def case_negative_rowsum():
+    """SURVEY a3's hazard, pinned: kNN mode on features with negative similarities.  One node points away from everybody else, so
+    every inner product it keeps is negative and its row sum of A + I is < 0: np.power(rowsum, -0.5) (helper.py:85) is NaN
+    there, and the NaN spreads to the rows and columns of their neighbours.  The reference does not guard; the fixture
+    records what it produces -- the graph, the row sums, A_hat with its NaN / inf pattern, and the first forward's embeddings."""
+    import warnings
+    rng = np.random.RandomState(11)
+    n, d, k = 96, 8, 5
+    X = rng.randn(n, d) * 0.3
+    X[:, 0] += 1.0                                  # a common direction: similarities among ordinary nodes are positive
+    X[17] = -2.5 * X[17]                            # one node that points the other way: every similarity it keeps is negative
+    X32 = X.astype(np.float32)
+    adj = knn_adj(X32, k)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a_hat = H.preprocess_graph(adj)                                # helper.py:82-89: NaN / inf, silently
+    rowsum = np.asarray((sp.csr_matrix(adj) + sp.eye(n)).sum(1)).reshape(-1)
+    bad = np.flatnonzero(~(rowsum > 0))
+    assert len(bad) > 0, "the construction must produce a non-positive row sum"
+    torch.manual_seed(5)
+    np.random.seed(5)
+    model = M.ResidualGraphConvolutionalNetwork(train_batch_size=32, val_batch_size=n, num_layers=2, hidden_units=d, init_weights=1e-5,
+                                                layer_decay=0.3)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        emb = model(x=torch.tensor(X32), adj=H.convert_sparse_matrix_to_sparse_tensor(a_hat)).numpy().copy()
+    out = {"X": X32, "k": np.int64(k), "rowsum": rowsum, "bad_rows": bad.astype(np.int64), "emb0": emb}
+    out.update(csr_parts(adj, "A"))
+    a = sp.csr_matrix(a_hat)
+    a.sort_indices()
+    out.update({"Ahat_indptr": a.indptr.astype(np.int64), "Ahat_indices": a.indices.astype(np.int64), "Ahat_data": a.data.astype(np.float64)})
+    path = os.path.join(HERE, "knn_negative_rowsum_n96_d8.npz")
+    np.savez_compressed(path, **out)
+    print(f"knn_negative_rowsum_n96_d8: rows with D_ii <= 0: {bad.tolist()} (sums {rowsum[bad].tolist()}), "
+          f"non-finite entries of A_hat: {int((~np.isfinite(a.data)).sum())} of {a.nnz}, non-finite embedding rows: "
+          f"{int((~np.isfinite(emb)).any(1).sum())} of {n} -> {os.path.getsize(path)/1e3:.1f} KB")
+
+
 def main():
+    if sys.argv[1:] == ["negative_rowsum"]:        # one case alone (the others are unchanged since round 1)
+        case_negative_rowsum()
+        return
     # 1. BASELINE config 1: toy.sif, d=64, L=2, full batch
     rng = np.random.RandomState(0)
     adj = toy_sif_adj()
@@ -228,6 +269,9 @@ def main():
 
     # 5. the reference's train.py, end to end
     case_train_py()
+
+    # 6. a non-positive row sum (SURVEY a3 hazard)
+    case_negative_rowsum()
 
 
 if __name__ == "__main__":

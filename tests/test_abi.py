@@ -36,7 +36,10 @@ def test_header_symbols_are_exported_and_bound(lib):
 
 
 def test_abi_version_and_error_text(lib):
-    assert lib.gss_abi_version() == 4
+    import gcn_drug_repurposing_amd as pkg
+    header = open(os.path.join(ROOT, "include", "gssgcn.h")).read()
+    declared = int(re.search(r"#define GSS_ABI_VERSION (\d+)", header).group(1))
+    assert lib.gss_abi_version() == declared == pkg._lib.ABI_VERSION      # header, library and binding agree
     assert isinstance(lib.gss_last_error(), bytes)
 
 

@@ -227,3 +227,79 @@ def test_host_staged_transport_callback_over_gloo(world):
     separate processes on CPU -- all-gather and all-to-all-v land every rank's bytes where the C side expects them"""
     import torch.multiprocessing as mp
     mp.spawn(_host_transport_worker, args=(world, _free_port()), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("relabel", [False, True])
+def test_edgelist_source_rows_equal_the_scipy_path(relabel):
+    """shards.EdgelistSource is train.py's --adj-file path for sharded runs and every graph of >= RELABEL_MIN_NODES nodes.
+    Its rows of A + I and of (A + I)^T must be the rows ScipySource(edgelist_adj(...)) has -- the path it replaced -- on a directed edgelist
+    with repeated (u, v) (last weight wins), self loops (added to the diagonal's 1), zero weights and a self loop of weight -1 (both
+    dropped, as scipy's `adj + eye` drops them): same stored entries, same nnz(A_hat), same row work, over several row windows."""
+    from gcn_drug_repurposing_amd.graph import edgelist_adj
+    from gcn_drug_repurposing_amd.shards import EdgelistSource, Relabel, ScipySource
+    rng = np.random.RandomState(5)
+    n, m = 120, 900
+    src, dst = rng.randint(0, n, m), rng.randint(0, n, m)
+    w = rng.uniform(0.1, 2.0, m)
+    src[:40], dst[:40] = src[40:80], dst[40:80]                     # repeated (u, v): the later line wins
+    w[100:130] = 0.0                                                # zero weights
+    src[200:215] = dst[200:215]                                     # self loops ...
+    w[200:205] = -1.0                                               # ... five of them cancel the diagonal's 1
+    ref = ScipySource(edgelist_adj(src, dst, w, n))
+    got = EdgelistSource(src, dst, w, n, device="cpu")
+    assert got.nnz == ref.nnz and ref.nnz < n + len(set(zip(src.tolist(), dst.tolist())))
+    np.testing.assert_array_equal(got.work(None, "cpu"), ref.work(None, "cpu"))
+    rl = Relabel(ref.work(None, "cpu")) if relabel else None
+    for lo, hi in ((0, n), (0, 37), (37, 90), (90, n), (50, 50)):
+        for name in ("rows", "rows_t"):
+            a = getattr(got, name)(lo, hi, "cpu", relabel=rl)
+            b = getattr(ref, name)(lo, hi, "cpu", relabel=rl)
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x.numpy(), y.numpy(), err_msg=f"{name} [{lo}, {hi})")
+
+
+def _bad_rowsum_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        import warnings
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from cpu_ops import GlooComm, NumpyShardOps
+        from gcn_drug_repurposing_amd.graph import NonPositiveRowSum
+        from gcn_drug_repurposing_amd.shards import ScipySource, build_shard
+        g = load_golden("knn_negative_rowsum_n96_d8")
+        n = g["X"].shape[0]
+        adj = sp.csr_matrix((g["A_data"], g["A_indices"], g["A_indptr"]), shape=(n, n))
+        msg = ""
+        try:
+            build_shard(ScipySource(adj), GlooComm(), device="cpu", relabel=bool(rank >= 0 and world == 3), ops=NumpyShardOps(), name_of=lambda i: f"n{i}")
+        except NonPositiveRowSum as e:
+            msg = f"{e.count} {e.first} {e.args[0]}"
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            shard = build_shard(ScipySource(adj), GlooComm(), device="cpu", relabel=False, ops=NumpyShardOps(), allow_nan=True)
+        lo, hi = shard.part.rows(rank)
+        ahat = sp.csr_matrix((g["Ahat_data"], g["Ahat_indices"], g["Ahat_indptr"]), shape=(n, n))[lo:hi]
+        same_nan = bool(np.array_equal(np.isnan(np.asarray(shard.a.m.data)), np.isnan(ahat.data)))
+        with open(os.path.join(out_dir, f"r{rank}.txt"), "w") as f:
+            f.write(f"{msg}\n{len(w)} {same_nan}\n")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_non_positive_row_sum_is_refused_on_every_rank(tmp_path, world):
+    """the guard helper.py:85 lacks, on shards: the rank that owns the bad row finds it, EVERY rank raises the same NonPositiveRowSum
+    (naming the node by its original id, relabelled or not) -- no rank is left waiting in a collective; under allow_nan every rank
+    warns and the shard's values have the reference's NaNs"""
+    import torch.multiprocessing as mp
+    mp.spawn(_bad_rowsum_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g = load_golden("knn_negative_rowsum_n96_d8")
+    bad = int(g["bad_rows"][0])
+    lines = [open(tmp_path / f"r{r}.txt").read().splitlines() for r in range(world)]
+    for l in lines:
+        assert l[0].startswith(f"1 {bad} 1 of 96 rows") and f"node {bad} = 'n{bad}'" in l[0], l
+        assert l[1] == "1 True", l

@@ -75,6 +75,51 @@ def test_normalize_adj_matches_reference_fixture(G, op_case):
     assert abs(t - gg.a.to_scipy().T).max() == 0
 
 
+def test_non_positive_row_sum_is_counted_and_refused_and_reproduces_the_reference_nans(G):
+    """helpers/helper.py:85 takes rowsum ** -0.5 of a negative row sum without a word (SURVEY a3).  gss_rowsum_check counts such rows;
+    GssGraph refuses the graph naming the first of them; under allow_nan the device normalisation has NaN at exactly the entries the
+    reference's preprocess_graph has them (fixture generated from the reference: one node that points away from all others) and its values elsewhere, and one hop spreads
+    the NaN to exactly the rows the reference's sparse product spreads it to"""
+    import warnings
+    from conftest import load_golden
+    g = load_golden("knn_negative_rowsum_n96_d8")
+    n = g["X"].shape[0]
+    bad = int(g["bad_rows"][0])
+    adj = G.graph.knn_descriptor_adj_device(g["X"].astype(np.float64), int(g["k"]))          # the device kNN builder keeps negative similarities
+    ref_a = sp.csr_matrix((g["A_data"], g["A_indices"], g["A_indptr"]), shape=(n, n))
+    adj = sp.csr_matrix(adj); adj.sort_indices()
+    assert np.array_equal(adj.indptr, ref_a.indptr) and np.array_equal(adj.indices, ref_a.indices)
+    with pytest.raises(G.graph.NonPositiveRowSum, match=f"first: node {bad} = 'n{bad}'") as ei:
+        G.graph.GssGraph(adj, name_of=lambda i: f"n{i}")
+    assert ei.value.count == 1 and ei.value.first == bad and ei.value.n == n
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        gg = G.graph.GssGraph(adj, allow_nan=True)
+    assert any("sum <= 0" in str(x.message) for x in w)
+    assert (gg.bad_rows, gg.first_bad_row) == (1, bad)
+    np.testing.assert_allclose(gg.rowsum.cpu().numpy(), g["rowsum"], rtol=1e-13)
+    assert np.array_equal(gg.a.h_indptr, g["Ahat_indptr"]) and np.array_equal(gg.a.col.cpu().numpy(), g["Ahat_indices"])
+    got = gg.a.val.cpu().numpy()
+    nan_ref = ~np.isfinite(g["Ahat_data"])
+    assert np.array_equal(~np.isfinite(got), nan_ref) and np.array_equal(np.isnan(got), np.isnan(g["Ahat_data"]))
+    np.testing.assert_allclose(got[~nan_ref], g["Ahat_data"][~nan_ref].astype(np.float32), rtol=1.2e-7, atol=0)
+    # one hop: rows that read the bad node's row of X through a NaN weight, i.e. the bad row and its neighbours (torch.sparse.mm, model.py:163)
+    x = torch.from_numpy(g["X"]).cuda()
+    xp = torch.zeros(n, 16, device="cuda"); xp[:, :8] = x
+    y = torch.empty(n, 16, device="cuda")
+    G._lib.check(G.load().gss_spmm(gg.a.handle, 16, xp.data_ptr(), y.data_ptr(), G._lib.current_stream()))
+    rows = np.repeat(np.arange(n), np.diff(g["Ahat_indptr"]))
+    expect = np.zeros(n, bool); expect[rows[nan_ref]] = True
+    torch.cuda.synchronize()
+    assert np.array_equal((~np.isfinite(y[:, :8].cpu().numpy())).any(1), expect)
+    # the raw entry point on healthy and empty inputs
+    cnt, first = G.graph.rowsum_check(torch.ones(1000, dtype=torch.float64, device="cuda"), 1000)
+    assert (cnt, first) == (0, -1)
+    v = torch.ones(1000, dtype=torch.float64, device="cuda"); v[[7, 300, 999]] = torch.tensor([0.0, -1.0, float("nan")], dtype=torch.float64, device="cuda")
+    assert G.graph.rowsum_check(v, 1000) == (3, 7)
+    assert G.graph.rowsum_check(v, 0) == (0, -1)
+
+
 def test_spmm_row_sums_within_1e5(G, op_case):
     """north_star: SpMM row sums within 1e-5 (fp32) of the host preprocess_graph result."""
     name, g = op_case

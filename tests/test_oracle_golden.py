@@ -21,6 +21,31 @@ def test_preprocess_graph(op_case):
     np.testing.assert_allclose(rowsum, g["rowsum"], rtol=1e-14, atol=0)
 
 
+def test_non_positive_row_sum_gives_the_reference_nan_pattern():
+    """SURVEY a3's hazard, pinned by a reference-generated fixture: a node whose kept similarities are all negative has D_ii < 0, the
+    reference's np.power(rowsum, -0.5) is NaN there and every entry of that node's row and column of A_hat is NaN; the oracle (same
+    arithmetic, no guard) must produce NaN at exactly the same entries and the same values elsewhere"""
+    import warnings
+    g = load_golden("knn_negative_rowsum_n96_d8")
+    n = g["X"].shape[0]
+    adj = O.gen_graph_descriptor(g["X"].astype(np.float64).T, int(g["k"]))
+    ref_a = sp.csr_matrix((g["A_data"], g["A_indices"], g["A_indptr"]), shape=(n, n))
+    assert np.array_equal(adj.indptr, ref_a.indptr) and np.array_equal(adj.indices, ref_a.indices)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a_hat, rowsum = O.preprocess_graph(adj)
+    np.testing.assert_allclose(rowsum, g["rowsum"], rtol=1e-13)
+    assert np.array_equal(np.flatnonzero(~(rowsum > 0)), g["bad_rows"]) and len(g["bad_rows"]) == 1
+    assert np.array_equal(a_hat.indptr, g["Ahat_indptr"]) and np.array_equal(a_hat.indices, g["Ahat_indices"])
+    nan_ref = ~np.isfinite(g["Ahat_data"])
+    assert nan_ref.sum() > 0 and np.array_equal(~np.isfinite(a_hat.data), nan_ref)
+    np.testing.assert_allclose(a_hat.data[~nan_ref], g["Ahat_data"][~nan_ref], rtol=1e-13)
+    # the NaN entries are the bad node's row and column, nothing else
+    rows = np.repeat(np.arange(n), np.diff(a_hat.indptr))
+    bad = int(g["bad_rows"][0])
+    assert np.array_equal(nan_ref, (rows == bad) | (a_hat.indices == bad))
+
+
 def test_knn_graph_matches_reference_gen_graph():
     for name in ("knn_n200_d16_L2", "knn_n2000_d64_L3"):
         g = load_golden(name)
