@@ -39,6 +39,11 @@ PMC_FILE = "r04_spmm_pmc.json"
 PMC_FALLBACK = "r03_spmm_pmc.json"
 PMC_FILE_RMAT10M = "r04_spmm_pmc_rmat10m.json"
 MFMA_F32_PEAK_TFLOPS = 157.3
+GUIDE_HBM_STREAM_TBS = 6.3   # MI355X_MICROARCH.md: "8 TB/s peak (spec); ~6.3 TB/s achievable"
+GUIDE_MALL_STREAM_TBS = 8.6  # MI355X_MICROARCH.md: 38 MB table, uniformly random 512-B rows served by the Infinity Cache
+# the bare gather stream of a workload's own col[] array (col[] streamed, one 512-B / 1-KB row gathered per entry, nothing else): the rate at which
+# the cache hierarchy serves this graph's gathers, measured with tools/micro/gather_hub_lds.py (H = 0 rows) on the GPU box
+GATHER_CEILING = {("whole_graph", 128): {"TBs": 19.37, "source": "profiles/r03_gather_hub_lds_whole_graph.txt: 506 MB of gathers in 26.1 us"}}
 XGMI_LINK_GBS = 153.0        # one xGMI link, one direction (7 links per GPU, one per peer in an 8-GPU node)
 COLLECTIVE_TIMEOUT_S = 300.0 # a stream that does not drain for this long = a peer stopped taking part: abort and exit non-zero
 
@@ -463,7 +468,9 @@ def main():
         "epoch_time_s": ms_per_step * 1e-3 * steps_per_epoch,
         # `value` counts the reference's work (every SpMM at nnz); value_executed counts the entries the kernels actually visited
         "value_executed": edges_executed * args.steps / elapsed,
-        "config": {"workload": f"{args.workload} stand-in: N={n}, nnz(A_hat)={nnz}, d={d}, L={L}, B={B}, "
+        "config": {"workload": f"{args.workload} stand-in (value = {value:.4g} edges/s counts every SpMM at nnz as the reference executes it; "
+                               f"value_executed = {edges_executed * args.steps / elapsed:.4g} counts the entries the kernels visited): "
+                               f"N={n}, nnz(A_hat)={nnz}, d={d}, L={L}, B={B}, "
                                f"{steps_per_epoch} steps/epoch; full train step (fwd+gss_loss+bwd+Adam), "
                                f"{spmm_per_step} SpMMs/step counted at nnz each (algorithmic; the top layer's first backward SpMM "
                                f"visits only entries whose neighbour is a batch row"
@@ -492,6 +499,7 @@ def main():
     # the headline and sum to ms_per_step; both the raw and the corrected launch time are reported.
     if hasattr(engine, "comm_stats"):
         engine.comm_stats()                  # reset: the counts below are those of the profiled steps
+        engine.sync_stats()
     engine.profile(True)
     run(args.warmup, args.warmup + args.steps)
     prof = engine.profile_read()
@@ -563,6 +571,29 @@ def main():
                 if out[key] and name in z.get("hbm_traffic", {}):
                     out[key]["traffic"] = z["hbm_traffic"][name]["traffic_bytes_per_launch"]
                     out[key]["traffic_source"] = f"offline rocprofv3 --pmc profile of the same command: profiles/{os.path.basename(pmc)}"
+        # Which bound binds.  `frac` above is the prescribed one: compulsory bytes against HBM.  A cache-resident
+        # graph (config 2 / 3: the operand fits the Infinity Cache) is bound by the rate at which the L2s serve row gathers -- SURVEY
+        # 8(d)'s bytes_gather = 8 nnz + 4 (N+1) + 4 nnz d + 4 N d per result, against the bare gather stream of the same col[] array
+        # (tools/micro/gather_ceiling.py / gather_hub_lds.py: col[] streamed, 512-B rows gathered, nothing else).  A graph far beyond the
+        # caches (RMAT 10M) is bound by what leaves the L2s: the counters' bytes per launch against the guide's streaming rates.
+        for key, extra in (("roofline", 1), ("roofline_plain", 0)):
+            r = out[key]
+            if not r:
+                continue
+            avg = r["avg_launch_us"] * 1e-6
+            bytes_gather = 8 * nnz_loc + 4 * (n_loc + 1) + 4 * nnz_loc * d + 4 * n_loc * d * (1 + extra) + (4 * n_loc * d if extra else 0)
+            ceil = GATHER_CEILING.get((args.workload, d))
+            r["gather"] = {"bytes_gather": bytes_gather, "achieved": bytes_gather / avg / 1e12, "unit": "TB/s",
+                           "ceiling": ceil["TBs"] if ceil else None, "frac": (bytes_gather / avg / 1e12 / ceil["TBs"]) if ceil else None,
+                           "ceiling_source": ceil["source"] if ceil else "no bare-stream measurement of this graph on file",
+                           "model": "SURVEY 8(d) bytes_gather: 8 nnz + 4 (N+1) + 4 nnz d (one row gather per entry) + 4 N d per result"
+                                    + (" + 4 N d (the Hadamard operand's own rows)" if extra else "")}
+            if r.get("traffic"):
+                r["fabric"] = {"achieved": r["traffic"] / avg / 1e12, "unit": "TB/s", "streaming_hbm": GUIDE_HBM_STREAM_TBS,
+                               "infinity_cache_hit": GUIDE_MALL_STREAM_TBS,
+                               "frac_of_streaming_hbm": r["traffic"] / avg / 1e12 / GUIDE_HBM_STREAM_TBS,
+                               "note": "bytes that left the L2s per launch (roofline.traffic) over the launch time, against the guide's measured "
+                                       "streaming rates (MI355X_MICROARCH.md: HBM 6.3 TB/s, Infinity-Cache-resident 8.6 TB/s)"}
         if out["roofline_plain"]:
             out["spmm_kernel_edges_per_s"] = nnz / (out["roofline_plain"]["avg_launch_us"] * 1e-6)
         # nnz / t_SpMM per launch, forward and backward kinds separately.  spmm_bwd1 at L = 2 is the sparsity-aware
@@ -607,6 +638,11 @@ def main():
                                        "us_each": {k: v[0] / v[1] * 1e3 for k, v in comm_cls.items()},
                                        "note": "gss_plan_comm_stats over the profiled steps; us_each = event bracket around one collective on this "
                                                "rank's stream (pack kernel + transfer for an exchange), the wait for the slowest peer included"}
+        syncs = engine.sync_stats() if hasattr(engine, "sync_stats") else (0, 0)
+        out["host_syncs_per_step"] = {"stream_drains": syncs[0] / args.steps, "request_stream_event_waits": syncs[1] / args.steps,
+                                      "note": "gss_plan_sync_stats over the profiled (full) steps: host waits that drain the caller's stream (the "
+                                              "sender-driven subset exchange of u, knob lazy_halo_u: off over RCCL) / host waits for an event of the "
+                                              "plan's request stream while the caller's stream keeps running (the lazy step's subset exchange of M)"}
         mine = [own_ms_per_step, comm_ms, halo_bytes_a, halo_bytes_t, pair_a, pair_t, out["roofline"]["frac"] if out["roofline"] else 0.0,
                 out["roofline"]["avg_launch_us"] if out["roofline"] else 0.0, n_loc, nnz_loc]
         allv = all_ranks(mine)
@@ -639,9 +675,9 @@ def main():
             rows = all_ranks([lh[3], lh[5]])
             out["xgmi"]["subset_exchange_u"] = {"rows_fetched_last_step_by_rank": rows[:, 0].astype(int).tolist(),
                                                 "rows_of_the_whole_halo_by_rank": rows[:, 1].astype(int).tolist(),
-                                                # a subset hop blocks the host once (gss_comm_sync: stream drain + the 144-byte
-                                                # D2H copy of the per-peer counts); its cost is inside ms_per_step, not inside the comm brackets
-                                                "host_round_trips_per_full_step": 1, "host_round_trips_per_lazy_step": 2,
+                                                # the sender-driven subset hop drains the stream once per step for the counts (gss_comm_sync + the
+                                                # 144-byte D2H copy): inside ms_per_step, not inside the comm brackets; off over RCCL by default
+                                                "stream_drains_per_step": 1,
                                                 "note": "ideal_exchange_us_per_step above is priced on whole halos"}
         fa, ft = shard.layout.halo_fraction()
         halo_info.update({"halo_fraction_a": fa, "halo_fraction_at": ft})

@@ -123,6 +123,9 @@ SIGNATURES = {
     "gss_plan_check_guards": (C.c_int, [_P]),
     "gss_plan_lazy_halo_rows": (C.c_int, [_P, C.POINTER(_I64)]),
     "gss_plan_comm_stats": (C.c_int, [_P, C.POINTER(_I64)]),
+    "gss_plan_sync_stats": (C.c_int, [_P, C.POINTER(_I64)]),
+    "gss_comm_local_mode": (C.c_int, [_P, _I32]),
+    "gss_comm_local_log": (C.c_int, [_P, C.POINTER(_I64), _I32, C.POINTER(_I32)]),
     "gss_plan_set_step": (None, [_P, _I32]),
     "gss_plan_adam_buffer": (_P, [_P, _I32, _I32]),
     "gss_plan_get_step": (_I32, [_P]),

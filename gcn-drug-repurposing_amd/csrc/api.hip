@@ -91,21 +91,6 @@ int set_knob(Knobs &k, const char *name, int value) {
     k.gemm_small_nt = value;
     return GSS_OK;
   }
-  if (strcmp(name, "gemm_prio") == 0) {
-    GSS_REQUIRE(value >= -1, "gemm_prio must be >= -1 (0 = off, -1 = by wave slot)");
-    k.gemm_prio = value;
-    return GSS_OK;
-  }
-  if (strcmp(name, "wgrad_prio") == 0) {
-    GSS_REQUIRE(value >= 0 && value <= 2, "wgrad_prio must be 0, 1 or 2");
-    k.wgrad_prio = value;
-    return GSS_OK;
-  }
-  if (strcmp(name, "gemm_lds_kb") == 0 || strcmp(name, "wgrad_lds_kb") == 0 || strcmp(name, "loss_lds_kb") == 0) {
-    GSS_REQUIRE(value >= 0 && value <= 160, "%s must be in [0, 160] (KB of dynamic LDS per workgroup, 0 = what the kernel needs)", name);
-    (name[0] == 'g' ? k.gemm_lds_kb : name[0] == 'w' ? k.wgrad_lds_kb : k.loss_lds_kb) = value;
-    return GSS_OK;
-  }
   if (strcmp(name, "wgrad_variant") == 0) {
     GSS_REQUIRE(value == 1 || value == 2, "wgrad_variant must be 1 (direct loads) or 2 (LDS-DMA ring)");
     k.wgrad_variant = value;
@@ -123,11 +108,6 @@ int set_knob(Knobs &k, const char *name, int value) {
     k.gemm_hoist = value ? 1 : 0;
     return GSS_OK;
   }
-  if (strcmp(name, "gemm_stagger") == 0) {
-    GSS_REQUIRE(value >= 0 && value <= 256, "gemm_stagger must be in [0, 256] (units of 512 cycles)");
-    k.gemm_stagger = value;
-    return GSS_OK;
-  }
   if (strcmp(name, "gemm_rows_split") == 0) {
     k.gemm_rows_split = value ? 1 : 0;
     return GSS_OK;
@@ -135,6 +115,11 @@ int set_knob(Knobs &k, const char *name, int value) {
   if (strcmp(name, "lazy_halo") == 0) {
     GSS_REQUIRE(value >= -1 && value <= 1, "lazy_halo must be -1 (by graph size), 0 or 1");
     k.lazy_halo = value;   // sharded plans created afterwards; every rank of a job must use the same value
+    return GSS_OK;
+  }
+  if (strcmp(name, "lazy_halo_u") == 0) {
+    GSS_REQUIRE(value >= -1 && value <= 1, "lazy_halo_u must be -1 (automatic), 0 or 1");
+    k.lazy_halo_u = value;   // sharded plans created afterwards; every rank of a job must use the same value
     return GSS_OK;
   }
   if (strcmp(name, "ppr_fused") == 0) {
@@ -161,12 +146,13 @@ int set_knob(Knobs &k, const char *name, int value) {
     return GSS_OK;
   }
   if (strcmp(name, "gemm_variant") == 0) {
-    GSS_REQUIRE(value >= 1 && value <= 5, "gemm_variant must be 1..5");
+    GSS_REQUIRE(value == 2 || value == 3 || value == 5, "gemm_variant must be 2 (automatic), 3 (128-node tiles, four waves) or 5 (128-node tiles, eight waves)");
     k.gemm_variant = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_ws") == 0) {
-    k.gemm_ws = value ? 1 : 0;
+    GSS_REQUIRE(value >= -1 && value <= 1, "gemm_ws must be -1 (by row count), 0 or 1");
+    k.gemm_ws = value;
     return GSS_OK;
   }
   if (strcmp(name, "gemm_ws_wgs") == 0) {

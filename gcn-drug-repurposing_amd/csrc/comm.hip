@@ -230,8 +230,60 @@ __global__ __launch_bounds__(256) void local_sum_kernel(size_t count, int world,
   out[i] = s;
 }
 
+// Record / replay (gss_comm_local_mode; tools/shard_emulation.py --serial): ranks that are threads of one process share ONE GPU, so a step
+// timed with all of them running says nothing about one rank's kernels.  Mode 1 keeps a device copy of what every collective DELIVERED to
+// this rank, in call order; mode 2 serves those copies again -- same call sequence, same sizes (checked), a device-to-device copy instead of
+// the peers, no barrier, no host wait -- so that ONE rank's step can run alone on the GPU and be timed kernel by kernel.  Mode 0 (the
+// default) frees the log.  The replayed payloads are the recorded step's (stale by the weight updates since): a timing aid, not a result.
+struct CommLog {
+  struct Rec {
+    void *buf = nullptr;
+    size_t bytes = 0;
+  };
+  int mode = 0;
+  std::vector<Rec> recs;
+  size_t cursor = 0;
+  ~CommLog() { clear(); }
+  void clear() {
+    for (Rec &r : recs)
+      if (r.buf) (void)hipFree(r.buf);
+    recs.clear();
+    cursor = 0;
+  }
+  int keep(const void *src, size_t bytes, hipStream_t st) {   // mode 1: after the payload has landed (stream order)
+    Rec r;
+    r.bytes = bytes;
+    if (bytes) {
+      GSS_HIP(hipMalloc(&r.buf, bytes));
+      GSS_HIP(hipMemcpyAsync(r.buf, src, bytes, hipMemcpyDeviceToDevice, st));
+    }
+    recs.push_back(r);
+    return GSS_OK;
+  }
+  int serve(void *dst, size_t bytes, hipStream_t st) {        // mode 2
+    if (cursor >= recs.size()) return fail(GSS_EINVAL, "local comm replay: collective %zu was never recorded (%zu in the log)", cursor, recs.size());
+    const Rec &r = recs[cursor];
+    if (r.bytes != bytes) return fail(GSS_EINVAL, "local comm replay: collective %zu delivers %zu bytes, the recorded one %zu", cursor, bytes, r.bytes);
+    ++cursor;
+    if (bytes) GSS_HIP(hipMemcpyAsync(dst, r.buf, bytes, hipMemcpyDeviceToDevice, st));
+    return GSS_OK;
+  }
+};
+
 struct LocalComm final : gss_comm {
   std::shared_ptr<LocalShared> sh;
+  CommLog log;
+  int set_mode(int mode) override {
+    if (mode == 0 || mode == 1) log.clear();
+    log.cursor = 0;
+    log.mode = mode;
+    return GSS_OK;
+  }
+  int log_bytes(int64_t *out, int32_t cap, int32_t *n_out) override {
+    *n_out = (int32_t)log.recs.size();
+    for (int32_t k = 0; k < cap && k < *n_out; ++k) out[k] = (int64_t)log.recs[(size_t)k].bytes;
+    return GSS_OK;
+  }
   void abort() override { sh->abort(); }
   int check_async() override {
     std::lock_guard<std::mutex> lk(sh->mu);
@@ -254,6 +306,7 @@ struct LocalComm final : gss_comm {
     if (tmp) (void)hipFree(tmp);
   }
   int all_gather(const void *send, void *recv, size_t bytes_per_rank, hipStream_t st) override {
+    if (log.mode == 2) return log.serve(recv, bytes_per_rank * (size_t)world, st);
     GSS_HIP(hipStreamSynchronize(st));  // my rows are complete before a peer copies them
     sh->src[(size_t)rank] = send;
     if (int rc = sh->wait()) return rc;
@@ -261,10 +314,13 @@ struct LocalComm final : gss_comm {
       char *dst = (char *)recv + (size_t)r * bytes_per_rank;
       if ((const void *)dst != sh->src[(size_t)r]) GSS_HIP(hipMemcpyAsync(dst, sh->src[(size_t)r], bytes_per_rank, hipMemcpyDeviceToDevice, st));
     }
+    if (log.mode == 1)
+      if (int rc = log.keep(recv, bytes_per_rank * (size_t)world, st)) return rc;
     GSS_HIP(hipStreamSynchronize(st));
     return sh->wait();  // nobody overwrites its send buffer while a peer still reads it
   }
   int exchange_rows(const float *send, const int64_t *send_off, float *recv, const int64_t *recv_off, int d, hipStream_t st) override {
+    if (log.mode == 2) return log.serve(recv, sizeof(float) * (size_t)recv_off[world] * d, st);
     GSS_HIP(hipStreamSynchronize(st));  // my packed rows are complete
     sh->src[(size_t)rank] = send;
     sh->off[(size_t)rank] = send_off;
@@ -278,10 +334,17 @@ struct LocalComm final : gss_comm {
       const float *src = (const float *)sh->src[(size_t)q] + (size_t)sh->off[(size_t)q][rank] * d;
       GSS_HIP(hipMemcpyAsync(recv + (size_t)recv_off[q] * d, src, sizeof(float) * (size_t)nr * d, hipMemcpyDeviceToDevice, st));
     }
+    if (log.mode == 1)
+      if (int rc = log.keep(recv, sizeof(float) * (size_t)recv_off[world] * d, st)) return rc;
     GSS_HIP(hipStreamSynchronize(st));
     return sh->wait();
   }
   int all_reduce_sum(float *const *bufs, const size_t *counts, int nbuf, hipStream_t st) override {
+    if (log.mode == 2) {
+      for (int k = 0; k < nbuf; ++k)
+        if (int rc = log.serve(bufs[k], sizeof(float) * counts[k], st)) return rc;
+      return GSS_OK;
+    }
     for (int k = 0; k < nbuf; ++k) {
       const size_t count = counts[k];
       if (tmp_floats < count * (size_t)world) {
@@ -301,6 +364,8 @@ struct LocalComm final : gss_comm {
         hipLaunchKernelGGL(local_sum_kernel, dim3(ceil_div((int64_t)count, 256)), dim3(256), 0, st, count, world, tmp, bufs[k]);
         GSS_LAUNCH_CHECK("local_sum_kernel");
       }
+      if (log.mode == 1)
+        if (int rc = log.keep(bufs[k], sizeof(float) * count, st)) return rc;
     }
     return GSS_OK;
   }
@@ -463,6 +528,16 @@ int gss_comm_create_local(gss_comm **out, int32_t world) {
   return GSS_OK;
 }
 
+int gss_comm_local_mode(gss_comm *c, int32_t mode) {
+  GSS_REQUIRE(c && mode >= 0 && mode <= 2, "comm_local_mode: bad argument");
+  GSS_REQUIRE(c->set_mode(mode) == GSS_OK, "comm_local_mode: only the in-process backend (gss_comm_create_local) records and replays");
+  return GSS_OK;
+}
+int gss_comm_local_log(gss_comm *c, int64_t *bytes_out, int32_t cap, int32_t *n_out) {
+  GSS_REQUIRE(c && n_out && (cap == 0 || bytes_out), "comm_local_log: bad argument");
+  GSS_REQUIRE(c->log_bytes(bytes_out, cap, n_out) == GSS_OK, "comm_local_log: only the in-process backend keeps a log");
+  return GSS_OK;
+}
 void gss_comm_destroy(gss_comm *c) { delete c; }
 void gss_comm_abort(gss_comm *c) {
   if (c) c->abort();

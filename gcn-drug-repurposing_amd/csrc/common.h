@@ -24,30 +24,26 @@ struct Knobs {
   int spmm_hot = -1;         // overrides every CSR's hot set with rows [0, value) (-1 = the CSR's own, 0 = none)
   int spmm_fly = 4;          // row gathers in flight per lane group on the large-table path (4 or 8)
   int seg_edges = 32;        // entries per SpMM segment (CSR handles created afterwards)
-  int gemm_variant = 2;      // 1 = L1/L2-fed GEMM, 2 = LDS-DMA staged (default), 3 / 4 = forced 128- / 64-node tiles
+  int gemm_variant = 2;      // projection tile shape: 2 = by width and row count (default), 3 = 128-node tiles of four waves forced, 5 = of eight waves forced
   int gemm_nt_cap = 0;       // cap of the feature tile width (16-feature units), 0 = none
   int gemm_small_nt = 2;     // narrowest feature tile for small problems, 0 = never narrow
   int gemm_rows_split = 1;   // forward projection over a short row list: 4 waves per 16 listed rows that split the features (0 = one wave per tile)
-  int gemm_prio = 0;         // static wave priority experiment of the projection (0 = off; see dense.hip)
   int wgrad_deep = 2;        // weight-gradient reduce: Adam's state / the batch ids requested first, slabs fetched sixteen at a time (1 = eight; 0 = four, state fetched late)
   int gemm_lines = 1;        // forward projection's epilogue in whole 128-B lines (neighbouring lanes swap feature blocks first; 0 = the MFMA layout's half lines)
   int gemm_hoist = 1;        // forward projection: biases / previous layer's P / batch-position map requested ahead of the K loop (0 = in the epilogue)
-  int gemm_stagger = 0;      // second-generation projection workgroups start this many x 512 cycles late (0 = off)
-  int gemm_ws = 0;           // d = 128 forward projection without a row list: weight-stationary persistent kernel (proj_ws_kernel; 0 = the staged tiles)
-  int gemm_ws_wgs = 256;     // its persistent workgroups (one per CU)
+  int gemm_ws = -1;          // d = 128 forward projection without a row list: weight-stationary persistent kernel (proj_ws_kernel) -- -1 = from
+                             // kWsMinRows rows on (dense.hip: there a workgroup walks >= 16 tiles and the 5 us it spends fetching its weights pay), 0 = never, 1 = always
+  int gemm_ws_wgs = 512;     // its persistent workgroups (two per CU)
   int gemm_ws_mode = 1;      // bit 0: its L2 warm-up pass, bit 1: its weights fetched in whole 128-B lines (lanes trade halves afterwards)
-  int gemm_ws_stagger = 0;   // its second generation of workgroups (linear id >= 256) starts this many x 512 cycles late (0 = together)
-  int wgrad_prio = 0;        // the same for the weight gradient
+  int gemm_ws_stagger = 4;   // its second generation of workgroups (linear id >= 256) starts this many x 512 cycles late (0 = together)
   int wgrad_variant = 1;     // 1 = operands by direct loads from L2, 2 = by LDS-DMA into a per-wave ring, one trip ahead (same bits)
   int wgrad_wgs = 256;       // workgroups of a full-size weight-gradient launch (sizes the plan's partial buffer)
   int xcd_remap = 1;         // workgroups that share input rows on one XCD
   int loss_wgs = 256;        // workgroups the loss sweep's grid aims at
   int sparse_bits_rows = 100000;  // operand rows from which a plan keeps the bitmaps of the sparsity-aware backward hops
-  // occupancy control by LDS footprint (KB of dynamic LDS requested per workgroup, 0 = what the kernel needs): the hardware dispatcher
-  // places as many workgroups on a CU as fit, not one per CU -- a grid of 256 "one per CU" workgroups may double up on some CUs and
-  // leave others idle.  > 80 KB admits one workgroup per CU, 54-80 KB two.
-  int gemm_lds_kb = 0, wgrad_lds_kb = 0, loss_lds_kb = 0;
   int lazy_halo = -1;        // sharded lazy step: fetch only the boundary rows of the top layer's M that the batch rows read (-1 = graphs of >= 262,144 nodes, 0 = never, 1 = always)
+  int lazy_halo_u = -1;      // the same for u in the top layer's second backward hop (sender-driven: costs one drain of the stream per step for the counts):
+                             // -1 = with lazy_halo, but not over RCCL (there the hop runs exchange-free on the shard's A_hat transposed in place), 0 = never, 1 = with lazy_halo
   int ppr_fused = 1;         // diffusion profiles: the update and the column errors in the SpMM's epilogue (0 = separate update pass)
   int loss_dgrad = -1;       // finish + normalise' / ELU' + the batch rows' input gradient in one launch, d in {64, 128, 256}: -1 = on shards only
                              // (it spares a collective there; on one GPU two launches are 1.9 us faster), 0 = never, 1 = always
@@ -59,9 +55,8 @@ struct Knobs {
                              // (-1 = automatic = on, 0 = never, 1 = always; every rank of a job must use the same value)
 };
 template <typename F>
-inline size_t lds_request(F kernel, size_t need, int knob_kb) {
-  size_t lds = need;
-  if (knob_kb > 0 && (size_t)knob_kb * 1024 > lds) lds = (size_t)knob_kb * 1024;
+inline size_t lds_request(F kernel, size_t need) {
+  const size_t lds = need;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   return lds;
 }
@@ -134,6 +129,17 @@ __device__ __forceinline__ float4 fma4(float s, float4 x, float4 a) {
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 scale4(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+// a row of F.normalize (modules/model.py:205): x / max(||x||, eps)
+#ifndef GSS_NORM_DIV
+#define GSS_NORM_DIV 0
+#endif
+__device__ __forceinline__ float4 unit4(float den, float4 a) {
+#if GSS_NORM_DIV
+  return make_float4(__fdiv_rn(a.x, den), __fdiv_rn(a.y, den), __fdiv_rn(a.z, den), __fdiv_rn(a.w, den));
+#else
+  return scale4(1.f / den, a);
+#endif
+}
 
 // F.elu (alpha = 1) and its derivative expressed through the pre-activation
 // torch's elu is exp(x) - 1 for x <= 0 (ATen/native/cpu/Activation.cpp), not expm1; expf - 1 is also a fraction of expm1f's cost

@@ -1,14 +1,13 @@
 // dense.hip -- the dense half of the GSS layer on fp32 MFMA (K3/K4/K8 of SURVEY.md section 2b).
 //
-//   gemm_nt_kernel   OUT[n][j] = sum_k IN[n][k] * W[j][k]      (both operands K-contiguous)
+//   gemm_nt_lds_kernel / proj_ws_kernel   OUT[n][j] = sum_k IN[n][k] * W[j][k]      (both operands K-contiguous)
 //       forward  : P = [AX|AM] . [W1|W2]^T + b1 + b2, O = ELU(P), x_next = P_prev + decay O
 //                  (nn.Linear x2 + add + F.elu + residual, modules/model.py:165,170-173,201-203)
 //       backward : [g_ax | g_am] = dP . [W1 ; W2]  using pre-transposed weights
 //   wgrad_tn_kernel  dW[f][k] = sum_n dP[n][f] * Z[n][k]        (reduction over the node dimension)
 //
-// MFMA: v_mfma_f32_16x16x4_f32 (exact fp32, 256 FLOP/clk/CU).  gemm_nt_kernel (gemm_variant 1, kept for A/B)
-// loads its operands as float4 per lane straight from L1/L2; the default is the LDS-DMA staged
-// gemm_nt_lds_kernel further down, which cuts the L2->L1 traffic sixfold.  The float4's four elements
+// MFMA: v_mfma_f32_16x16x4_f32 (exact fp32, 256 FLOP/clk/CU).  Operands reach the MFMAs through LDS (LDS-DMA staged tiles; round 1's
+// L1/L2-fed form moved six times the L2->L1 traffic and is gone).  A float4's four elements
 // feed four consecutive k-steps: a k-chunk of 16 is consumed in the order k = kc + 4*(lane>>4) + e,
 // a permutation of the reduction order that both operands share.
 // The operands are swapped (A = weights, B = node rows) so that each lane ends up with 4 consecutive
@@ -49,111 +48,10 @@ struct GemmArgs {
   float *rows_out;      // EPI_FWD_NORM over a row list (nullable): the unit-norm row of tile row t ALSO goes to rows_out[t] -- the lazy step's
                         // tile rows are the batch positions, so this IS E_B = emb[idx] (model.py:216-217) without a gather launch
   int xcd_remap;        // renumber the workgroups so that those sharing input rows sit on one XCD (xcd_ids below)
-  int prio_cut;         // > 0: workgroups whose linear id is below it raise their wave priority (debug knob "gemm_prio")
   int hoist;            // the epilogue's operands are requested ahead of the K loop (knob "gemm_hoist", default 1)
-  int stagger;          // > 0: workgroups of the second generation (linear id >= 256) start this many x 512 cycles late (knob "gemm_stagger")
   unsigned long long *stamps;  // diagnostic (gss_debug_set_stamp_buffer, NULL in production): per wave {start, loop begin, loop end, end} in
                                // 100 MHz wall-clock ticks + {linear workgroup id, HW_ID}; tools/gemm_stamps.py reads it
 };
-
-template <int FT, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
-  const int lane = threadIdx.x & 63;
-  const int wib = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int node0 = (blockIdx.x * 4 + wib) * 32;
-  if (node0 >= g.n) return;
-  const int j0 = blockIdx.y * (16 * FT);
-  const int jh = j0 >= g.jsplit ? 1 : 0;
-  const int jrow0 = j0 - (jh ? g.jsplit : 0);
-
-  int node[2];
-  node[0] = min(g.n - 1, node0 + r);
-  node[1] = min(g.n - 1, node0 + 16 + r);
-
-  f32x4 acc[2][FT];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int u = 0; u < FT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // operand row pointers for both halves of K (k < ksplit from in0 / w[.][0], the rest from in1 / w[.][1])
-  const float *bp[2][2];
-  const float *ap[2][FT];
-#pragma unroll
-  for (int kh = 0; kh < 2; ++kh) {
-    const float *in = kh ? g.in1 : g.in0;
-    const int ld = kh ? g.ld_in1 : g.ld_in0;
-    const float *w = g.w[jh][kh];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) bp[kh][t] = in ? in + (size_t)node[t] * ld + 4 * q : nullptr;
-#pragma unroll
-    for (int u = 0; u < FT; ++u) ap[kh][u] = w ? w + (size_t)(jrow0 + 16 * u + r) * g.ld_w + 4 * q : nullptr;
-  }
-  const int nchunk = g.K / 16;
-  const int csplit = g.ksplit / 16;
-
-  auto load_chunk = [&](int ci, float4 (&b)[2], float4 (&a)[FT]) {
-    const int kh = ci >= csplit ? 1 : 0;
-    const int off = (ci - (kh ? csplit : 0)) * 16;
-    b[0] = ld4(bp[kh][0] + off);
-    b[1] = ld4(bp[kh][1] + off);
-#pragma unroll
-    for (int u = 0; u < FT; ++u) a[u] = ld4(ap[kh][u] + off);
-  };
-  auto mma_chunk = [&](const float4 (&b)[2], const float4 (&a)[FT]) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const float bv = e == 0 ? b[t].x : e == 1 ? b[t].y : e == 2 ? b[t].z : b[t].w;
-#pragma unroll
-        for (int u = 0; u < FT; ++u) {
-          const float av = e == 0 ? a[u].x : e == 1 ? a[u].y : e == 2 ? a[u].z : a[u].w;
-          acc[t][u] = mfma16(av, bv, acc[t][u]);
-        }
-      }
-    }
-  };
-  // register double buffer: the loads of chunk c+1 are in flight under the 8*FT MFMAs of chunk c
-  float4 b0[2], a0[FT], b1[2], a1[FT];
-  load_chunk(0, b0, a0);
-  int ci = 0;
-  for (; ci + 2 <= nchunk; ci += 2) {
-    load_chunk(ci + 1, b1, a1);
-    mma_chunk(b0, a0);
-    if (ci + 2 < nchunk) load_chunk(ci + 2, b0, a0);
-    mma_chunk(b1, a1);
-  }
-  if (ci < nchunk) mma_chunk(b0, a0);
-
-  // epilogue: lane (r, q) holds OUT[node0 + 16 t + r][j0 + 16 u + 4 q + 0..3]
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int nd = node0 + 16 * t + r;
-    if (nd >= g.n) continue;
-#pragma unroll
-    for (int u = 0; u < FT; ++u) {
-      const int j = j0 + 16 * u + 4 * q;
-      float4 v = make_float4(acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]);
-      if (EPI == EPI_FWD) {
-        const float4 bb = add4(ld4(g.b1 + j), ld4(g.b2 + j));
-        const float4 p = add4(v, bb);
-        const size_t off = (size_t)nd * g.ld_out0 + j;
-        st4(g.out0 + off, p);
-        float4 o = make_float4(elu1(p.x), elu1(p.y), elu1(p.z), elu1(p.w));
-        if (g.p_prev) o = add4(ld4(g.p_prev + off), scale4(g.decay, o));
-        st4(g.x_next + off, o);
-      } else {
-        const int orow = g.rows ? g.rows[nd] : nd;
-        if (jh == 0)
-          st4(g.out0 + (size_t)orow * g.ld_out0 + j, v);
-        else
-          st4(g.out1 + (size_t)orow * g.ld_out1 + (j - g.jsplit), v);
-      }
-    }
-  }
-}
 
 // Epilogue of the forward projection for one 16-node x 16 NT tile row: lane (r, q) holds OUT[nd][j0 + 16 u + 4 q + 0..3]
 // in acc[u].  All loads (biases, previous layer's P) are issued before the first store: the stores may alias them as
@@ -247,7 +145,7 @@ __device__ __forceinline__ void fwd_epilogue_lines(const GemmArgs &g, const f32x
       o1[m] = add4(f.pp[NT / 2 + m], scale4(g.decay, o1[m]));
     }
   }
-  float inv0 = 1.f, inv1 = 1.f;
+  float den0 = 1.f, den1 = 1.f;
   if (EPI == EPI_FWD_NORM) {
     // F.normalize (modules/model.py:205).  The even lane collects the squares of the pair's first row, the odd lane those of the second
     // (its neighbour's come by one swap per block), added in block order u = 0 .. NT - 1 like the MFMA-layout form does; then the same
@@ -262,9 +160,9 @@ __device__ __forceinline__ void fwd_epilogue_lines(const GemmArgs &g, const f32x
     }
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
-    const float mine = 1.f / fmaxf(sqrtf(ss), 1e-12f), other = swap_neighbour(mine);
-    inv0 = odd ? other : mine;
-    inv1 = odd ? mine : other;
+    const float mine = fmaxf(sqrtf(ss), 1e-12f), other = swap_neighbour(mine);
+    den0 = odd ? other : mine;
+    den1 = odd ? mine : other;
   }
 #pragma unroll
   for (int m = 0; m < NT / 2; ++m) {
@@ -272,19 +170,19 @@ __device__ __forceinline__ void fwd_epilogue_lines(const GemmArgs &g, const f32x
     if (f.live) {
       const size_t off = (size_t)f.ndc * g.ld_out0 + j;
       st4(g.out0 + off, pv0[m]);
-      st4(g.x_next + off, EPI == EPI_FWD_NORM ? scale4(inv0, o0[m]) : o0[m]);
-      if (EPI == EPI_FWD_NORM && g.rows_out && f.out_row >= 0) st4(g.rows_out + (size_t)f.out_row * g.ld_out0 + j, scale4(inv0, o0[m]));
+      st4(g.x_next + off, EPI == EPI_FWD_NORM ? unit4(den0, o0[m]) : o0[m]);
+      if (EPI == EPI_FWD_NORM && g.rows_out && f.out_row >= 0) st4(g.rows_out + (size_t)f.out_row * g.ld_out0 + j, unit4(den0, o0[m]));
     }
     if (f.live1) {
       const size_t off = (size_t)f.ndc1 * g.ld_out0 + j;
       st4(g.out0 + off, pv1[m]);
-      st4(g.x_next + off, EPI == EPI_FWD_NORM ? scale4(inv1, o1[m]) : o1[m]);
-      if (EPI == EPI_FWD_NORM && g.rows_out && f.out_row1 >= 0) st4(g.rows_out + (size_t)f.out_row1 * g.ld_out0 + j, scale4(inv1, o1[m]));
+      st4(g.x_next + off, EPI == EPI_FWD_NORM ? unit4(den1, o1[m]) : o1[m]);
+      if (EPI == EPI_FWD_NORM && g.rows_out && f.out_row1 >= 0) st4(g.rows_out + (size_t)f.out_row1 * g.ld_out0 + j, unit4(den1, o1[m]));
     }
   }
   if (EPI == EPI_FWD_NORM && q == 0) {
-    if (!odd && f.live) g.inv_den[f.ndc] = inv0;
-    if (odd && f.live1) g.inv_den[f.ndc1] = inv1;
+    if (!odd && f.live) g.inv_den[f.ndc] = 1.f / den0;
+    if (odd && f.live1) g.inv_den[f.ndc1] = 1.f / den1;
   }
 }
 template <int NT, int EPI, bool LINES = false>
@@ -329,13 +227,13 @@ __device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&ac
     if (g.p_prev) o[u] = add4(f.pp[u], scale4(g.decay, o[u]));
     ss = __fadd_rn(ss, sumsq4(o[u]));
   }
-  float inv = 1.f;
+  float den = 1.f;
   if (EPI == EPI_FWD_NORM) {
     // last layer: F.normalize (modules/model.py:205).  The tile row spans all d features, so the 4 lanes q = 0..3 of a
     // node hold its whole row; the sum of squares is reduced with two xor-shuffles.
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
-    inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    den = fmaxf(sqrtf(ss), 1e-12f);
   }
   if (!f.live) return;
   const int out_row = f.out_row;
@@ -343,10 +241,10 @@ __device__ __forceinline__ void fwd_epilogue(const GemmArgs &g, const f32x4 (&ac
   for (int u = 0; u < NT; ++u) {
     const size_t off = (size_t)ndc * g.ld_out0 + j0 + 16 * u + 4 * q;   // ndc == nd for a live row without a row list
     st4(g.out0 + off, pv[u]);
-    st4(g.x_next + off, EPI == EPI_FWD_NORM ? scale4(inv, o[u]) : o[u]);
-    if (EPI == EPI_FWD_NORM && g.rows_out && out_row >= 0) st4(g.rows_out + (size_t)out_row * g.ld_out0 + j0 + 16 * u + 4 * q, scale4(inv, o[u]));
+    st4(g.x_next + off, EPI == EPI_FWD_NORM ? unit4(den, o[u]) : o[u]);
+    if (EPI == EPI_FWD_NORM && g.rows_out && out_row >= 0) st4(g.rows_out + (size_t)out_row * g.ld_out0 + j0 + 16 * u + 4 * q, unit4(den, o[u]));
   }
-  if (EPI == EPI_FWD_NORM && q == 0) g.inv_den[ndc] = inv;
+  if (EPI == EPI_FWD_NORM && q == 0) g.inv_den[ndc] = 1.f / den;
 }
 
 // (the stand-alone form: everything fetched right in front of the arithmetic -- kernels that do not hoist it)
@@ -439,16 +337,6 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void gemm_nt_lds_kernel(GemmArgs 
     stamp[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | ((16 - 1) << 11));
   }
   const XcdIds id = xcd_ids(linear, (int)gridDim.x, (int)gridDim.y, g.xcd_remap != 0);
-  // The first generation of workgroups (one per CU) and the ones that double up on the CUs start together and otherwise run in
-  // lockstep: shared MFMA pipe at half rate each, then both store at once.  With the first generation at a higher wave priority it
-  // takes the pipe, finishes early and stores while the second generation computes (MI355X guide, 'static priority').  Speed only.
-  if (g.prio_cut > 0 && linear < g.prio_cut) __builtin_amdgcn_s_setprio(3);
-  // prio_cut < 0: by wave slot instead -- the waves a SIMD received first (even HW_ID.wave_id) win the pipe, whatever the dispatch order was
-  // de-phasing experiment: the second generation of workgroups (those that double up on the CUs) waits a fraction of a K chunk, so that
-  // its per-chunk barrier / fragment-read bubbles fall under the first generation's MFMAs instead of coinciding with its bubbles
-  if (g.stagger > 0 && linear >= 256)
-    for (int k = 0; k < g.stagger; ++k) __builtin_amdgcn_s_sleep(8);
-  if (g.prio_cut < 0 && (__builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11)) & 1u) == 0u) __builtin_amdgcn_s_setprio(3);
   const int node_base = id.spread * BM;
   const int j0 = id.share * BN;
   const int jh = j0 >= g.jsplit ? 1 : 0;
@@ -861,7 +749,7 @@ __global__ __launch_bounds__(256, 1) void proj_ws_kernel(GemmArgs g, int stagger
       o0 = add4(pp0, scale4(g.decay, o0));
       o1 = add4(pp1, scale4(g.decay, o1));
     }
-    float inv0 = 1.f, inv1 = 1.f;
+    float den0 = 1.f, den1 = 1.f;
     if (EPI == EPI_FWD_NORM) {
       // F.normalize (modules/model.py:205): this lane's two partial sums -- rows (r & ~1) and (r | 1), block 2 w + odd -- go to LDS;
       // behind the barrier the lane adds its own row's eight blocks in block order, then the two shuffles over q of the other forms
@@ -883,27 +771,27 @@ __global__ __launch_bounds__(256, 1) void proj_ws_kernel(GemmArgs g, int stagger
       ss = __fadd_rn(ss, s1.w);
       ss += __shfl_xor(ss, 16, 64);
       ss += __shfl_xor(ss, 32, 64);
-      const float mine = 1.f / fmaxf(sqrtf(ss), 1e-12f), other = swap_neighbour(mine);
-      inv0 = odd ? other : mine;
-      inv1 = odd ? mine : other;
+      const float mine = fmaxf(sqrtf(ss), 1e-12f), other = swap_neighbour(mine);
+      den0 = odd ? other : mine;
+      den1 = odd ? mine : other;
     } else {
       __builtin_amdgcn_s_barrier();   // every wave has read this tile's slot and has the next tile's pieces in
     }
     if (live0) {
       const size_t off = (size_t)nd0 * g.ld_out0 + j;
       st4(g.out0 + off, pv0);
-      st4(g.x_next + off, EPI == EPI_FWD_NORM ? scale4(inv0, o0) : o0);
-      if (EPI == EPI_FWD_NORM && orow0 >= 0) st4(g.rows_out + (size_t)orow0 * g.ld_out0 + j, scale4(inv0, o0));
+      st4(g.x_next + off, EPI == EPI_FWD_NORM ? unit4(den0, o0) : o0);
+      if (EPI == EPI_FWD_NORM && orow0 >= 0) st4(g.rows_out + (size_t)orow0 * g.ld_out0 + j, unit4(den0, o0));
     }
     if (live1) {
       const size_t off = (size_t)nd1 * g.ld_out0 + j;
       st4(g.out0 + off, pv1);
-      st4(g.x_next + off, EPI == EPI_FWD_NORM ? scale4(inv1, o1) : o1);
-      if (EPI == EPI_FWD_NORM && orow1 >= 0) st4(g.rows_out + (size_t)orow1 * g.ld_out0 + j, scale4(inv1, o1));
+      st4(g.x_next + off, EPI == EPI_FWD_NORM ? unit4(den1, o1) : o1);
+      if (EPI == EPI_FWD_NORM && orow1 >= 0) st4(g.rows_out + (size_t)orow1 * g.ld_out0 + j, unit4(den1, o1));
     }
     if (EPI == EPI_FWD_NORM && w == 0 && q == 0) {
-      if (!odd && live0) g.inv_den[nd0] = inv0;
-      if (odd && live1) g.inv_den[nd1] = inv1;
+      if (!odd && live0) g.inv_den[nd0] = 1.f / den0;
+      if (odd && live1) g.inv_den[nd1] = 1.f / den1;
     }
     if (STAMP && stamp && lane == 0 && i < 9) stamp->t[3 + 2 * i] = wall_clock64();
   }
@@ -924,22 +812,20 @@ __global__ __launch_bounds__(256, 1) void proj_ws_kernel(GemmArgs g, int stagger
 
 // debug knob "wgrad_wgs": workgroups of a full-size weight-gradient launch (one per CU)   [knob wgrad_wgs, common.h Knobs]
 // debug knob "xcd_remap": workgroups that share input rows on one XCD (xcd_ids)   [knob xcd_remap, common.h Knobs]
-// debug knob "gemm_prio": linear workgroup ids below it run at raised wave priority (0 = off)   [knob gemm_prio, common.h Knobs]
-// debug knob "wgrad_prio": 1 = waves 4-7 of a weight-gradient workgroup at priority 1, 2 = waves 0-3   [knob wgrad_prio, common.h Knobs]
 // debug knob "gemm_small_nt": narrowest feature tile (in 16-feature units) for small problems, 0 = never narrow   [knob gemm_small_nt, common.h Knobs]
 
 unsigned long long *g_gemm_stamps = nullptr;   // gss_debug_set_stamp_buffer: diagnostic only, process-wide, not a knob
+
+constexpr int kWsMinRows = 131072;   // gemm_ws = -1: the weight-stationary projection from this many rows on
 
 template <int EPI>
 static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
   if (g_in.n <= 0) return GSS_OK;
   GemmArgs g = g_in;
   g.xcd_remap = K().xcd_remap;
-  g.prio_cut = K().gemm_prio;
-  g.stagger = K().gemm_stagger;
   g.hoist = K().gemm_hoist;
   g.stamps = g_gemm_stamps;
-  if (K().gemm_variant >= 2) {
+  {
     int nt = (d % 128 == 0) ? 8 : (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
     if (K().gemm_nt_cap > 0 && EPI != EPI_FWD_NORM)   // debug knob "gemm_nt_cap": narrower feature tiles (the fused normalise needs whole rows)
       while (nt > K().gemm_nt_cap) nt >>= 1;
@@ -950,7 +836,7 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
     // 64-node tiles give 2-3 co-resident workgroups per CU (epilogue traffic overlaps MFMA); at d >= 256 the
     // W-staging redundancy of small tiles costs more than that buys (measured, tools/gemm_bench.py), and so it does once
     // the grid is many waves of workgroups deep (d = 128: N = 1M 791 -> 753 us, N = 4M 3061 -> 2913 us with 128-node tiles)
-    const int mt = K().gemm_variant == 3 ? 2 : K().gemm_variant == 4 ? 1 : ((d >= 256 || g.n >= 262144) ? 2 : 1);
+    const int mt = K().gemm_variant == 3 ? 2 : ((d >= 256 || g.n >= 262144) ? 2 : 1);
     if (EPI != EPI_SPLIT && g.rows && (int64_t)ceil_div(g.n, 64) * (g.J / (16 * nt)) < 256) {
       // forward over a short row list: 16 listed rows per workgroup.  Whole rows of 64 / 128 / 256 features: 4 waves that split the
       // features (gemm_rows_split_kernel, same bits); other widths: one wave per 16 x 16 nt tile
@@ -978,8 +864,12 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
       return GSS_OK;
     }
     if constexpr (EPI != EPI_SPLIT) {
-      // d = 128, all rows: the weight-stationary persistent kernel (round 5; proj_ws_kernel above).  Same bits as the staged tiles.
-      if (K().gemm_ws && K().gemm_variant == 2 && d == 128 && g.K == 256 && g.J == 128 && !g.rows && g.in1 && (!g.rows_out || g.rows_out_pos)) {
+      // d = 128, all rows: the weight-stationary persistent kernel (round 5; proj_ws_kernel above).  Same bits as the staged tiles.  It
+      // spends ~5 us per workgroup pulling its 128 KB of weights before the first MFMA and earns that back tile by tile: slower than the
+      // staged tiles at N = 29,960 (31 vs 28 us), 10-11 % faster from 250k rows on (0.63-0.64 of the fp32-MFMA peak against 0.57-0.58;
+      // profiles/r05_proj_ws_bench.txt) -- automatic from kWsMinRows rows on.
+      const bool ws = K().gemm_ws == 1 || (K().gemm_ws < 0 && g.n >= kWsMinRows);
+      if (ws && K().gemm_variant == 2 && d == 128 && g.K == 256 && g.J == 128 && !g.rows && g.in1 && (!g.rows_out || g.rows_out_pos)) {
         const int ntiles = ceil_div(g.n, 16);
         const int wgs = std::min(ntiles, K().gemm_ws_wgs);
         const size_t ldsw = (size_t)(3 * 16 * 256 + 2 * 512) * sizeof(float);
@@ -1009,7 +899,7 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
       // the 16-node tile's 104-110 registers (no hoisted operands, the whole-line epilogue), so two such workgroups share a CU: 16
       // waves per CU instead of 8.  Same MFMA order per output, same bits.  d = 128 (tools/gemm_w8_ab.py): 28.0 vs 30.2 us (64-node
       // tiles) at N = 29,960, 188 vs 197 us (128-node, 4 waves) at 250k, equal from 1M on; in the step -1.75 us (full), -1.1 us (the
-      // trainer's).  gemm_variant 5 forces it for other widths, 3 / 4 force the 4-wave tiles.
+      // trainer's).  gemm_variant 5 forces it for other widths, 3 forces the 4-wave 128-node tiles.
       dim3 grid8(ceil_div(g.n, 128), g.J / (16 * nt));
       const size_t lds8 = 4 * (size_t)(128 * 16 + 16 * nt * 16) * sizeof(float);
       hipLaunchKernelGGL((gemm_nt_lds_kernel<8, 1, EPI, 8, false, true, 4>), grid8, dim3(512), lds8, st, g);
@@ -1040,9 +930,9 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
 #define GSS_GEMM_CASE(NTV)                                                                              \
   case NTV:                                                                                             \
     if (mt == 2)                                                                                        \
-      hipLaunchKernelGGL((gemm_nt_lds_kernel<NTV, 2, EPI>), grid, dim3(256), lds_request(gemm_nt_lds_kernel<NTV, 2, EPI>, lds, K().gemm_lds_kb), st, g); \
+      hipLaunchKernelGGL((gemm_nt_lds_kernel<NTV, 2, EPI>), grid, dim3(256), lds_request(gemm_nt_lds_kernel<NTV, 2, EPI>, lds), st, g); \
     else                                                                                                \
-      hipLaunchKernelGGL((gemm_nt_lds_kernel<NTV, 1, EPI>), grid, dim3(256), lds_request(gemm_nt_lds_kernel<NTV, 1, EPI>, lds, K().gemm_lds_kb), st, g); \
+      hipLaunchKernelGGL((gemm_nt_lds_kernel<NTV, 1, EPI>), grid, dim3(256), lds_request(gemm_nt_lds_kernel<NTV, 1, EPI>, lds), st, g); \
     break;
     switch (nt) {
       GSS_GEMM_CASE(8)
@@ -1055,24 +945,12 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
     GSS_LAUNCH_CHECK("gemm_nt_lds_kernel");
     return GSS_OK;
   }
-  if (EPI == EPI_FWD_NORM) return fail(GSS_EINVAL, "fused normalise epilogue needs gemm_variant >= 2");
-  const int ft = (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
-  dim3 grid(ceil_div(g.n, 128), g.J / (16 * ft));
-  if (ft == 4)
-    hipLaunchKernelGGL((gemm_nt_kernel<4, EPI>), grid, dim3(256), 0, st, g);
-  else if (ft == 2)
-    hipLaunchKernelGGL((gemm_nt_kernel<2, EPI>), grid, dim3(256), 0, st, g);
-  else
-    hipLaunchKernelGGL((gemm_nt_kernel<1, EPI>), grid, dim3(256), 0, st, g);
-  GSS_LAUNCH_CHECK("gemm_nt_kernel");
-  return GSS_OK;
 }
 
 int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
               const float *b2, const float *p_prev, float decay, float *p, float *x_next, void *stream, const int32_t *row_list) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(n >= 0 && ax && am && w1 && b1 && w2 && b2 && p && x_next, "dense_fwd: null operand");
-  GSS_REQUIRE(!row_list || K().gemm_variant >= 2, "dense_fwd: a row list needs the LDS-staged GEMM");
   GemmArgs g{};
   g.n = n;
   g.K = 2 * d;
@@ -1099,15 +977,14 @@ int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const floa
 }
 
 // last layer: P as usual, but the residual mix is row-normalised on the fly: e = normalize(p_prev + decay elu(p))
-bool dense_fwd_norm_available(int32_t d) { return K().gemm_variant >= 2 && (d == 128 || d == 64 || d == 32 || d == 16); }
-bool dense_row_list_available() { return K().gemm_variant >= 2; }   // the projection over a row list (gss_plan_step_lazy) is the LDS-staged kernel's
+bool dense_fwd_norm_available(int32_t d) { return d == 128 || d == 64 || d == 32 || d == 16; }
 
 int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
                    const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream, const int32_t *row_list,
                    float *rows_out, const int32_t *rows_out_pos) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(n >= 0 && ax && am && w1 && b1 && w2 && b2 && p && e && inv_den, "dense_fwd_norm: null operand");
-  GSS_REQUIRE(dense_fwd_norm_available(d), "dense_fwd_norm: needs d in {16, 32, 64, 128} and the LDS-staged GEMM");
+  GSS_REQUIRE(dense_fwd_norm_available(d), "dense_fwd_norm: needs d in {16, 32, 64, 128}");
   GemmArgs g{};
   g.n = n;
   g.K = 2 * d;
@@ -1184,7 +1061,6 @@ struct WgradArgs {
   float *part_b;  // [nslices][d]
   int rows_per_slice;
   int xcd_remap;
-  int prio;
 };
 
 // Two problems may share one launch (grid.y = ns0 + slices of the second): the top layer's batch-row gradient is 64
@@ -1203,8 +1079,6 @@ __global__ __launch_bounds__(64 * kWgWaves) void wgrad_tn_kernel(WgradArgs g0, W
   const bool second = by >= ns0;
   const WgradArgs &g = second ? g1 : g0;
   // the two waves of a SIMD run the same program in lockstep; a static priority for one half (MI355X guide, item 4)
-  if (g0.prio == 1 && (threadIdx.x >> 6) >= 4) __builtin_amdgcn_s_setprio(1);
-  if (g0.prio == 2 && (threadIdx.x >> 6) < 4) __builtin_amdgcn_s_setprio(1);
   float4 *red = reinterpret_cast<float4 *>(smem);  // [4 slots][16 tiles][64 lanes] float4
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
@@ -1540,7 +1414,7 @@ int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const 
   *nslices_out = ns;
   float *pw = (float *)ws + (size_t)slice0 * d * 2 * d;
   float *pb = (float *)ws + (size_t)total_slices * d * 2 * d + (size_t)slice0 * d;
-  WgradArgs g{n, d, dp, ax, am, rows, pw, pb, rps, K().xcd_remap, K().wgrad_prio};
+  WgradArgs g{n, d, dp, ax, am, rows, pw, pb, rps, K().xcd_remap};
   if (n == 0) {  // empty shard: its slices must still read as zero
     GSS_HIP(hipMemsetAsync(pw, 0, sizeof(float) * (size_t)ns * d * 2 * d, st));
     GSS_HIP(hipMemsetAsync(pb, 0, sizeof(float) * (size_t)ns * d, st));
@@ -1549,11 +1423,11 @@ int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const 
   if (d % 64 == 0) {
     const int tiles = (d / 64) * (2 * d / 64);
     if (K().wgrad_variant == 2)
-      hipLaunchKernelGGL(wgrad_tn_kernel<true>, dim3(tiles, ns), dim3(64 * kWgWaves), lds_request(wgrad_tn_kernel<true>, kWgradRingLds, K().wgrad_lds_kb),
+      hipLaunchKernelGGL(wgrad_tn_kernel<true>, dim3(tiles, ns), dim3(64 * kWgWaves), lds_request(wgrad_tn_kernel<true>, kWgradRingLds),
                          st, g, g, ns);
     else
       hipLaunchKernelGGL(wgrad_tn_kernel<false>, dim3(tiles, ns), dim3(64 * kWgWaves),
-                         lds_request(wgrad_tn_kernel<false>, 4 * 16 * 64 * sizeof(float4), K().wgrad_lds_kb), st, g, g, ns);
+                         lds_request(wgrad_tn_kernel<false>, 4 * 16 * 64 * sizeof(float4)), st, g, g, ns);
     GSS_LAUNCH_CHECK("wgrad_tn_kernel");
   } else {
     hipLaunchKernelGGL(wgrad_simple_kernel, dim3(ceil_div((int64_t)d * 2 * d + d, 256), ns), dim3(256), 0, st, g);
@@ -1580,15 +1454,15 @@ int wgrad_partial_pair(int32_t d, int32_t n0, const float *dp0, const float *ax0
   *ns0_out = ns0;
   *ns1_out = ns1;
   float *base_w = (float *)ws, *base_b = (float *)ws + (size_t)total_slices * d * 2 * d;
-  WgradArgs g0{n0, d, dp0, ax0, am0, rows0, base_w + (size_t)slice0_0 * d * 2 * d, base_b + (size_t)slice0_0 * d, rps0, K().xcd_remap, K().wgrad_prio};
-  WgradArgs g1{n1, d, dp1, ax1, am1, rows1, base_w + (size_t)slice0_1 * d * 2 * d, base_b + (size_t)slice0_1 * d, rps1, K().xcd_remap, K().wgrad_prio};
+  WgradArgs g0{n0, d, dp0, ax0, am0, rows0, base_w + (size_t)slice0_0 * d * 2 * d, base_b + (size_t)slice0_0 * d, rps0, K().xcd_remap};
+  WgradArgs g1{n1, d, dp1, ax1, am1, rows1, base_w + (size_t)slice0_1 * d * 2 * d, base_b + (size_t)slice0_1 * d, rps1, K().xcd_remap};
   const int tiles = (d / 64) * (2 * d / 64);
   if (K().wgrad_variant == 2)
     hipLaunchKernelGGL(wgrad_tn_kernel<true>, dim3(tiles, ns0 + ns1), dim3(64 * kWgWaves),
-                       lds_request(wgrad_tn_kernel<true>, kWgradRingLds, K().wgrad_lds_kb), as_stream(stream), g0, g1, ns0);
+                       lds_request(wgrad_tn_kernel<true>, kWgradRingLds), as_stream(stream), g0, g1, ns0);
   else
     hipLaunchKernelGGL(wgrad_tn_kernel<false>, dim3(tiles, ns0 + ns1), dim3(64 * kWgWaves),
-                       lds_request(wgrad_tn_kernel<false>, 4 * 16 * 64 * sizeof(float4), K().wgrad_lds_kb), as_stream(stream), g0, g1, ns0);
+                       lds_request(wgrad_tn_kernel<false>, 4 * 16 * 64 * sizeof(float4)), as_stream(stream), g0, g1, ns0);
   GSS_LAUNCH_CHECK("wgrad_tn_kernel");
   return GSS_OK;
 }

@@ -28,14 +28,14 @@ __global__ __launch_bounds__(256) void rownorm_fwd_kernel(int n, int d4, int lpr
     ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
   }
   for (int o = 1; o < lpr; o <<= 1) ss += __shfl_xor(ss, o, 64);
-  const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+  const float den = fmaxf(sqrtf(ss), 1e-12f);
   if (!ok) return;
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
     const int f4 = li + k * 64;
-    if (f4 < d4) st4(e + ((size_t)row * d4 + f4) * 4, scale4(inv, v[k]));
+    if (f4 < d4) st4(e + ((size_t)row * d4 + f4) * 4, unit4(den, v[k]));
   }
-  if (li == 0) inv_den[row] = inv;
+  if (li == 0) inv_den[row] = 1.f / den;
 }
 
 // backward of F.normalize and of F.elu / the residual mix on the batch rows (autograd of

@@ -663,9 +663,9 @@ static int loss_sweep(int32_t d, int32_t b, float beta, float alpha, const float
 #define GSS_LOSS_CASE(NGV)                                                              \
   case NGV:                                                                             \
     if (exact)                                                                          \
-      hipLaunchKernelGGL((loss_fused_kernel<NGV, true>), grid, block, lds_request(loss_fused_kernel<NGV, true>, lds, K().loss_lds_kb), st, g);      \
+      hipLaunchKernelGGL((loss_fused_kernel<NGV, true>), grid, block, lds_request(loss_fused_kernel<NGV, true>, lds), st, g);      \
     else                                                                                \
-      hipLaunchKernelGGL((loss_fused_kernel<NGV, false>), grid, block, lds_request(loss_fused_kernel<NGV, false>, lds, K().loss_lds_kb), st, g);     \
+      hipLaunchKernelGGL((loss_fused_kernel<NGV, false>), grid, block, lds_request(loss_fused_kernel<NGV, false>, lds), st, g);     \
     break;
   switch (L.ng) {
     GSS_LOSS_CASE(1)

@@ -37,6 +37,9 @@ struct gss_comm {
   // halo exchange: rows [send_off[q], send_off[q+1]) of `send` go to rank q, rows from rank q land at [recv_off[q], recv_off[q+1])
   // of `recv` (row = d floats; offsets are host arrays of world + 1 entries; own entries are empty)
   virtual int exchange_rows(const float *send, const int64_t *send_off, float *recv, const int64_t *recv_off, int d, hipStream_t st) = 0;
+  // measurement aid of the in-process backend (gss_comm_local_mode): record what every collective delivers / serve it again without peers
+  virtual int set_mode(int /*mode*/) { return -1; }
+  virtual int log_bytes(int64_t * /*out*/, int32_t /*cap*/, int32_t * /*n_out*/) { return -1; }
 };
 
 namespace gss {
@@ -75,7 +78,6 @@ int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const floa
               const int32_t *row_list = nullptr);  // row_list: the n tile rows are node rows row_list[0..n) of every operand; a negative
                                                    // entry is skipped (nothing of it is written)
 bool dense_fwd_norm_available(int32_t d);
-bool dense_row_list_available();
 int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
                    const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream,
                    const int32_t *row_list = nullptr, float *rows_out = nullptr,    // rows_out: tile row t's unit-norm row also to rows_out[t]

@@ -12,6 +12,8 @@
 // rows of other shards its CSR references (the boundary features), which one fused group of point-to-point transfers
 // fetches before the hop.  The CSR column ids are operand rows.  A single-GPU plan is the case P = 1 with empty halos.
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "ops.h"
@@ -117,6 +119,14 @@ struct gss_plan {
     float *recvbuf = nullptr;                      // [n_halo][d] staging of the fetched rows
     int64_t last_recv = -1, last_send = -1;        // rows moved by the last exchange (gss_plan_lazy_halo_rows)
   } lz, lzt;
+  // The request phase of lz depends on the batch ids and the graph only (never on values), so gss_plan_step_lazy runs it FIRST, on the
+  // plan's request stream `rq`, while the caller's stream works through layer 1; the 2 (P + 1) counts reach the host by an event-gated
+  // async copy and the host waits for that EVENT just before it enqueues the transfer -- the caller's stream is never drained for it
+  // (round 5; until then: comm->sync on the caller's stream, a device bubble per step, which kept the subset exchange off over RCCL).
+  hipStream_t rq = nullptr;
+  hipEvent_t ev_rq_in = nullptr, ev_rq_cnt = nullptr;
+  bool lz_pending = false;     // a request phase is in flight on rq
+  int64_t n_sync[2] = {0, 0};  // since the last gss_plan_sync_stats: host waits that DRAIN the caller's stream / host waits for an event of rq
   // lzt: the same machinery for A_hat^T's halo, driven by the SENDER: of u -- the operand of the top layer's second backward hop, non-zero
   // only in the batch's neighbourhood (nzbits) -- the owners send the rows that can be non-zero and the bitmap that says which; the receiver
   // sets exactly those bits behind its own rows' in nzbits, so the hop never reads a row that was not sent.  Full and lazy steps alike.
@@ -252,7 +262,7 @@ void carve(gss_plan *p, Carver &c) {
   // (the sizing pass carves from a null base: conditions must not look at the pointers it hands out)
   // (with the lazy halo the bitmaps are kept whatever the size of THIS shard: whether a hop's exchange is a subset is a decision all
   // ranks must share, and the sender-driven subset of u's halo is read off nzbits)
-  const bool bitmaps = L > 1 && (p->rows_t >= (size_t)K().sparse_bits_rows || p->lzt.on);
+  const bool bitmaps = L > 1 && (p->rows_t >= (size_t)K().sparse_bits_rows || p->lzt.on || p->lz.on);
   p->posbits = bitmaps ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;
   p->nzbits = bitmaps ? c.take<uint32_t>(p->rows_t / 32 + 1) : nullptr;
   // (a shard needs the peers' requests to know which of its rows anything reads: with the lazy halo only)
@@ -392,14 +402,16 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
     p->prof_cnt[k] = 0;
   }
   {
-    // every rank takes the same decision: it depends on the knob and the size of the whole graph only
-    // (automatic: large graphs, and not over RCCL -- a subset hop costs a host round trip for the counts (comm->sync: stream drain +
-    // D2H copy), whose price between real devices nobody has measured yet; over RCCL it is opt-in (knob 1) until a multi-GPU run shows
-    // a net gain.  ADVICE round 3.)
-    const int knob = K().lazy_halo;
+    // every rank takes the same decision: it depends on the knobs, the transport and the size of the whole graph only.
+    //   lz  (the top layer's M in a lazy step, receiver-driven): automatic from 262,144 nodes on, on every transport -- its request phase
+    //       runs ahead on the request stream and costs the caller's stream nothing (round 5);
+    //   lzt (u in the top layer's second backward hop, sender-driven: the bitmap is the sparse hop's OUTPUT, so the counts cannot be known
+    //       ahead and the host drains the stream once per step for them): automatic on the host-side transports only; over RCCL the hop
+    //       runs exchange-free on the shard's A_hat transposed in place instead (tloc below) -- opt-in there (knob lazy_halo_u = 1).
+    const int knob = K().lazy_halo, knob_u = K().lazy_halo_u;
     const bool rccl = comm && comm->device_transport();
-    p->lz.on = P > 1 && desc->num_layers > 1 && (knob == 1 || (knob < 0 && n_global >= 262144 && !rccl));
-    p->lzt.on = p->lz.on && spmm_sparse_available();      // (the sparse first backward hop writes nzbits; knob spmm_variant is process-wide)
+    p->lz.on = P > 1 && desc->num_layers > 1 && (knob == 1 || (knob < 0 && n_global >= 262144));
+    p->lzt.on = p->lz.on && spmm_sparse_available() && (knob_u == 1 || (knob_u < 0 && (knob == 1 || !rccl)));   // (the sparse first backward hop writes nzbits; knob spmm_variant is process-wide)
     auto word_offsets = [&](gss_plan::LazyHalo &z, const gss_plan::Halo &h) {
       if (!z.on) return;
       z.w_recv_off.assign((size_t)P + 1, 0);
@@ -493,6 +505,16 @@ int plan_create_impl(gss_plan **out, const gss_plan_desc *desc, const gss_shard_
       return fail(GSS_EHIP, "plan_create: exchange stream/events -> %s", hipGetErrorString(e));
     }
   }
+  if (p->lz.on) {
+    e = hipStreamCreateWithFlags(&p->rq, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_rq_in, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_rq_cnt, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      (void)hipFree(p->slab);
+      delete p;
+      return fail(GSS_EHIP, "plan_create: request stream/events -> %s", hipGetErrorString(e));
+    }
+  }
   if (p->pos) {
     e = hipMemset(p->pos, 0xff, sizeof(int32_t) * (p->rows_t ? p->rows_t : 1));  // all -1
     if (e != hipSuccess) {
@@ -570,8 +592,9 @@ int plan_halo(gss_plan *p, const gss_plan::Halo &h, float *op, void *stream) {
 // of the step come back to the host once (ncclSend / ncclRecv take host-side counts).  Boundary rows that are not fetched keep whatever
 // they held: nothing reads them.
 // Request phase: who needs what.  Afterwards z.send_list / z.recv_list and the host-side counts z.h_cnt describe the transfer.
-int plan_halo_requests(gss_plan *p, gss_plan::LazyHalo &z, const gss_plan::Halo &h, const gss_csr *a, const int32_t *need_rows, int32_t b,
-                       const uint32_t *src_bits, void *stream) {
+// enqueue only: bitmaps, their exchange, the two lists and the async copy of the counts to the pinned host buffer, all on `stream`
+int plan_halo_requests_enqueue(gss_plan *p, gss_plan::LazyHalo &z, const gss_plan::Halo &h, const gss_csr *a, const int32_t *need_rows, int32_t b,
+                               const uint32_t *src_bits, void *stream) {
   PROF(GSS_PROF_COMM);
   p->n_coll[0] += 1;
   const int P = p->P, n = p->desc.n;
@@ -595,14 +618,67 @@ int plan_halo_requests(gss_plan *p, gss_plan::LazyHalo &z, const gss_plan::Halo 
   if (int rc = bits_compact(z.reqw, P, d_wsend_off, d_send_off, h.d_send_rows, 0, z.send_list, z.d_cnt, stream)) return rc;
   if (int rc = bits_compact(z.needw, P, d_wrecv_off, d_recv_off, nullptr, n, z.recv_list, z.d_cnt + P1, stream)) return rc;
   GSS_HIP(hipMemcpyAsync(z.h_cnt, z.d_cnt, sizeof(int64_t) * 2 * P1, hipMemcpyDeviceToHost, st));
-  if (int rc = p->comm->sync(st, 300.0)) return rc;          // the counts of this step; with the communicator's watchdog
-  const int64_t *send_off = z.h_cnt, *recv_off = z.h_cnt + P1;
+  return GSS_OK;
+}
+
+// the counts are on the host: check them
+int plan_halo_requests_counts(gss_plan *p, gss_plan::LazyHalo &z, const gss_plan::Halo &h) {
+  const int P = p->P;
+  const int64_t *send_off = z.h_cnt, *recv_off = z.h_cnt + (size_t)P + 1;
   GSS_REQUIRE(send_off[P] >= 0 && send_off[P] <= h.n_send && recv_off[P] >= 0 && recv_off[P] <= h.n_halo,
               "lazy halo: %lld rows to send of %lld, %lld to fetch of %lld", (long long)send_off[P], (long long)h.n_send, (long long)recv_off[P],
               (long long)h.n_halo);
   z.last_send = send_off[P];
   z.last_recv = recv_off[P];
   return GSS_OK;
+}
+
+// Sender-driven form (u): the bitmap is the sparse hop's output of THIS step, the transfer follows at once -- the host waits for the
+// caller's stream (with the communicator's watchdog): a drain per step, counted in n_sync[0]
+int plan_halo_requests(gss_plan *p, gss_plan::LazyHalo &z, const gss_plan::Halo &h, const gss_csr *a, const int32_t *need_rows, int32_t b,
+                       const uint32_t *src_bits, void *stream) {
+  if (int rc = plan_halo_requests_enqueue(p, z, h, a, need_rows, b, src_bits, stream)) return rc;
+  p->n_sync[0] += 1;
+  if (int rc = p->comm->sync(as_stream(stream), 300.0)) return rc;          // the counts of this step
+  return plan_halo_requests_counts(p, z, h);
+}
+
+// Receiver-driven form (the top layer's M), ahead of time: the request phase on the plan's request stream, behind everything the caller's
+// stream holds so far (the batch preparation that wrote need_rows; the previous step's readers of the lists)
+int plan_lazy_requests_begin(gss_plan *p, const int32_t *need_rows, int32_t b, void *stream) {
+  GSS_HIP(hipEventRecord(p->ev_rq_in, as_stream(stream)));
+  GSS_HIP(hipStreamWaitEvent(p->rq, p->ev_rq_in, 0));
+  if (int rc = plan_halo_requests_enqueue(p, p->lz, p->halo_a, p->a, need_rows, b, nullptr, p->rq)) return rc;
+  GSS_HIP(hipEventRecord(p->ev_rq_cnt, p->rq));
+  p->lz_pending = true;
+  return GSS_OK;
+}
+
+// ... and its end: the host waits for the EVENT behind the counts (polled, with the communicator's error poll and a deadline -- never a
+// blocking call, never the caller's stream, which keeps running what it has), the caller's stream orders itself behind the lists
+int plan_lazy_requests_end(gss_plan *p, void *stream) {
+  GSS_REQUIRE(p->lz_pending, "lazy halo: no request phase in flight");
+  p->lz_pending = false;
+  p->n_sync[1] += 1;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int spins = 0;; ++spins) {
+    const hipError_t q = hipEventQuery(p->ev_rq_cnt);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) return fail(GSS_EHIP, "lazy halo: hipEventQuery -> %s", hipGetErrorString(q));
+    if ((spins & 63) == 63) {
+      if (int rc = p->comm->check_async()) return rc;
+      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (el > 300.0) {
+        p->comm->abort();
+        return fail(GSS_ETIMEOUT, "lazy halo: rank %d of %d waited %.0f s for the request exchange (a peer stopped taking part?); communicator aborted",
+                    p->rank, p->P, el);
+      }
+    }
+    if (spins < 2000) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 20 : 500));
+  }
+  GSS_HIP(hipStreamWaitEvent(as_stream(stream), p->ev_rq_cnt, 0));
+  return plan_halo_requests_counts(p, p->lz, p->halo_a);
 }
 
 // Transfer phase: the listed rows of `op` to the peers, theirs into the listed boundary rows.  set_bits (sender-driven form): the
@@ -731,8 +807,11 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
       float *m = l == 0 ? p->m0op : p->m_tmp;
       const bool lazy_l = lazy_rows && l == L - 1;
       const bool needed_only = lazy_l && p->P > 1 && p->lz.on;   // sharded: A_hat M fetches only the boundary rows of M its rows read
-      if (needed_only)   // who reads which of M's rows: the peers' requests also say which of THIS shard's rows anything reads
-        if (int rc = plan_halo_requests(p, p->lz, p->halo_a, p->a, lazy_rows, lazy_b, nullptr, stream)) return rc;
+      if (needed_only) {  // who reads which of M's rows: the peers' requests also say which of THIS shard's rows anything reads
+        if (!p->lz_pending)   // (gss_plan_step_lazy started the request phase before layer 1; anything else that gets here starts it now)
+          if (int rc = plan_lazy_requests_begin(p, lazy_rows, lazy_b, stream)) return rc;
+        if (int rc = plan_lazy_requests_end(p, stream)) return rc;
+      }
       if (lazy_l && p->needbits) {
         // huge graphs: AX and M of the top layer on the batch rows and their neighbours only (what A_hat M on the batch rows, the
         // batch-row weight gradient and the backward hop's epilogue read); a shard adds the rows its peers' batch rows reference
@@ -1182,6 +1261,12 @@ void gss_plan_destroy(gss_plan *p) {
     (void)hipStreamSynchronize(p->xs);
     (void)hipStreamDestroy(p->xs);
   }
+  if (p->rq) {
+    (void)hipStreamSynchronize(p->rq);
+    (void)hipStreamDestroy(p->rq);
+  }
+  if (p->ev_rq_in) (void)hipEventDestroy(p->ev_rq_in);
+  if (p->ev_rq_cnt) (void)hipEventDestroy(p->ev_rq_cnt);
   if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
   if (p->ev_halo) (void)hipEventDestroy(p->ev_halo);
   if (p->ev_main_ready) (void)hipEventDestroy(p->ev_main_ready);
@@ -1198,7 +1283,7 @@ void gss_plan_destroy(gss_plan *p) {
 // different addresses); the same plan under alternating settings does not.
 int gss_plan_debug_set_option(gss_plan *p, const char *name, int value) {
   GSS_REQUIRE(p && name, "plan_debug_set_option: null argument");
-  static const char *const kLive[] = {"gemm_lines", "spmm_pair", "wgrad_deep", "gemm_hoist", "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "spmm_slices", "spmm_pin", "spmm_fly", "gemm_prio", "gemm_stagger", "wgrad_prio", "gemm_lds_kb", "wgrad_lds_kb", "loss_lds_kb", "gemm_rows_split", "gemm_ws", "gemm_ws_wgs", "gemm_ws_stagger", "gemm_ws_mode"};
+  static const char *const kLive[] = {"gemm_lines", "spmm_pair", "wgrad_deep", "gemm_hoist", "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "spmm_slices", "spmm_pin", "spmm_fly", "gemm_rows_split", "gemm_ws", "gemm_ws_wgs", "gemm_ws_stagger", "gemm_ws_mode"};
   bool ok = false;
   for (const char *k : kLive) ok = ok || strcmp(k, name) == 0;
   GSS_REQUIRE(ok, "plan_debug_set_option: only kernel-selection knobs can change on a live plan");
@@ -1244,13 +1329,13 @@ int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *
 // N - b rows are not read by anything inside a step.  A row that IS computed goes through the same segments, the same summation tree
 // and the same MFMA rows as in the full pass, so loss, gradients and parameters equal gss_plan_step's bit for bit; afterwards
 // io.emb holds this step's embeddings on the batch rows only (call gss_plan_forward for all of them).  Falls back to the full step
-// where the pieces it needs are absent (one layer, spmm_variant 1, gemm_variant 1).  On a sharded plan every shard evaluates the
+// where the pieces it needs are absent (one layer, spmm_variant 1).  On a sharded plan every shard evaluates the
 // top layer on the batch rows it owns.
 int gss_plan_step_lazy(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream) {
   KnobScope knob_scope(p ? &p->knobs : nullptr);
   GSS_REQUIRE(p, "plan_step_lazy: null plan");
   const gss_plan_desc &D = p->desc;
-  const bool can = D.num_layers > 1 && spmm_sparse_available() && dense_row_list_available() && !D.pipeline_layer1 && p->pos;
+  const bool can = D.num_layers > 1 && spmm_sparse_available() && !D.pipeline_layer1 && p->pos;
   return plan_step_impl(p, idx, b, beta, stream, can);
 }
 
@@ -1286,7 +1371,15 @@ static int plan_step_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta
     // a shard lists the batch members it OWNS (rlist: -1 for the others, whose tile rows compute on row 0's operands and store
     // nothing): every listed row has one writer, no row outside the batch is touched; an empty shard has no top layer to evaluate
     const int32_t *rows = p->rlist ? p->rlist : (mapped ? p->rloc : idx);
+    // the subset exchange's request phase: it needs the prepared lists and the graph, nothing else -- started now, on the request stream,
+    // it runs underneath layer 1
+    if (p->P > 1 && p->lz.on)
+      if (int rc = plan_lazy_requests_begin(p, rows, p->desc.n > 0 ? b : 0, stream)) return rc;
     const int rc_f = plan_forward_impl(p, stream, rows, p->desc.n > 0 ? b : 0);
+    if (rc_f && p->lz_pending) {   // the forward failed before it consumed the request phase: do not leave it dangling
+      (void)hipStreamSynchronize(p->rq);
+      p->lz_pending = false;
+    }
     p->prep_pending = nullptr;
     p->eb_scatter_b = 0;
     if (rc_f) return rc_f;
@@ -1378,6 +1471,15 @@ int gss_plan_comm_stats(gss_plan *p, int64_t *out3) {
   for (int k = 0; k < 3; ++k) {
     out3[k] = p->n_coll[k];
     p->n_coll[k] = 0;
+  }
+  return GSS_OK;
+}
+
+int gss_plan_sync_stats(gss_plan *p, int64_t *out2) {
+  GSS_REQUIRE(p && out2, "plan_sync_stats: null argument");
+  for (int k = 0; k < 2; ++k) {
+    out2[k] = p->n_sync[k];
+    p->n_sync[k] = 0;
   }
   return GSS_OK;
 }

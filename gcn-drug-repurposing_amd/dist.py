@@ -91,6 +91,18 @@ class Comm:
         the communicator and raises instead of hanging"""
         _lib.check(_lib.load().gss_comm_sync(self.handle, _lib.current_stream(), float(timeout_s)), "gss_comm_sync")
 
+    def local_mode(self, mode: int):
+        """in-process backend only (gss_comm_local_mode): 1 = record what every collective delivers, 2 = replay it without peers, 0 = normal"""
+        _lib.check(_lib.load().gss_comm_local_mode(self.handle, int(mode)), "gss_comm_local_mode")
+
+    def local_log(self):
+        """delivered bytes of every recorded collective, in call order (gss_comm_local_log)"""
+        n = C.c_int32(0)
+        _lib.check(_lib.load().gss_comm_local_log(self.handle, None, 0, C.byref(n)), "gss_comm_local_log")
+        out = (C.c_int64 * max(1, n.value))()
+        _lib.check(_lib.load().gss_comm_local_log(self.handle, out, n.value, C.byref(n)), "gss_comm_local_log")
+        return [int(out[k]) for k in range(n.value)]
+
     def allgather_bytes(self, src: torch.Tensor) -> torch.Tensor:
         """every rank's `src` (same shape and dtype everywhere), concatenated in rank order -> [world * src.numel()]"""
         src = src.contiguous()

@@ -191,5 +191,13 @@ class GssEngine:
         _lib.check(self.lib.gss_plan_comm_stats(self.handle, out), "gss_plan_comm_stats")
         return tuple(int(v) for v in out)
 
+    def sync_stats(self):
+        """host-side waits of a sharded plan since the last call (gss_plan_sync_stats): (drains of the caller's stream, waits for an event
+        of the plan's request stream); zeros on one GPU"""
+        import ctypes as C
+        out = (C.c_int64 * 2)()
+        _lib.check(self.lib.gss_plan_sync_stats(self.handle, out), "gss_plan_sync_stats")
+        return tuple(int(v) for v in out)
+
     def device_bytes(self) -> int:
         return int(self.lib.gss_plan_device_bytes(self.handle))

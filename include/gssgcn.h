@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GSS_ABI_VERSION 5   /* 5 (round 5): gss_rowsum_check; 4 (round 4): gss_shard_desc gained a_loc_t, gss_plan_comm_stats, gss_knn_topk_rows */
+#define GSS_ABI_VERSION 5   /* 5 (round 5): gss_rowsum_check, gss_plan_sync_stats, gss_comm_local_mode / gss_comm_local_log; 4 (round 4): gss_shard_desc gained a_loc_t, gss_plan_comm_stats, gss_knn_topk_rows */
 
 #define GSS_OK 0
 #define GSS_EINVAL (-22)   /* bad argument (shape, null pointer, unsupported d) */
@@ -44,8 +44,8 @@ int gss_abi_version(void);
  * NULL (the default) switches it off; no production path sets it. */
 int gss_debug_set_stamp_buffer(void *device_buffer);
 /* measurement aid (tools/ab_live.py): changes one KERNEL-SELECTION knob ("gemm_lines", "spmm_pair", "wgrad_deep", "gemm_hoist",
- * "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "spmm_slices", "spmm_pin", "spmm_fly", "gemm_prio", "gemm_stagger", "wgrad_prio",
- * "gemm_lds_kb", "wgrad_lds_kb", "loss_lds_kb", "gemm_rows_split") in a live plan's snapshot, so that one plan -- the same buffers at the same addresses --
+ * "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "spmm_slices", "spmm_pin", "spmm_fly", "gemm_rows_split",
+ * "gemm_ws", "gemm_ws_wgs", "gemm_ws_stagger", "gemm_ws_mode") in a live plan's snapshot, so that one plan -- the same buffers at the same addresses --
  * can be timed under alternating settings; knobs that size a workspace or steer the plan's bookkeeping are refused (GSS_EINVAL).
  * Not thread-safe against gss_debug_set_option on another thread. */
 int gss_plan_debug_set_option(gss_plan *plan, const char *name, int value);
@@ -165,6 +165,13 @@ int gss_scatter_add_rows(int32_t d, const float *src, const int32_t *rows, int32
 int gss_comm_unique_id(void *id_out);
 int gss_comm_create_rccl(gss_comm **out, int32_t world, int32_t rank, const void *id);
 int gss_comm_create_local(gss_comm **out /* [world] */, int32_t world);
+/* Measurement aid of the in-process backend (tools/shard_emulation.py --serial): rank threads share ONE GPU, so a step timed with all
+ * of them running says nothing about one rank's kernels.  mode 1 = record: keep a device copy of what every collective DELIVERS to this
+ * rank, in call order; mode 2 = replay: serve those copies again (same call sequence and sizes, checked) by a device-to-device copy --
+ * no peers, no barrier, no host wait -- so that one rank's step can run alone on the GPU and be timed; mode 0 (default) = normal, frees
+ * the log.  gss_comm_local_log: the delivered bytes of every recorded collective (n_out = how many there are; at most cap are written). */
+int gss_comm_local_mode(gss_comm *c, int32_t mode);
+int gss_comm_local_log(gss_comm *c, int64_t *bytes_out, int32_t cap, int32_t *n_out);
 /* A third backend for boxes where RCCL cannot run the job: one PROCESS per rank as with RCCL, but every collective is staged through
  * pinned host memory and handed to a transport callback of the host language (the Python package passes torch.distributed's gloo;
  * GSS_COMM_BACKEND=host).  RCCL refuses two ranks on one device, so this is how `train.py --ngpus N` / `bench.py --gpus N` run as N
@@ -416,17 +423,27 @@ int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *
 int gss_plan_step_lazy(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream);
 /* Sharded plans, knob lazy_halo (default: graphs of >= 262,144 nodes): two hops fetch a SUBSET of their operand's boundary rows.
  * (1) Lazy steps, the top layer's M: only the boundary rows that the batch rows of this shard reference (the receiver marks them over
- * its halo slots and sends the bitmaps to the owners).  (2) Every step, u -- the operand of the top layer's second backward hop, zero
- * outside the batch's neighbourhood --: only the rows that can be non-zero (the owners send them and the bitmap that says which).
- * One device -> host round trip per such hop for the row counts.  Same bits as the full exchanges.  out6 reports what the LAST such
- * exchanges moved: {rows fetched, rows sent, rows of the whole halo} for (1) and then for (2); fetched / sent are -1 when the plan
- * exchanges whole halos. */
+ * its halo slots and sends the bitmaps to the owners).  What is needed depends on the batch ids and the graph alone, so the request
+ * phase is the FIRST thing gss_plan_step_lazy enqueues, on the plan's own request stream: it runs underneath layer 1, the row counts
+ * reach the host through an event-gated async copy, and the host waits for that event -- never for the caller's stream -- just before
+ * it enqueues the transfer (gss_plan_sync_stats).  On by default on every transport.
+ * (2) Every step, u -- the operand of the top layer's second backward hop, zero outside the batch's neighbourhood --: only the rows
+ * that can be non-zero (the owners send them and the bitmap that says which).  That bitmap is an OUTPUT of the hop before it, so the
+ * host drains the caller's stream once per step for the counts; knob lazy_halo_u (-1, the default: with lazy_halo on the host-side
+ * transports, not over RCCL -- there a two-layer plan runs the hop exchange-free on gss_shard_desc.a_loc_t instead; 0 never; 1 with lazy_halo).
+ * Same bits as the full exchanges.  out6 reports what the LAST such exchanges moved: {rows fetched, rows sent, rows of the whole
+ * halo} for (1) and then for (2); fetched / sent are -1 when the plan exchanges whole halos. */
 int gss_plan_lazy_halo_rows(const gss_plan *p, int64_t *out6);
 /* Collectives a sharded plan has enqueued since the last call (then reset): out3 = {boundary-row exchanges, batch-row all-reduces,
  * weight-gradient all-reduces}.  A steady full step at L layers: 2L - 2 + 2L - 3 exchanges (one less with halo_recompute: layer 2's
  * boundary input rows are recomputed from layer 1's constant AX / AM), 1 batch-row all-reduce ([E_B | P_B | inv_B] as one buffer; 2
  * at widths outside {64, 128, 256} or with the row-slab loss sweep, knob loss_slab), 1 weight-gradient all-reduce.  Zeros on one GPU. */
 int gss_plan_comm_stats(gss_plan *p, int64_t *out3);
+/* Host-side waits of a sharded plan since the last call (then reset): out2 = {waits that DRAIN the caller's stream (the device idles
+ * until the host has enqueued again): the sender-driven subset exchange of u, knob lazy_halo_u; waits for an EVENT of the plan's
+ * request stream while the caller's stream keeps running: the request phase of the lazy step's subset exchange}.  An RCCL job with
+ * default knobs: {0, 0} per full step, {0, 1} per lazy step from 262,144 nodes on, {0, 0} below.  Zeros on one GPU. */
+int gss_plan_sync_stats(gss_plan *p, int64_t *out2);
 /* layer activations for parity tests: which 0 AX, 1 AM, 2 P of layer `layer` (0-based) */
 const float *gss_plan_activation(const gss_plan *p, int layer, int which);
 size_t gss_plan_device_bytes(const gss_plan *p);
@@ -465,19 +482,17 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
 /* tuning/debug knobs (A/B runs inside one process): "spmm_variant" = 1 (whole-row gather, wave per row) or
  * 2 (nnz-balanced segments, default); "spmm_slices" = 0 (automatic, default) or 1..8 time-separated feature
  * slices in the balanced SpMM; "spmm_seg_edges" = entries per SpMM segment (default 32; applies to gss_csr handles
- * created afterwards); "gemm_variant" = 1 (operand fragments from L1/L2), 2 (LDS-DMA staged, node tile
- * chosen by width; default), 3 / 4 (LDS-DMA staged, 128- / 64-node tiles forced); "spmm_pin" = with a manual "spmm_slices": slices time-separated (0, default) or pinned to XCDs (1); the automatic policy pins operands of <= 64 MB; "spmm_fly" = 4 (default) / 8 row gathers in flight per lane group; "spmm_hot_rows" = -1 (default: what
+ * created afterwards); "gemm_variant" = projection tile shape: 2 (by width and row count; default), 3 (128-node tiles of four
+ * waves forced), 5 (128-node tiles of eight waves forced); "gemm_ws" = -1 (default: from 131,072 rows on) / 0 / 1: the d = 128 forward projection as the
+ * weight-stationary persistent kernel (same bits; "gemm_ws_wgs", "gemm_ws_stagger", "gemm_ws_mode" shape its launch); "spmm_pin" = with a manual "spmm_slices": slices time-separated (0, default) or pinned to XCDs (1); the automatic policy pins operands of <= 64 MB; "spmm_fly" = 4 (default) / 8 row gathers in flight per lane group; "spmm_hot_rows" = -1 (default: what
  * gss_csr_set_hot declared) or a row count; "gemm_small_nt", "gemm_nt_cap" = narrowest / widest feature tile of the projections in
  * 16-feature units (0 = automatic); "xcd_remap" = 0 / 1 (default): workgroups that read the same rows share an XCD (dense kernels);
  * "wgrad_wgs", "loss_wgs" = workgroups of a full-size weight-gradient launch / the loss sweep (default 256 = one per CU; set
  * before plans are created); "sparse_bits_rows" = operand rows from which a plan keeps the bitmaps of the sparsity-aware backward hops
- * (default 100000); round-3 experiments, all off by default: "gemm_prio", "wgrad_prio" (static wave priorities), "gemm_stagger" (late
- * start of the second generation of projection workgroups), "gemm_lds_kb" / "wgrad_lds_kb" / "loss_lds_kb" (occupancy by LDS
- * footprint), "wgrad_variant" = 1 (default) / 2 (operands through an LDS-DMA ring), "ppr_fused" = 1 (default) / 0 (separate update
+ * (default 100000); "wgrad_variant" = 1 (default) / 2 (operands through an LDS-DMA ring), "ppr_fused" = 1 (default) / 0 (separate update
  * pass of the diffusion profiles); "gemm_rows_split" = 1 (default) / 0: the forward projection over a short row list (lazy step)
  * by four waves per 16 rows that split the features / by one wave; "lazy_halo" = -1 (default: graphs of >= 262,144 nodes) / 0 / 1: sharded plans fetch subsets of the
- * boundary rows where a hop reads a subset (gss_plan_lazy_halo_rows; every rank of a job must use the same value; over RCCL the
- * automatic choice is "never" until a multi-GPU run has priced its host round trip); "halo_recompute" = -1 (default: on) / 0 / 1: sharded plans recompute layer 2's boundary input rows from layer 1's constant AX / AM (fetched once)
+ * boundary rows where a hop reads a subset (gss_plan_lazy_halo_rows; every rank of a job must use the same value), "lazy_halo_u" = -1 / 0 / 1 the same for u in the second backward hop (see gss_plan_lazy_halo_rows); "halo_recompute" = -1 (default: on) / 0 / 1: sharded plans recompute layer 2's boundary input rows from layer 1's constant AX / AM (fetched once)
  * instead of exchanging them every step (same bits; every rank of a job must use the same value); "loss_dgrad" = -1 (default: on shards only) / 0 / 1: the
  * loss finish and the batch rows' input gradient in one launch instead of two (same bits; on a shard it spares a collective); "prep_side" = 1 (default) / 0: on one GPU a step's batch preparation rides in its
  * first forward SpMM launch and E_B comes out of the top layer's projection (no batch_prepare / gather launch; same bits);

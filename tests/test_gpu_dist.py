@@ -273,6 +273,62 @@ def test_rccl_watchdog_aborts_instead_of_hanging():
     del comm                                      # destroying an aborted communicator is fine
 
 
+def test_rccl_abort_from_another_thread_while_enqueueing():
+    """RcclComm holds its mutex for pointer bookkeeping only, never across a call into RCCL -- abort() from a watchdog
+    thread returns at once even while the main thread is busy enqueueing, the enqueues in flight end (success or -104, never a hang or a
+    crash) and every later one is refused with -104.  (A rank stalled INSIDE RCCL behind a peer that never joins needs two devices:
+    test_two_rccl_ranks_abort_releases_a_rank_whose_peer_never_joins.)"""
+    import threading
+    import time
+    from gcn_drug_repurposing_amd import GssError
+    from gcn_drug_repurposing_amd.dist import rccl_comm
+    comm = rccl_comm(1, 0)
+    t = torch.ones(1 << 16, device="cuda")
+    comm.all_reduce_sum_(t)
+    comm.sync(30.0)
+    took = []
+
+    def watchdog():
+        time.sleep(0.05)
+        t0 = time.time()
+        comm.abort()
+        took.append(time.time() - t0)
+
+    th = threading.Thread(target=watchdog)
+    th.start()
+    refused = 0
+    t_end = time.time() + 20.0
+    while time.time() < t_end and refused < 5:
+        try:
+            comm.all_reduce_sum_(t)
+        except GssError as e:
+            assert "-104" in str(e)
+            refused += 1
+    th.join(30.0)
+    assert not th.is_alive() and took and took[0] < 5.0, took
+    assert refused == 5
+    torch.cuda.synchronize()
+    del comm
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_rccl_ranks_abort_releases_a_rank_whose_peer_never_joins(tmp_path):
+    """rank 1 never calls the exchange; rank 0's watchdog thread aborts after a second: abort() must return and rank 0's enqueue / sync
+    must end with an error instead of hanging (tests/mp_abort_job.py)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tests", "mp_abort_job.py")], capture_output=True, text=True,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=300)
+    assert "rank 0: abort returned" in r.stdout and "rank 0: released with" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_local_backend_abort_is_reported_by_check():
     from gcn_drug_repurposing_amd import GssError
     from gcn_drug_repurposing_amd.dist import local_comms

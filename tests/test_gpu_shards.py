@@ -460,7 +460,9 @@ def test_lazy_halo_fetches_only_what_the_batch_rows_read(world, case, relabel, s
     values from earlier steps (the weights change every step, so a row wrongly left out would show).  Losses, parameters and
     embeddings equal the plan that exchanges the whole halo bit for bit (same split, so the same summation order); the number of
     rows fetched is exactly the number of distinct boundary columns of the owned batch rows, and what the ranks fetch in total is
-    what they send in total."""
+    what they send in total.  Round 5: the request phase of M's exchange runs ahead on the plan's request stream -- the host waits for
+    its event, never for the caller's stream (gss_plan_sync_stats: no drain); u's sender-driven exchange still drains once per step, and
+    with lazy_halo_u = 0 -- what an RCCL job gets by default -- a step drains nothing at all, with the same bits."""
     import gcn_drug_repurposing_amd as pkg
     from gcn_drug_repurposing_amd.dist import local_comms
     from gcn_drug_repurposing_amd.shards import ScipySource, build_shard, shard_engine, shard_rows
@@ -473,8 +475,8 @@ def test_lazy_halo_fetches_only_what_the_batch_rows_read(world, case, relabel, s
     batches = [rng.choice(n, size=s, replace=False).astype(np.int32) for s in (min(n, 100), 3, 1, 48, min(n, 128), 17)]
     kw = dict(num_layers=L, layer_decay=float(g["decay"]), alpha=float(g["alpha"]), lr=float(g["lr"]), max_batch=128)
 
-    def run(knob):
-        assert lib.gss_debug_set_option(b"lazy_halo", knob) == 0
+    def run(knob, knob_u=-1):
+        assert lib.gss_debug_set_option(b"lazy_halo", knob) == 0 and lib.gss_debug_set_option(b"lazy_halo_u", knob_u) == 0
         try:
             comms = local_comms(world)
 
@@ -487,12 +489,18 @@ def test_lazy_halo_fetches_only_what_the_batch_rows_read(world, case, relabel, s
                 lo, hi = shard.part.rows(rank)
                 indptr, col = shard.a.h_indptr, shard.a.col.cpu().numpy()[:shard.a.nnz]
                 losses, moved, moved_u = [], [], []
+                eng.sync_stats()
                 for k, idx in enumerate(batches):
                     (eng.step if k == 3 else eng.step_lazy)(torch.from_numpy(idx).cuda(), float(g["beta"]))   # one full step in between
                     losses.append(eng.loss.item())
                     fetched, sent, halo, u_fetched, u_sent, u_halo = eng.lazy_halo_rows()
+                    # host-side waits of the step: (drains of the caller's stream, event waits on the request stream)
+                    u_on = knob == 1 and knob_u != 0
+                    assert eng.sync_stats() == (1 if u_on else 0, 1 if (knob == 1 and k != 3) else 0), (knob, knob_u, k)
                     if knob == 0:
                         assert (fetched, sent, u_fetched, u_sent) == (-1, -1, -1, -1)
+                    elif not u_on:
+                        assert (u_fetched, u_sent) == (-1, -1)
                     else:
                         assert 0 <= u_fetched <= u_halo == shard.layout.halo_at.n_halo
                         moved_u.append((u_fetched, u_sent))
@@ -510,13 +518,16 @@ def test_lazy_halo_fetches_only_what_the_batch_rows_read(world, case, relabel, s
             return _threaded(world, fn, comms)
         finally:
             lib.gss_debug_set_option(b"lazy_halo", -1)
+            lib.gss_debug_set_option(b"lazy_halo_u", -1)
 
-    whole, needed = run(0), run(1)
-    for a, b in zip(whole, needed):
-        assert a["losses"] == b["losses"]
-        np.testing.assert_array_equal(a["emb"], b["emb"])
-        for x, y in zip(a["params"], b["params"]):
-            np.testing.assert_array_equal(x, y)
+    whole, needed, rccl_like = run(0), run(1), run(1, 0)
+    for other in (needed, rccl_like):
+        for a, b in zip(whole, other):
+            assert a["losses"] == b["losses"]
+            np.testing.assert_array_equal(a["emb"], b["emb"])
+            for x, y in zip(a["params"], b["params"]):
+                np.testing.assert_array_equal(x, y)
+    assert [r["moved"] for r in rccl_like] == [r["moved"] for r in needed]
     for k in range(len(needed[0]["moved"])):
         assert sum(r["moved"][k][0] for r in needed) == sum(r["moved"][k][1] for r in needed)
     for k in range(len(batches)):

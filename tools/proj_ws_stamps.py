@@ -11,6 +11,7 @@ lib = pkg.load()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 29960
 d = 128
 wgs = 512
+assert lib.gss_debug_set_option(b"gemm_ws", 1) == 0      # the stamps below are the weight-stationary kernel's (by default it runs from 131,072 rows on)
 for kv in sys.argv[2:]:
     k, v = kv.split("=")
     assert lib.gss_debug_set_option(k.encode(), int(v)) == 0, kv
