@@ -35,8 +35,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_FILE = "r04_spmm_pmc.json"
-PMC_FALLBACK = "r03_spmm_pmc.json"
+PMC_FILE = "r05_spmm_pmc.json"
+PMC_FALLBACK = "r04_spmm_pmc.json"
 PMC_FILE_RMAT10M = "r04_spmm_pmc_rmat10m.json"
 MFMA_F32_PEAK_TFLOPS = 157.3
 GUIDE_HBM_STREAM_TBS = 6.3   # MI355X_MICROARCH.md: "8 TB/s peak (spec); ~6.3 TB/s achievable"
@@ -571,6 +571,13 @@ def main():
                 if out[key] and name in z.get("hbm_traffic", {}):
                     out[key]["traffic"] = z["hbm_traffic"][name]["traffic_bytes_per_launch"]
                     out[key]["traffic_source"] = f"offline rocprofv3 --pmc profile of the same command: profiles/{os.path.basename(pmc)}"
+        if args.workload == "whole_graph_pathway" and d == 256 and pmc:
+            # BASELINE config 3: the counters of the d = 256 SpMMs on this graph (tools/profile_r05.sh)
+            z = json.load(open(pmc))
+            for key, name in (("roofline", "fwd1"), ("roofline_plain", "plain")):
+                if out[key] and name in z.get("hbm_traffic_config3", {}):
+                    out[key]["traffic"] = z["hbm_traffic_config3"][name]["traffic_bytes_per_launch"]
+                    out[key]["traffic_source"] = f"offline rocprofv3 --pmc profile of the same kernels on this workload: profiles/{os.path.basename(pmc)}"
         # Which bound binds.  `frac` above is the prescribed one: compulsory bytes against HBM.  A cache-resident
         # graph (config 2 / 3: the operand fits the Infinity Cache) is bound by the rate at which the L2s serve row gathers -- SURVEY
         # 8(d)'s bytes_gather = 8 nnz + 4 (N+1) + 4 nnz d + 4 N d per result, against the bare gather stream of the same col[] array

@@ -32,7 +32,7 @@ struct Knobs {
   int gemm_lines = 1;        // forward projection's epilogue in whole 128-B lines (neighbouring lanes swap feature blocks first; 0 = the MFMA layout's half lines)
   int gemm_hoist = 1;        // forward projection: biases / previous layer's P / batch-position map requested ahead of the K loop (0 = in the epilogue)
   int gemm_ws = -1;          // d = 128 forward projection without a row list: weight-stationary persistent kernel (proj_ws_kernel) -- -1 = from
-                             // kWsMinRows rows on (dense.hip: there a workgroup walks >= 16 tiles and the 5 us it spends fetching its weights pay), 0 = never, 1 = always
+                             // kWsMinRows = 32,769 rows on (dense.hip: more 128-node tiles than CUs -- the staged tiles would need a second round), 0 = never, 1 = always
   int gemm_ws_wgs = 512;     // its persistent workgroups (two per CU)
   int gemm_ws_mode = 1;      // bit 0: its L2 warm-up pass, bit 1: its weights fetched in whole 128-B lines (lanes trade halves afterwards)
   int gemm_ws_stagger = 4;   // its second generation of workgroups (linear id >= 256) starts this many x 512 cycles late (0 = together)
@@ -129,16 +129,11 @@ __device__ __forceinline__ float4 fma4(float s, float4 x, float4 a) {
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 scale4(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
-// a row of F.normalize (modules/model.py:205): x / max(||x||, eps)
-#ifndef GSS_NORM_DIV
-#define GSS_NORM_DIV 0
-#endif
+// a row of F.normalize (modules/model.py:205): x / max(||x||, eps) -- a DIVISION per element, as torch computes it (one rounding; a multiplication
+// by the reciprocal rounds twice).  Measured at config 2 against the CPU port (tools/norm_order_probe.py, profiles/r05_norm_probe_*.txt): with the
+// reciprocal one of the 840 indication AUCs differs by 1.2e-4 - 3.0e-4 (one swapped pair at n_pos = 2), with the division none by more than 3.6e-5.
 __device__ __forceinline__ float4 unit4(float den, float4 a) {
-#if GSS_NORM_DIV
   return make_float4(__fdiv_rn(a.x, den), __fdiv_rn(a.y, den), __fdiv_rn(a.z, den), __fdiv_rn(a.w, den));
-#else
-  return scale4(1.f / den, a);
-#endif
 }
 
 // F.elu (alpha = 1) and its derivative expressed through the pre-activation

@@ -816,7 +816,7 @@ __global__ __launch_bounds__(256, 1) void proj_ws_kernel(GemmArgs g, int stagger
 
 unsigned long long *g_gemm_stamps = nullptr;   // gss_debug_set_stamp_buffer: diagnostic only, process-wide, not a knob
 
-constexpr int kWsMinRows = 131072;   // gemm_ws = -1: the weight-stationary projection from this many rows on
+constexpr int kWsMinRows = 256 * 128 + 1;   // gemm_ws = -1: the weight-stationary projection from this many rows on -- more 128-node tiles than CUs
 
 template <int EPI>
 static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
@@ -866,8 +866,9 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
     if constexpr (EPI != EPI_SPLIT) {
       // d = 128, all rows: the weight-stationary persistent kernel (round 5; proj_ws_kernel above).  Same bits as the staged tiles.  It
       // spends ~5 us per workgroup pulling its 128 KB of weights before the first MFMA and earns that back tile by tile: slower than the
-      // staged tiles at N = 29,960 (31 vs 28 us), 10-11 % faster from 250k rows on (0.63-0.64 of the fp32-MFMA peak against 0.57-0.58;
-      // profiles/r05_proj_ws_bench.txt) -- automatic from kWsMinRows rows on.
+      // staged tiles while those fit the chip in one round (<= 256 tiles of 128 nodes: 31.3 vs 28.5 us at N = 32,768), faster from the
+      // first tile beyond (N = 36,000: 33.2 vs 46.7 us -- the staged tiles' second round), 8-19 % faster from 45k rows on, 0.63-0.64 of
+      // the fp32-MFMA peak against 0.57-0.58 at 250k - 1M rows (profiles/r05_proj_ws_bench.txt, r05_proj_ws_crossover.txt).
       const bool ws = K().gemm_ws == 1 || (K().gemm_ws < 0 && g.n >= kWsMinRows);
       if (ws && K().gemm_variant == 2 && d == 128 && g.K == 256 && g.J == 128 && !g.rows && g.in1 && (!g.rows_out || g.rows_out_pos)) {
         const int ntiles = ceil_div(g.n, 16);

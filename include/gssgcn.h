@@ -483,7 +483,7 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
  * 2 (nnz-balanced segments, default); "spmm_slices" = 0 (automatic, default) or 1..8 time-separated feature
  * slices in the balanced SpMM; "spmm_seg_edges" = entries per SpMM segment (default 32; applies to gss_csr handles
  * created afterwards); "gemm_variant" = projection tile shape: 2 (by width and row count; default), 3 (128-node tiles of four
- * waves forced), 5 (128-node tiles of eight waves forced); "gemm_ws" = -1 (default: from 131,072 rows on) / 0 / 1: the d = 128 forward projection as the
+ * waves forced), 5 (128-node tiles of eight waves forced); "gemm_ws" = -1 (default: from 32,769 rows on -- more 128-node tiles than CUs) / 0 / 1: the d = 128 forward projection as the
  * weight-stationary persistent kernel (same bits; "gemm_ws_wgs", "gemm_ws_stagger", "gemm_ws_mode" shape its launch); "spmm_pin" = with a manual "spmm_slices": slices time-separated (0, default) or pinned to XCDs (1); the automatic policy pins operands of <= 64 MB; "spmm_fly" = 4 (default) / 8 row gathers in flight per lane group; "spmm_hot_rows" = -1 (default: what
  * gss_csr_set_hot declared) or a row count; "gemm_small_nt", "gemm_nt_cap" = narrowest / widest feature tile of the projections in
  * 16-feature units (0 = automatic); "xcd_remap" = 0 / 1 (default): workgroups that read the same rows share an XCD (dense kernels);

@@ -368,18 +368,20 @@ def test_config2_downstream_auc_with_the_real_drug_indication_pairs():
     delta = np.abs(auc_gpu - auc_cpu)
     record_measured("config2_auc.auc", max_delta=delta.max(), frac_above_1e4=(delta > 1e-4).mean(), median=abs(np.median(auc_gpu) - np.median(auc_cpu)))
     # The north star's 1e-4 is on the two scores evaluate_auc.py prints (median and mean, asserted above).  Per indication the honest
-    # unit is a SWAPPED PAIR: embeddings that differ by 5e-7 order two near-equal scores differently now and then, and one positive
+    # unit is a SWAPPED PAIR: embeddings that differ by 6e-7 order two near-equal scores differently now and then, and one positive
     # and one negative drug swapping places moves that indication's AUC by exactly 1 / (n_pos n_neg) -- 3.0e-4 for an indication with
-    # two positive drugs, whatever the arithmetic.  Measured: round 3 no indication differed by more than 3.6e-5; round 4 (the row
-    # norm's squares added in a stated order) 839 of 840 within 1e-4 and one at 3.01e-4 = one pair at n_pos = 2 (the counter-example to
-    # "every indication within 1e-4" VERDICT round 3 asked to record).  Asserted: no indication moves by more than ONE pair, and
-    # at most 0.5 % of them by more than 1e-4.
+    # two positive drugs.  History: round 3 no indication differed by more than 3.6e-5; round 4 one at 3.0e-4 (a pair at n_pos = 2).
+    # Round 5 traced that to HOW the row is normalised, not to the order of the norm's additions (unchanged since round 3): the
+    # kernels multiplied by 1 / max(||x||, eps) -- two roundings -- where F.normalize divides; with the division
+    # (csrc/common.h unit4) the count is back to round 3's: 1-2 indications differ at all, by one pair each, none by more than 3.6e-5
+    # (tools/norm_order_probe.py on two batch orders, profiles/r05_norm_probe_*.txt).  Asserted: no indication differs by more than
+    # 1e-4, none by more than one pair.
     dset = set(drugs)
     n_pos = np.array([sum(1 for dname in positives.get(ind, ()) if dname in dset) for ind in used_g], dtype=np.float64)
     pairs = delta * n_pos * (len(drugs) - n_pos)
     record_measured("config2_auc.pairs", max_pairs=pairs.max())
     assert pairs.max() < 1.5, (pairs.max(), delta.max())
-    assert (delta > 1e-4).mean() <= 0.005, (delta.max(), (delta > 1e-4).mean())
+    assert delta.max() < 1e-4, (delta.max(), (delta > 1e-4).sum())
     # predict_drug.py:55-73: the drugs ranked for the COVID node
     r_gpu, _ = consumer.rank_by_query(emb_gpu, names, "NodeCovid", drugs)
     r_cpu, _ = consumer.rank_by_query(emb_cpu.numpy(), names, "NodeCovid", drugs)

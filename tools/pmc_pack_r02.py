@@ -15,6 +15,8 @@ PREFIX = sys.argv[1] if len(sys.argv) > 1 else "r02"     # round tag of the pass
 CASES = {  # tag -> (description, n, nnz, d, extra operand rows)
     "wg_fwd1": ("whole_graph stand-in as bench.py runs it (nodes relabelled hub-first), spmm_balanced_kernel<FWD1> (AX = A_hat X, M = AX (.) X)", 29960, 988028, 128, 1),
     "wg_plain": ("whole_graph stand-in as bench.py runs it (nodes relabelled hub-first), spmm_balanced_kernel<PLAIN> (AM = A_hat M)", 29960, 988028, 128, 0),
+    "wgp_fwd1": ("BASELINE config 3: whole_graph + pathway edges stand-in, d = 256, as bench.py --workload whole_graph_pathway runs it, spmm_balanced_kernel<FWD1>", 29960, 988676, 256, 1),
+    "wgp_plain": ("BASELINE config 3: whole_graph + pathway edges stand-in, d = 256, spmm_balanced_kernel<PLAIN>", 29960, 988676, 256, 0),
     "wg_norelabel_fwd1": ("whole_graph stand-in in the loader's node order, FWD1", 29960, 988028, 128, 1),
     "wg_norelabel_plain": ("whole_graph stand-in in the loader's node order, PLAIN", 29960, 988028, 128, 0),
     "r1m_plain": ("RMAT 1M / 20M (+1M self loops), generator node order, PLAIN", 1000000, 21000000, 128, 0),
@@ -60,6 +62,8 @@ for tag, (desc, n, nnz, d, extra) in CASES.items():
         out["hbm_traffic"]["fwd1"] = {"traffic_bytes_per_launch": fetch + write}
     if tag == "wg_plain":
         out["hbm_traffic"]["plain"] = {"traffic_bytes_per_launch": fetch + write}
+    if tag in ("wgp_fwd1", "wgp_plain"):     # config 3 (d = 256): bench.py --workload whole_graph_pathway reads these
+        out.setdefault("hbm_traffic_config3", {})[tag[4:]] = {"traffic_bytes_per_launch": fetch + write}
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{PREFIX}_spmm_pmc.json"), "w"), indent=1)
 for tag, c in out["cases"].items():
     print(f"{tag:14s} traffic {c['traffic_bytes_per_launch'] / 1e9:8.3f} GB = {c['traffic_over_alg']:.2f} x alg, L2 hit {c['l2_hit_rate']:.3f}, "

@@ -192,10 +192,13 @@ for world in [int(v) for v in args.worlds.split(",")]:
             fl = [floor_us(r[f"delivered_bytes_{kind}"][c], r["halo_rows_a"], r["max_pair_rows_a"]) if c < len(r[f"delivered_bytes_{kind}"]) else 0.0 for r in ranks]
             coll.append({"max_delivered_bytes": max((r[f"delivered_bytes_{kind}"][c] if c < len(r[f"delivered_bytes_{kind}"]) else 0) for r in ranks),
                          "xgmi_floor_us": round(max(fl), 2)})
-        comm_us = sum(c["xgmi_floor_us"] for c in coll) + (LATENCY_US * ncoll if world > 1 else 0.0)
+        # latency: per COLLECTIVE the plan enqueued (gss_plan_comm_stats; the four weight gradients are one fused all-reduce but four
+        # deliveries in the log), + the request phase's bitmap exchange where the lazy step's subset exchange is on
+        n_launch = max(sum(r[f"collectives_{kind}"]) for r in ranks)
+        comm_us = sum(c["xgmi_floor_us"] for c in coll) + (LATENCY_US * n_launch if world > 1 else 0.0)
         entry[kind] = {"kernel_ms_by_rank": kt.round(4).tolist(), "critical_rank": int(kt.argmax()), "kernel_ms_max": round(float(kt.max()), 4),
                        "kernel_ms_mean": round(float(kt.mean()), 4), "imbalance_max_over_mean": round(float(kt.max() / kt.mean()), 3),
-                       "collectives": coll, "collectives_us_at_floor_plus_latency": round(comm_us, 1),
+                       "collectives": coll, "collectives_enqueued": n_launch, "collectives_us_at_floor_plus_latency": round(comm_us, 1),
                        "forecast_ms_per_step_no_overlap": round(float(kt.max()) + comm_us * 1e-3, 4)}
     res["worlds"][str(world)] = entry
     for r in ranks:
