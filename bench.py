@@ -306,7 +306,8 @@ def main():
         from gcn_drug_repurposing_amd.shards import ScipySource, build_shard, gaussian_rows, shard_engine
         comm = make_job_comm(world, rank) if sharded else local_comms(1)[0]
         t_setup = time.perf_counter()
-        shard = build_shard(adj if from_source else ScipySource(adj), comm, need_transpose=L > 1)
+        from gcn_drug_repurposing_amd.shards import row_weight_for
+        shard = build_shard(adj if from_source else ScipySource(adj), comm, need_transpose=L > 1, row_weight=row_weight_for(d, L))
         lo_, hi_ = shard.part.rows(rank)
         from gcn_drug_repurposing_amd.shards import shard_rows
         x_rows = gaussian_rows(lo_, hi_, d, 5) if from_source else shard_rows(shard, x_host)

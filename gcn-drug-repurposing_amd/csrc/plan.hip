@@ -1283,7 +1283,7 @@ void gss_plan_destroy(gss_plan *p) {
 // different addresses); the same plan under alternating settings does not.
 int gss_plan_debug_set_option(gss_plan *p, const char *name, int value) {
   GSS_REQUIRE(p && name, "plan_debug_set_option: null argument");
-  static const char *const kLive[] = {"gemm_lines", "spmm_pair", "wgrad_deep", "gemm_hoist", "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "spmm_slices", "spmm_pin", "spmm_fly", "gemm_rows_split", "gemm_ws", "gemm_ws_wgs", "gemm_ws_stagger", "gemm_ws_mode"};
+  static const char *const kLive[] = {"gemm_lines", "spmm_pair", "wgrad_deep", "gemm_hoist", "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "gemm_nt_cap", "spmm_slices", "spmm_pin", "spmm_fly", "gemm_rows_split", "gemm_ws", "gemm_ws_wgs", "gemm_ws_stagger", "gemm_ws_mode"};
   bool ok = false;
   for (const char *k : kLive) ok = ok || strcmp(k, name) == 0;
   GSS_REQUIRE(ok, "plan_debug_set_option: only kernel-selection knobs can change on a live plan");
@@ -1380,9 +1380,11 @@ static int plan_step_impl(gss_plan *p, const int32_t *idx, int32_t b, float beta
       (void)hipStreamSynchronize(p->rq);
       p->lz_pending = false;
     }
+    const bool hosted = host_prep && p->prep_pending == nullptr;
     p->prep_pending = nullptr;
     p->eb_scatter_b = 0;
     if (rc_f) return rc_f;
+    GSS_REQUIRE(!host_prep || hosted, "plan_step_lazy: internal error, no forward SpMM carried the batch preparation");
   } else {
     const int rc_f = plan_forward_impl(p, stream);
     const bool hosted = host_prep && p->prep_pending == nullptr;

@@ -473,9 +473,21 @@ class Shard:
         return self.a.nnz
 
 
-ROW_WEIGHT = 12      # what a row costs besides its stored entries (dense projection, weight gradient, epilogue streams), in units
-                     # of one stored entry of A_hat + A_hat^T: measured at RMAT 10M / 200M, d = 128 (2.15 ns per row and step against
-                     # 0.064 ns per entry visit, 3 visits per entry)
+ROW_WEIGHT = 12      # build_shard's default cost of a row besides its stored entries, in stored entries of A_hat + A_hat^T (callers that know
+                     # the width and depth pass row_weight_for(d, num_layers) instead)
+
+
+def row_weight_for(d, num_layers):
+    """What a row costs a training step besides its stored entries, in units of one stored entry of A_hat + A_hat^T: the dense kernels
+    (projection, input gradient, weight gradient: 3 L - 1 passes over the rows, d^2 work each) against the SpMMs (4 L - 2 passes over the
+    entries, d work each).  Measured with each rank alone on the GPU (tools/scaling_forecast.py, RMAT 10M / 200M, d = 128, L = 2, world 8;
+    profiles/r05_scaling_forecast_c5*.json): a least-squares fit gives 0.124 ns per entry, 3.6 ns per own row and 1.6 ns per BOUNDARY row
+    (halo_recompute projects them, the exchange-free last hop sums the weight gradient over them) -- 29 entries per own row.  The partition
+    cannot price boundary rows (they are a result of it), and with the hub-first order they pile up on the low ranks (rank 0: 4 k own rows,
+    3.0 M boundary rows), so the weight that balances the measured per-rank times is lower: slowest / mean rank 1.27 at 12 (the round-2
+    constant: the ranks with the many low-degree rows are slowest), 1.24 at 29 (the hub ranks are), ~1.1 at 18."""
+    L = max(1, int(num_layers))
+    return max(4, int(round(18.0 * (d / 128.0) * ((3 * L - 1) / 5.0) / ((4 * L - 2) / 6.0))))
 
 
 SPLIT_MIN_HALO_ROWS = 65536   # split="auto": overlap a hop with its exchange from this many boundary rows on (32 MB at d = 128); below

@@ -194,9 +194,10 @@ def main(argv=None):
         # one process per GPU, node-range shards: a native gss_plan per rank that owns the RCCL communicator and enqueues
         # kernels and collectives from C++ (dist.sharded_plan_engine); same step semantics
         from .dist import job_comm, local_comms
-        from .shards import build_shard, shard_engine, shard_rows
+        from .shards import build_shard, row_weight_for, shard_engine, shard_rows
         comm = job_comm(world, rank) if sharded else local_comms(1)[0]
-        shard = build_shard(source, comm, need_transpose=args.num_layers > 1, device=dev, allow_nan=args.allow_nan, name_of=lambda i: names[i])
+        shard = build_shard(source, comm, need_transpose=args.num_layers > 1, device=dev, allow_nan=args.allow_nan, name_of=lambda i: names[i],
+                            row_weight=row_weight_for(d_pad, args.num_layers))
         engine = shard_engine(shard, shard_rows(shard, X32), host_params, comm, num_layers=args.num_layers, layer_decay=args.layer_decay,
                               alpha=args.alpha, lr=args.lr, max_batch=min(bsz, n), cache_layer1=args.cache_layer1)
         if rank == 0:

@@ -412,7 +412,10 @@ int gss_plan_loss_backward(gss_plan *p, const int32_t *idx, int32_t b, float bet
 int gss_plan_backward(gss_plan *p, const int32_t *rows, int32_t b, const float *de_rows, void *stream);
 /* Adam on the four tensors with the plan's gradients; step numbers are counted by the plan */
 int gss_plan_adam(gss_plan *p, void *stream);
-/* forward + loss + backward + Adam = one iteration of train.py:155-184 */
+/* forward + loss + backward + Adam = one iteration of train.py:155-184.  idx[0..b): the batch's node ids (device), DISTINCT -- what the
+ * reference's sampler draws (a permutation cut into batches, method/dataset.py:5-28); the batch-position map holds one position per
+ * node, so a repeated id would leave the other position's rows unwritten.  The same holds for gss_plan_step_lazy and
+ * gss_plan_loss_backward. */
 int gss_plan_step(gss_plan *p, const int32_t *idx, int32_t b, float beta, void *stream);
 /* gss_plan_step with the top layer evaluated on the b batch rows only -- the rows of it that the loss (model.py:216-221) and the
  * backward pass read; the reference computes all N every step (train.py:158-161) and reads B of them.  Loss, gradients and

@@ -40,7 +40,7 @@ ap.add_argument("--layers", type=int, default=2)
 ap.add_argument("--batch", type=int, default=2048)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--rccl-default", type=int, default=1)
-ap.add_argument("--row-weight", type=int, default=None, help="override shards.ROW_WEIGHT (the partition's cost of a row besides its entries)")
+ap.add_argument("--row-weight", type=int, default=None, help="the partition's cost of a row besides its entries (default: shards.row_weight_for(d, layers), what train.py and bench.py pass)")
 args = ap.parse_args()
 lib = pkg.load()
 if args.rccl_default:
@@ -77,7 +77,8 @@ def run_world(world):
             torch.cuda.set_device(0)
             with torch.cuda.stream(torch.cuda.Stream()):
                 from gcn_drug_repurposing_amd.shards import shard_rows
-                kw = {} if args.row_weight is None else {"row_weight": args.row_weight}
+                from gcn_drug_repurposing_amd.shards import row_weight_for
+                kw = {"row_weight": row_weight_for(d, L) if args.row_weight is None else args.row_weight}
                 shard = build_shard(make_source(), comms[rank], need_transpose=L > 1, device="cuda:0", **kw)
                 lo, hi = shard.part.rows(rank)
                 x_loc = feats(lo, hi) if feats else shard_rows(shard, X)
@@ -174,7 +175,8 @@ def floor_us(bytes_in, rows_total, max_pair_rows):
     return bytes_in * share / (XGMI_LINK_GBS * 1e9) * 1e6
 
 
-res = {"workload": args.workload, "n": n, "d": d, "layers": L, "batch": B, "reps": args.reps, "rccl_default_knobs": bool(args.rccl_default),
+from gcn_drug_repurposing_amd.shards import row_weight_for as _rwf  # noqa: E402
+res = {"workload": args.workload, "n": n, "d": d, "layers": L, "batch": B, "reps": args.reps, "row_weight": _rwf(d, L) if args.row_weight is None else args.row_weight, "rccl_default_knobs": bool(args.rccl_default),
        "assumed_latency_us_per_collective": LATENCY_US, "xgmi_link_GBs": XGMI_LINK_GBS,
        "what_this_is": "a FORECAST from per-rank kernel times measured with each rank alone on ONE MI355X (recorded exchange payloads replayed by device "
                        "copies) + collectives priced at the xGMI floor of their most loaded pair + an ASSUMED latency per collective; no two-device run exists",
