@@ -57,6 +57,7 @@ SIGNATURES = {
     "gss_normalize_adj": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P]),
     "gss_rowsum_dinv": (C.c_int, [_I32, _P, _P, _P, _P, _P]),
     "gss_rowsum_check": (C.c_int, [_I32, _P, _P, _P, _P]),
+    "gss_csr_giant_rows": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32)]),
     "gss_scale_adj_shard": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _I32, _P, _P]),
     "gss_csr_create": (C.c_int, [C.POINTER(_P), _I32, _I32, _I64, _P, _P, _P, _P]),
     "gss_csr_destroy": (None, [_P]),

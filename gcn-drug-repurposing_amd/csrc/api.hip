@@ -62,6 +62,11 @@ int set_knob(Knobs &k, const char *name, int value) {
     k.seg_edges = value;
     return GSS_OK;
   }
+  if (strcmp(name, "spmm_giant") == 0) {
+    GSS_REQUIRE(value == 0 || (value >= 64 && value % 4 == 0), "spmm_giant must be 0 (off) or a multiple of 4 >= 64 (stored entries)");
+    k.spmm_giant = value;
+    return GSS_OK;
+  }
   if (strcmp(name, "loss_wgs") == 0) {
     GSS_REQUIRE(value >= 64 && value <= 4096, "loss_wgs must be in [64, 4096]");
     k.loss_wgs = value;

@@ -24,6 +24,8 @@ struct Knobs {
   int spmm_hot = -1;         // overrides every CSR's hot set with rows [0, value) (-1 = the CSR's own, 0 = none)
   int spmm_fly = 4;          // row gathers in flight per lane group on the large-table path (4 or 8)
   int seg_edges = 32;        // entries per SpMM segment (CSR handles created afterwards)
+  int spmm_giant = 32768;    // balanced SpMM, dense modes: rows with more stored entries than this are cut into chunks of a quarter of it that
+                             // other workgroups sum (spmm.hip GiantRows); 0 = never.  CSR handles look at it with their first launch
   int gemm_variant = 2;      // projection tile shape: 2 = by width and row count (default), 3 = 128-node tiles of four waves forced, 5 = of eight waves forced
   int gemm_nt_cap = 0;       // cap of the feature tile width (16-feature units), 0 = none
   int gemm_small_nt = 2;     // narrowest feature tile for small problems, 0 = never narrow

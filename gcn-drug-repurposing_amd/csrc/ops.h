@@ -16,6 +16,11 @@ struct gss_csr {
   std::vector<int32_t> h_rowptr;  // host copy, used to build segment descriptors lazily
   int32_t *d_segs[5];             // balanced SpMM: int4 descriptors per lane group, by log2(groups per wave)
   int32_t n_seg_blocks[5];
+  // a VIEW (spmm.hip GiantRows): the schedule covers the listed rows / entry ranges of the borrowed arrays instead of every row of rowptr
+  bool by_items = false;
+  std::vector<int32_t> item_row, item_first, item_len;
+  struct gss_giant_rows *giant = nullptr;   // rows too long for one workgroup, cut into chunks (built on first use; spmm.hip)
+  int32_t giant_threshold = -1;             // the knob value `giant` was built (or found empty) for; -1 = not looked at yet
 };
 
 // communicator interface of the sharded plan (comm.hip): RCCL, or threads of one process

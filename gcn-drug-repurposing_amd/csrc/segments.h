@@ -1,6 +1,6 @@
 // segments.h -- host-only: the nnz-balanced schedule of the balanced SpMM (spmm.hip spmm_balanced_kernel, ppr.hip ppr_spmm_kernel).
 //
-// Every row is cut into segments of <= seg_edges stored entries; a row with s segments occupies an ALIGNED block of p = pow2ceil(s)
+// Every scheduled row is cut into segments of <= seg_edges stored entries; a row with s segments occupies an ALIGNED block of p = pow2ceil(s)
 // consecutive lane groups of ONE workgroup (waves x 2^gpw_log2 groups), rows too long for that take the whole workgroup with longer
 // segments.  Rows are placed in order of non-increasing block size (then non-increasing length), so blocks stay aligned without
 // gaps; the tail of the last workgroup is padded with empty descriptors (row -1).  One int4 per lane group:
@@ -15,25 +15,30 @@
 
 namespace gss {
 
-// -> number of workgroups; segs receives 4 int32 per lane group
-inline int build_segments(const int32_t *rowptr, int32_t n_rows, int waves, int gpw_log2, int seg_edges, std::vector<int32_t> &segs) {
+struct SegItem {
+  int32_t row, first, len;   // output row, first entry (index into the col / val arrays the kernel is given), entry count
+};
+
+// -> number of workgroups; segs receives 4 int32 per lane group.  `items`: the rows to schedule, in row order (rows that are not
+// listed get no descriptor: nothing computes or writes them)
+inline int build_segments_items(const SegItem *items_in, size_t n_items, int waves, int gpw_log2, int seg_edges, std::vector<int32_t> &segs) {
   const int gpw = 1 << gpw_log2;
   const int ngb = waves * gpw;  // groups per workgroup
   int ngb_log2 = 0;
   while ((1 << ngb_log2) < ngb) ++ngb_log2;
   struct RowItem {
-    int32_t row, len, plog;
+    int32_t row, first, len, plog;
   };
   std::vector<RowItem> items;
-  items.reserve((size_t)(n_rows > 0 ? n_rows : 0));
+  items.reserve(n_items);
   int64_t nnz = 0;
-  for (int32_t r = 0; r < n_rows; ++r) {
-    const int32_t len = rowptr[r + 1] - rowptr[r];
+  for (size_t i = 0; i < n_items; ++i) {
+    const int32_t len = items_in[i].len;
     nnz += len;
     const int sgm = len <= seg_edges ? 1 : (len + seg_edges - 1) / seg_edges;
     int plog = 0;
     while ((1 << plog) < sgm && plog < ngb_log2) ++plog;  // longer rows: whole workgroup, longer segments
-    items.push_back({r, len, plog});
+    items.push_back({items_in[i].row, items_in[i].first, len, plog});
   }
   std::stable_sort(items.begin(), items.end(), [](const RowItem &x, const RowItem &y) {
     return x.plog != y.plog ? x.plog > y.plog : x.len > y.len;
@@ -46,7 +51,7 @@ inline int build_segments(const int32_t *rowptr, int32_t n_rows, int waves, int 
     for (int k = 0; k < p; ++k) {
       const int b0 = std::min(it.len, k * per), b1 = std::min(it.len, (k + 1) * per);
       segs.push_back(it.row);
-      segs.push_back(rowptr[it.row] + b0);
+      segs.push_back(it.first + b0);
       segs.push_back(b1 - b0);
       segs.push_back(it.plog);
     }
@@ -65,6 +70,14 @@ inline int build_segments(const int32_t *rowptr, int32_t n_rows, int waves, int 
       for (int k = 0; k < ngb; ++k) segs[((size_t)bi * ngb + k) * 4 + 3] |= 0x100;
   }
   return nblk;
+}
+
+// every row of a CSR
+inline int build_segments(const int32_t *rowptr, int32_t n_rows, int waves, int gpw_log2, int seg_edges, std::vector<int32_t> &segs) {
+  std::vector<SegItem> items;
+  items.reserve((size_t)(n_rows > 0 ? n_rows : 0));
+  for (int32_t r = 0; r < n_rows; ++r) items.push_back({r, rowptr[r], rowptr[r + 1] - rowptr[r]});
+  return build_segments_items(items.data(), items.size(), waves, gpw_log2, seg_edges, segs);
 }
 
 }  // namespace gss

@@ -54,6 +54,8 @@ struct SpmmEpi {
   int pair_index;               // narrow lane groups take their (col, val) pairs two per lane and trip: whole-line index loads (knob "spmm_pair")
   int pos_row_limit;            // SPMM_BWD2S / SPMM_BWD2, > 0: t, the residual and pos_row are defined for output rows below it only (a shard's
                                 // own rows; the rows behind them -- the boundary rows of the in-place transposed A_hat -- have none)
+  const int32_t *row_alias;     // SPMM_PLAIN, optional (the chunk pass of GiantRows): the row filters (pos, rowbits) are looked up at
+                                // row_alias[row] -- the row a chunk belongs to -- instead of row
 };
 
 struct CsrView {
@@ -321,7 +323,8 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   // SPMM_PLAIN with a row map (ep.pos): only rows with pos[row] >= 0 are computed -- the others' segments gather nothing and store
   // nothing (their output rows keep whatever they held).  A computed row is summed exactly as in the full launch (same segments,
   // same tree): gss_plan_step_lazy's top layer needs A_hat M on the batch rows only
-  if (MODE == SPMM_PLAIN && ep.pos && row >= 0 && ep.pos[row] < 0) {
+  const int frow = (MODE == SPMM_PLAIN && ep.row_alias && row >= 0) ? ep.row_alias[row] : row;   // (the chunk pass: filters speak of the chunk's row)
+  if (MODE == SPMM_PLAIN && ep.pos && row >= 0 && ep.pos[frow] < 0) {
     row = -1;
     e1 = e0;
   }
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
     row = -1;
     e1 = e0;
   }
-  if (MODE == SPMM_PLAIN && ep.rowbits && row >= 0 && !((ep.rowbits[(unsigned)row >> 5] >> (row & 31)) & 1u)) {
+  if (MODE == SPMM_PLAIN && ep.rowbits && row >= 0 && !((ep.rowbits[(unsigned)frow >> 5] >> (frow & 31)) & 1u)) {
     row = -1;
     e1 = e0;
   }
@@ -625,7 +628,14 @@ int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks
     return GSS_OK;
   }
   std::vector<int32_t> segs;
-  const int nblk = build_segments(m->h_rowptr.data(), a->n_rows, kBalWaves, gpw_log2, K().seg_edges, segs);
+  int nblk = 0;
+  if (m->by_items) {
+    std::vector<SegItem> items(m->item_row.size());
+    for (size_t i = 0; i < items.size(); ++i) items[i] = SegItem{m->item_row[i], m->item_first[i], m->item_len[i]};
+    nblk = build_segments_items(items.data(), items.size(), kBalWaves, gpw_log2, K().seg_edges, segs);
+  } else {
+    nblk = build_segments(m->h_rowptr.data(), a->n_rows, kBalWaves, gpw_log2, K().seg_edges, segs);
+  }
   const size_t bytes = segs.size() * sizeof(int32_t);
   if (bytes) {
     GSS_HIP(hipMalloc((void **)&m->d_segs[gpw_log2], bytes));
@@ -707,13 +717,174 @@ static int launch_balanced(const gss_csr *a, int d4, const float *x, const SpmmE
   return launch_balanced_t<MODE, 6, 4>(a, ds, ns, pin, x, ep, st);
 }
 
+}  // namespace gss
+
+// ---- giant rows --------------------------------------------------------------------------------------------------------------
+// A row with more segments than a workgroup has lane groups is ONE workgroup's job (longer segments, segments.h): fine for the hubs of a
+// protein graph (thousands of entries), a tail for the hubs of a scale-free graph with 10^7 nodes -- the top rows of RMAT 10M / 200M hold
+// ~270 k entries each, and the workgroup that walks one gathers for milliseconds while the rest of the launch has drained (on ONE GPU it
+// starts first and hides under a 30 ms launch; on the shard that owns the hubs it doubled the launch: 5.0 ms against 2.6-3.0 ms on the
+// shards next to it with as many entries, profiles/r05_scaling_forecast_c5.json).  Rows above `spmm_giant` entries (default 32,768)
+// are therefore cut into CHUNKS of a quarter of that, and a dense-mode product runs as three launches of the same kernel:
+//   1. chunks:  a view whose rows are the chunks -- entry ranges of the ORIGINAL col / val arrays -- PLAIN product into a scratch
+//               [chunks][d]; the caller's row filters are looked up at the chunk's row (SpmmEpi::row_alias);
+//   2. short:   the caller's product and epilogue over a schedule WITHOUT the giant rows;
+//   3. finish:  the caller's product and epilogue over a [rows] x [chunks] matrix of ones -- a giant row = the sum of its chunks, in
+//               chunk order -- gathered from the scratch.
+// Every row is still written by exactly one lane group, every sum has one fixed order (inside a chunk as inside a row; chunks in
+// order): bit-reproducible, and the same on one GPU and on a shard (a row's length does not depend on who owns it).  A giant row's sum
+// is grouped differently from an unchunked one (rounding-level).  The sparse walks (the batch-sparse backward hops, the gather-filtered
+// first pass) keep the single schedule: they test entries, they do not gather for most of them.
+struct gss_giant_rows {
+  int32_t n_giant = 0, n_chunks = 0;
+  gss_csr chunks{}, shortv{}, finish{};
+  int32_t *d_chunk_row = nullptr, *d_fin_col = nullptr;
+  float *d_fin_val = nullptr;
+  ~gss_giant_rows() {
+    for (gss_csr *v : {&chunks, &shortv, &finish})
+      for (int k = 0; k < 5; ++k)
+        if (v->d_segs[k]) (void)hipFree(v->d_segs[k]);
+    if (d_chunk_row) (void)hipFree(d_chunk_row);
+    if (d_fin_col) (void)hipFree(d_fin_col);
+    if (d_fin_val) (void)hipFree(d_fin_val);
+  }
+};
+
+namespace gss {
+
+static void giant_view_init(gss_csr &v, const gss_csr *a, int32_t n_rows, int32_t n_cols) {
+  v.n_rows = n_rows;
+  v.n_cols = n_cols;
+  v.nnz = 0;
+  v.rowptr = a->rowptr;   // (the balanced kernel reads descriptors, not rowptr)
+  v.col = a->col;
+  v.val = a->val;
+  v.n_long = 0;
+  v.d_long_rows = nullptr;
+  v.max_row = 0;
+  v.hot_own = a->hot_own;
+  v.hot_halo0 = a->hot_halo0;
+  v.hot_halo1 = a->hot_halo1;
+  for (int k = 0; k < 5; ++k) {
+    v.d_segs[k] = nullptr;
+    v.n_seg_blocks[k] = 0;
+  }
+  v.by_items = true;
+}
+
+// the chunked views of `a`, or NULL when it has no giant row (looked at once per handle, with the knob as it stands then)
+static int csr_giant_rows(const gss_csr *a, gss_giant_rows **out) {
+  gss_csr *m = const_cast<gss_csr *>(a);   // lazily filled cache; a gss_csr is used from one host thread
+  *out = nullptr;
+  if (m->by_items) return GSS_OK;          // a view itself
+  const int thr = K().spmm_giant;
+  if (m->giant_threshold == thr) {
+    *out = m->giant;
+    return GSS_OK;
+  }
+  delete m->giant;
+  m->giant = nullptr;
+  m->giant_threshold = thr;
+  if (thr <= 0 || m->h_rowptr.empty()) return GSS_OK;
+  const int32_t chunk = thr / 4;
+  const int32_t *rp = m->h_rowptr.data();
+  int64_t n_giant = 0;
+  for (int32_t r = 0; r < a->n_rows; ++r) n_giant += (rp[r + 1] - rp[r]) > thr;
+  if (n_giant == 0) return GSS_OK;
+  gss_giant_rows *g = new gss_giant_rows();
+  std::vector<int32_t> chunk_row;
+  giant_view_init(g->chunks, a, 0, a->n_cols);
+  giant_view_init(g->shortv, a, a->n_rows, a->n_cols);
+  giant_view_init(g->finish, a, a->n_rows, 0);
+  for (int32_t r = 0; r < a->n_rows; ++r) {
+    const int32_t len = rp[r + 1] - rp[r];
+    if (len <= thr) {
+      g->shortv.item_row.push_back(r);
+      g->shortv.item_first.push_back(rp[r]);
+      g->shortv.item_len.push_back(len);
+      continue;
+    }
+    const int32_t c0 = (int32_t)chunk_row.size();
+    for (int32_t b0 = 0; b0 < len; b0 += chunk) {
+      g->chunks.item_row.push_back((int32_t)chunk_row.size());
+      g->chunks.item_first.push_back(rp[r] + b0);
+      g->chunks.item_len.push_back(std::min(chunk, len - b0));
+      chunk_row.push_back(r);
+    }
+    g->finish.item_row.push_back(r);
+    g->finish.item_first.push_back(c0);
+    g->finish.item_len.push_back((int32_t)chunk_row.size() - c0);
+  }
+  g->n_giant = (int32_t)n_giant;
+  g->n_chunks = (int32_t)chunk_row.size();
+  g->chunks.n_rows = g->n_chunks;
+  g->finish.n_cols = g->n_chunks;
+  g->finish.hot_own = -1;                  // the scratch is small: no hot / cold split
+  std::vector<int32_t> fin_col((size_t)g->n_chunks);
+  std::vector<float> fin_val((size_t)g->n_chunks, 1.0f);
+  for (int32_t k = 0; k < g->n_chunks; ++k) fin_col[(size_t)k] = k;
+  hipError_t e = hipMalloc((void **)&g->d_chunk_row, sizeof(int32_t) * (size_t)g->n_chunks);
+  if (e == hipSuccess) e = hipMalloc((void **)&g->d_fin_col, sizeof(int32_t) * (size_t)g->n_chunks);
+  if (e == hipSuccess) e = hipMalloc((void **)&g->d_fin_val, sizeof(float) * (size_t)g->n_chunks);
+  if (e == hipSuccess) e = hipMemcpy(g->d_chunk_row, chunk_row.data(), sizeof(int32_t) * (size_t)g->n_chunks, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(g->d_fin_col, fin_col.data(), sizeof(int32_t) * (size_t)g->n_chunks, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(g->d_fin_val, fin_val.data(), sizeof(float) * (size_t)g->n_chunks, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    delete g;
+    return fail(GSS_EHIP, "spmm: giant-row tables -> %s", hipGetErrorString(e));
+  }
+  g->finish.col = g->d_fin_col;
+  g->finish.val = g->d_fin_val;
+  m->giant = g;
+  *out = g;
+  return GSS_OK;
+}
+
+template <int MODE>
+static int launch_giant(const gss_csr *a, gss_giant_rows *g, int d4, const float *x, const SpmmEpi &ep, hipStream_t st) {
+  (void)a;
+  float *scratch = nullptr;
+  GSS_HIP(hipMallocAsync((void **)&scratch, sizeof(float) * 4 * (size_t)d4 * (size_t)g->n_chunks, st));
+  int rc = GSS_OK;
+  {
+    // 1. the chunks' partial sums; only chunks of rows the caller's product computes at all
+    SpmmEpi pe{};
+    pe.o0 = scratch;
+    pe.row_alias = g->d_chunk_row;
+    if (MODE == SPMM_PLAIN) {
+      pe.pos = ep.pos;
+      pe.rowbits = ep.rowbits;
+    }
+    if (MODE == SPMM_FWD1) pe.rowbits = ep.posbits;   // (FWD1 keeps its row bitmap in posbits)
+    rc = launch_balanced<SPMM_PLAIN>(&g->chunks, d4, x, pe, st);
+  }
+  // 2. every other row: the caller's product as it is (the batch-preparation side job of a FWD1 launch rides here)
+  if (rc == GSS_OK) rc = launch_balanced<MODE>(&g->shortv, d4, x, ep, st);
+  // 3. the giant rows: the sum of their chunks + the caller's epilogue
+  if (rc == GSS_OK) {
+    SpmmEpi fe = ep;
+    fe.prep = BatchPrep{};
+    rc = launch_balanced<MODE>(&g->finish, d4, scratch, fe, st);
+  }
+  (void)hipFreeAsync(scratch, st);
+  return rc;
+}
+
 template <int MODE>
 static int launch_spmm(const gss_csr *a, int32_t d, const float *x, const SpmmEpi &ep, void *stream) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(a && x, "spmm: null operand");
   hipStream_t st = as_stream(stream);
   const int d4 = d / 4;
-  if (K().spmm_variant == 2) return launch_balanced<MODE>(a, d4, x, ep, st);
+  if (K().spmm_variant == 2) {
+    constexpr bool kDense = MODE == SPMM_FWD1 || MODE == SPMM_PLAIN || MODE == SPMM_BWD1 || MODE == SPMM_BWD2;
+    if (kDense && !(MODE == SPMM_PLAIN && ep.gather_bits)) {
+      gss_giant_rows *g = nullptr;
+      if (int rc = csr_giant_rows(a, &g)) return rc;
+      if (g) return launch_giant<MODE>(a, g, d4, x, ep, st);
+    }
+    return launch_balanced<MODE>(a, d4, x, ep, st);
+  }
   if (d4 <= 4) return launch_spmm_t<MODE, 2, 1>(a, d4, x, ep, st);
   if (d4 <= 8) return launch_spmm_t<MODE, 3, 1>(a, d4, x, ep, st);
   if (d4 <= 16) return launch_spmm_t<MODE, 4, 1>(a, d4, x, ep, st);
@@ -1003,11 +1174,28 @@ int gss_csr_set_hot(gss_csr *a, int32_t own_hot, int32_t halo_begin, int32_t hal
   a->hot_own = own_hot;
   a->hot_halo0 = halo_begin;
   a->hot_halo1 = halo_end;
+  if (a->giant)   // the views that gather from the same operand follow
+    for (gss_csr *v : {&a->giant->chunks, &a->giant->shortv}) {
+      v->hot_own = own_hot;
+      v->hot_halo0 = halo_begin;
+      v->hot_halo1 = halo_end;
+    }
+  return GSS_OK;
+}
+
+int gss_csr_giant_rows(const gss_csr *a, int32_t *n_rows_out, int32_t *n_chunks_out) {
+  GSS_REQUIRE(a && n_rows_out && n_chunks_out, "csr_giant_rows: null argument");
+  KnobScope none(nullptr);
+  gss_giant_rows *g = nullptr;
+  if (int rc = csr_giant_rows(a, &g)) return rc;
+  *n_rows_out = g ? g->n_giant : 0;
+  *n_chunks_out = g ? g->n_chunks : 0;
   return GSS_OK;
 }
 
 void gss_csr_destroy(gss_csr *a) {
   if (!a) return;
+  delete a->giant;
   if (a->d_long_rows) (void)hipFree(a->d_long_rows);
   for (int k = 0; k < 5; ++k)
     if (a->d_segs[k]) (void)hipFree(a->d_segs[k]);

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GSS_ABI_VERSION 5   /* 5 (round 5): gss_rowsum_check, gss_plan_sync_stats, gss_comm_local_mode / gss_comm_local_log; 4 (round 4): gss_shard_desc gained a_loc_t, gss_plan_comm_stats, gss_knn_topk_rows */
+#define GSS_ABI_VERSION 5   /* 5 (round 5): gss_rowsum_check, gss_plan_sync_stats, gss_comm_local_mode / gss_comm_local_log, gss_csr_giant_rows; 4 (round 4): gss_shard_desc gained a_loc_t, gss_plan_comm_stats, gss_knn_topk_rows */
 
 #define GSS_OK 0
 #define GSS_EINVAL (-22)   /* bad argument (shape, null pointer, unsupported d) */
@@ -85,6 +85,13 @@ void gss_csr_destroy(gss_csr *a);
  * every other row with the non-temporal policy, so that once-read rows do not evict the hubs' rows.  own_hot = -1: no split
  * (the default).  Speed only: results are unchanged. */
 int gss_csr_set_hot(gss_csr *a, int32_t own_hot, int32_t halo_begin, int32_t halo_end);
+/* Rows with more stored entries than knob "spmm_giant" (default 32,768; 0 = never) are not one workgroup's job: the dense products cut
+ * them into chunks of a quarter of that, sum the chunks in a pass of their own and add a row's chunks in order in a finish pass that runs
+ * the product's epilogue (three launches of the same kernel; results agree with the unchunked sum to rounding, rows below the threshold
+ * keep their bits).  The hubs of a 10^7-node scale-free graph hold ~3 x 10^5 entries: as one workgroup's job such a row alone outlasts
+ * the rest of a shard's launch.  A handle looks at the knob with its first product (or with this call): n_rows_out = its giant rows,
+ * n_chunks_out = their chunks. */
+int gss_csr_giant_rows(const gss_csr *a, int32_t *n_rows_out, int32_t *n_chunks_out);
 
 /* ---- K1/K2  torch.sparse.mm + torch.mul, modules/model.py:163,168-169 -----------------------
  * y = A x  (x: [n_cols][d], y: [n_rows][d]).  If m != NULL also m = y (.) h, h: [n_rows][d]
@@ -485,7 +492,8 @@ int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void 
 /* tuning/debug knobs (A/B runs inside one process): "spmm_variant" = 1 (whole-row gather, wave per row) or
  * 2 (nnz-balanced segments, default); "spmm_slices" = 0 (automatic, default) or 1..8 time-separated feature
  * slices in the balanced SpMM; "spmm_seg_edges" = entries per SpMM segment (default 32; applies to gss_csr handles
- * created afterwards); "gemm_variant" = projection tile shape: 2 (by width and row count; default), 3 (128-node tiles of four
+ * created afterwards); "spmm_giant" = stored entries above which a row is summed chunk by chunk across workgroups (default 32768, 0 = never;
+ * gss_csr_giant_rows); "gemm_variant" = projection tile shape: 2 (by width and row count; default), 3 (128-node tiles of four
  * waves forced), 5 (128-node tiles of eight waves forced); "gemm_ws" = -1 (default: from 32,769 rows on -- more 128-node tiles than CUs) / 0 / 1: the d = 128 forward projection as the
  * weight-stationary persistent kernel (same bits; "gemm_ws_wgs", "gemm_ws_stagger", "gemm_ws_mode" shape its launch); "spmm_pin" = with a manual "spmm_slices": slices time-separated (0, default) or pinned to XCDs (1); the automatic policy pins operands of <= 64 MB; "spmm_fly" = 4 (default) / 8 row gathers in flight per lane group; "spmm_hot_rows" = -1 (default: what
  * gss_csr_set_hot declared) or a row count; "gemm_small_nt", "gemm_nt_cap" = narrowest / widest feature tile of the projections in

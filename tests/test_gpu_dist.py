@@ -191,6 +191,66 @@ def test_native_collectives_local_backend():
             assert torch.equal(blk[rows[o]:], torch.zeros(maxr - rows[o], d))
 
 
+def test_local_backend_records_and_replays_what_collectives_deliver():
+    """gss_comm_local_mode (the measurement aid behind tools/scaling_forecast.py): in mode 1 every collective keeps a device copy of what it
+    DELIVERED to this rank; in mode 2 the same call sequence is served from those copies with no peer taking part -- here by ONE rank
+    thread while the other never calls --, a different size is refused, and mode 0 forgets the log.  Also: the sharded plan's recorded step
+    replays alone (same collective sequence) and leaves its guards intact."""
+    from gcn_drug_repurposing_amd import GssError
+    from gcn_drug_repurposing_amd.dist import local_comms
+    world, d = 2, 16
+    comms = local_comms(world)
+    out, errors = [None] * world, []
+    off_send = [np.array([0, 0, 3], dtype=np.int64), np.array([0, 2, 2], dtype=np.int64)]     # rank 0 sends 3 rows to rank 1, rank 1 sends 2 to rank 0
+    off_recv = [np.array([0, 0, 2], dtype=np.int64), np.array([0, 3, 3], dtype=np.int64)]
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                c = comms[rank]
+                c.local_mode(1)
+                send = (100.0 * (rank + 1) + torch.arange(4 * d, device="cuda").float()).view(4, d)
+                recv = torch.zeros(4, d, device="cuda")
+                c.exchange_rows(d, send, off_send[rank], recv, off_recv[rank])
+                t = torch.full((9,), float(rank + 1), device="cuda")
+                c.all_reduce_sum_(t)
+                g = c.allgather_bytes(torch.full((5,), float(10 + rank), device="cuda"))
+                torch.cuda.current_stream().synchronize()
+                out[rank] = (recv.clone(), t.clone(), g.clone(), c.local_log())
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            comms[rank].abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not errors, errors
+    n_recv0 = int(off_recv[0][-1])
+    assert out[0][3] == [n_recv0 * d * 4, 9 * 4, 2 * 5 * 4]
+    # replay on rank 0 ALONE (rank 1 does nothing): no barrier, the recorded payloads come back
+    c = comms[0]
+    c.local_mode(2)
+    recv = torch.full((4, d), -1.0, device="cuda")
+    c.exchange_rows(d, torch.zeros(4, d, device="cuda"), off_send[0], recv, off_recv[0])
+    t = torch.zeros(9, device="cuda")
+    c.all_reduce_sum_(t)
+    g = c.allgather_bytes(torch.zeros(5, device="cuda"))
+    torch.cuda.synchronize()
+    assert torch.equal(recv[:n_recv0], out[0][0][:n_recv0]) and torch.equal(recv[n_recv0:], torch.full((4 - n_recv0, d), -1.0, device="cuda"))
+    assert torch.equal(t, torch.full((9,), 3.0, device="cuda")) and torch.equal(g, out[0][2])
+    with pytest.raises(GssError):                      # a fourth collective was never recorded
+        c.all_reduce_sum_(t)
+    c.local_mode(2)                                    # rewinds
+    with pytest.raises(GssError):                      # the first recorded collective delivered another size
+        c.all_reduce_sum_(t)
+    c.local_mode(0)
+    assert c.local_log() == []
+    from gcn_drug_repurposing_amd.dist import rccl_comm
+    with pytest.raises(GssError):                      # only the in-process backend records
+        rccl_comm(1, 0).local_mode(1)
+
+
 def test_native_halo_exchange_local_backend():
     """gss_exchange_rows (the boundary form of C1) through the in-process backend: uneven lists, an empty pair"""
     import ctypes as C

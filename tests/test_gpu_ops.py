@@ -236,6 +236,74 @@ def test_spmm_hot_cold_split_and_deeper_queues_do_not_change_a_bit(G, d):
     assert torch.equal(run()[0], base[0])
 
 
+@pytest.mark.parametrize("d", [16, 64, 128, 256])
+def test_giant_rows_are_summed_chunk_by_chunk_across_workgroups(G, d):
+    """Rows with more stored entries than knob spmm_giant (default 32,768; 64 here) are cut into chunks of a quarter of it: a chunk pass
+    sums them into a scratch, the product proper runs over the other rows, and a finish pass adds a giant row's chunks in order and runs
+    the caller's epilogue (spmm.hip GiantRows).  Every dense form -- plain, Hadamard-fused, both backward epilogues, the second pass of a
+    two-pass product -- must equal the fp64 product to the usual tolerance and the unchunked kernel to rounding; rows below the
+    threshold keep their bits; empty rows and a row that holds every column are covered."""
+    rng = np.random.RandomState(3 * d + 1)
+    n = 2100
+    a = random_graph(rng, n, 7, hub_rows=(5, 900, 1500), hub_deg=1300, empty_rows=(2, n - 1))
+    a = sp.lil_matrix(a)
+    a[40, :] = rng.uniform(0.1, 1.0, n)                      # one row with every column: 33 chunks of 16
+    a = sp.csr_matrix(a)
+    a.sort_indices()
+    a32 = sp.csr_matrix((a.data.astype(np.float32), a.indices, a.indptr), shape=a.shape)
+    A = a32.astype(np.float64)
+    lens = np.diff(a32.indptr)
+    giant = np.flatnonzero(lens > 64)
+    small = torch.from_numpy(np.flatnonzero(lens <= 64)).cuda()
+    assert len(giant) >= 4 and lens.max() == n
+    x, hh, gam, gax, xin, ax, pp, res = (rng.randn(n, d).astype(np.float32) for _ in range(8))
+    xd, hd, gam_d, gax_d, xin_d, ax_d, p_d, res_d = (cu(v) for v in (x, hh, gam, gax, xin, ax, pp, res))
+
+    def run(thr):
+        G._lib.check(G.lib.gss_debug_set_option(b"spmm_giant", thr))
+        try:
+            csr = G.graph.DeviceCSR(a32.indptr, a32.indices, a32.data, n, n, "cuda")     # a handle looks at the knob with its first launch
+            ng, nc = C.c_int32(-1), C.c_int32(-1)
+            G._lib.check(G.lib.gss_csr_giant_rows(csr.handle, C.byref(ng), C.byref(nc)))
+            assert (ng.value, nc.value) == ((len(giant), int(sum(-(-int(l) // 16) for l in lens[giant]))) if thr else (0, 0))
+            out = {}
+            y, m = torch.full((n, d), float("nan"), device="cuda"), torch.full((n, d), float("nan"), device="cuda")
+            G._lib.check(G.lib.gss_spmm(csr.handle, d, xd.data_ptr(), y.data_ptr(), None, None, G.st()))
+            out["plain"] = y.clone()
+            G._lib.check(G.lib.gss_spmm(csr.handle, d, xd.data_ptr(), y.data_ptr(), hd.data_ptr(), m.data_ptr(), G.st()))
+            out["fwd1_y"], out["fwd1_m"] = y.clone(), m.clone()
+            u, t = torch.empty(n, d, device="cuda"), torch.empty(n, d, device="cuda")
+            G._lib.check(G.lib.gss_spmm_bwd1(csr.handle, d, gam_d.data_ptr(), gax_d.data_ptr(), xin_d.data_ptr(), ax_d.data_ptr(), u.data_ptr(),
+                                             t.data_ptr(), G.st()))
+            out["u"], out["t"] = u.clone(), t.clone()
+            dp, gx = torch.empty(n, d, device="cuda"), torch.empty(n, d, device="cuda")
+            G._lib.check(G.lib.gss_spmm_bwd2(csr.handle, d, gam_d.data_ptr(), gax_d.data_ptr(), p_d.data_ptr(), 0.3, res_d.data_ptr(), dp.data_ptr(),
+                                             gx.data_ptr(), G.st()))
+            out["dp"], out["gx"] = dp.clone(), gx.clone()
+            # second pass of a two-pass product: y_in + A x, then the Hadamard epilogue
+            y2, m2 = out["plain"].clone(), torch.empty(n, d, device="cuda")
+            G._lib.check(G.lib.gss_spmm_add(csr.handle, d, xd.data_ptr(), y2.data_ptr(), y2.data_ptr(), hd.data_ptr(), m2.data_ptr(), G.st()))
+            out["add_y"], out["add_m"] = y2.clone(), m2.clone()
+            torch.cuda.synchronize()
+            return out
+        finally:
+            G._lib.check(G.lib.gss_debug_set_option(b"spmm_giant", 32768))
+
+    whole, chunked = run(0), run(64)
+    ax_ref = A @ x.astype(np.float64)
+    dm = A @ gam.astype(np.float64)
+    gref = gax.astype(np.float64) + A @ gam.astype(np.float64)          # bwd2 called with u := gam, t := gax
+    refs = {"plain": ax_ref, "fwd1_y": ax_ref, "fwd1_m": ax_ref * hh, "u": gax + dm * xin, "t": dm * ax, "gx": gref,
+            "dp": 0.3 * gref * np.where(pp > 0, 1.0, np.exp(np.minimum(pp, 0).astype(np.float64))) + res,
+            "add_y": 2 * ax_ref, "add_m": 2 * ax_ref * hh}
+    for k, ref in refs.items():
+        assert rel_err(chunked[k].cpu().numpy(), ref) < 3e-6, k
+        assert rel_err(chunked[k].cpu().numpy(), whole[k].cpu().numpy()) < 1e-6, k
+        assert torch.equal(chunked[k].index_select(0, small), whole[k].index_select(0, small)), k      # rows below the threshold: same bits
+    for r in (2, n - 1):                                                     # empty rows: zeros / the epilogue of a zero sum
+        assert float(chunked["plain"][r].abs().max()) == 0.0
+
+
 def test_spmm_backward_epilogues(G, spmm_variant):
     rng = np.random.RandomState(5)
     n, d = 900, 128

@@ -269,3 +269,11 @@ def test_gss_options_environment_is_checked(tmp_path):
     for bad in ("lazy_halo=7", "no_such_knob=1", "lazy_halo"):
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, GSS_OPTIONS=bad), capture_output=True, text=True)
         assert r.returncode != 0 and "GSS_OPTIONS" in r.stderr, (bad, r.stderr[-500:])
+
+
+def test_partition_row_weight_follows_width_and_depth():
+    """shards.row_weight_for: the cost of a row in stored entries that the node-range partition balances with -- the measured 18 at
+    d = 128, L = 2 (tools/scaling_forecast.py), doubling with the width (dense work ~ d^2, SpMM work ~ d), near-constant in the depth"""
+    from gcn_drug_repurposing_amd.shards import ROW_WEIGHT, row_weight_for
+    assert row_weight_for(128, 2) == 18 and row_weight_for(256, 2) == 36 and row_weight_for(64, 2) == 9
+    assert 30 <= row_weight_for(256, 3) <= 40 and row_weight_for(16, 2) >= 4 and ROW_WEIGHT == 12
