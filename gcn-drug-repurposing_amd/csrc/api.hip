@@ -156,7 +156,7 @@ int set_knob(Knobs &k, const char *name, int value) {
     return GSS_OK;
   }
   if (strcmp(name, "gemm_ws") == 0) {
-    GSS_REQUIRE(value >= -1 && value <= 2, "gemm_ws must be -1 (by row count), 0, 1 or 2 (eight waves x 16 features, one workgroup per CU)");
+    GSS_REQUIRE(value >= -1 && value <= 1, "gemm_ws must be -1 (by row count), 0 or 1");
     k.gemm_ws = value;
     return GSS_OK;
   }

@@ -797,130 +797,6 @@ __global__ __launch_bounds__(256, 1) void proj_ws_kernel(GemmArgs g, int stagger
   }
 }
 
-// ---- the same with EIGHT waves per workgroup, 16 features each, ONE workgroup per CU (round 5, knob gemm_ws = 2) ---------------------
-// proj_ws_kernel keeps [W1 | W2] twice per CU (two workgroups of four waves x 32 features): 256 KB through the L2s before the first
-// MFMA, 6.5 - 11 us at N = 29,960 -- what it never earns back at that size.  Here a workgroup is eight waves, wave w owns features
-// [16 w, 16 w + 16): the weights sit in the CU's registers ONCE (64 registers per lane), every SIMD still hosts two waves (so one's
-// LDS reads, exp and stores fall under the other's MFMAs), a tile is 64 MFMAs per wave.  The price: a wave's 16 features of a row
-// are 64 B -- the epilogue moves half cache lines, as the MFMA layout has it.  Same k order per output, same block order in the row
-// norm: the same bits as every other form.
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void proj_ws8_kernel(GemmArgs g, int flags) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NCH = 16;             // 16-wide chunks of K = 2 d = 256
-  constexpr int SLOT = NCH * 256;     // floats of one tile: 16 rows x 256 k as 16 fragment blocks of 1 KB
-  constexpr int NSLOT = 3;
-  float *lds = reinterpret_cast<float *>(smem);
-  float *part = lds + NSLOT * SLOT;   // [2][16 rows][4 q][8 blocks] partial sums of squares (EPI_FWD_NORM)
-  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 .. 7
-  const int r = lane & 15, q = lane >> 4;
-  const int ntiles = (g.n + 15) >> 4;
-  const int G = (int)gridDim.x, b = (int)blockIdx.x;
-  const int my_tiles = b < ntiles ? (ntiles - b + G - 1) / G : 0;
-  if (my_tiles == 0) return;
-
-  // a tile's DMA: wave w stages fragment blocks w (AX, k = 16 w ..) and 8 + w (AM)
-  auto stage_piece = [&](int i, int k) {
-    const int node = min(g.n - 1, 16 * (b + i * G) + r);
-    const float *s = (k == 0 ? g.in0 + (size_t)node * g.ld_in0 : g.in1 + (size_t)node * g.ld_in1) + 4 * q + 16 * w;
-    glds16(s, lds_base + (unsigned)(((i % NSLOT) * SLOT + (w + 8 * k) * 256) * 4));
-  };
-  stage_piece(0, 0);
-  stage_piece(0, 1);
-  if (my_tiles > 1) {
-    stage_piece(1, 0);
-    stage_piece(1, 1);
-  }
-  // L2 warm-up (see proj_ws_kernel): the 32 workgroups x 8 waves of an XCD touch the 128 KB of [W1 | W2] one KB each, then wait
-  if (flags & 1) {
-    const int slice = (((b >> 3) & 31) * 8 + w) & 127;   // KB of W1 (< 64) or W2
-    const float *wp = g.w[0][slice >> 6] + (size_t)(slice & 63) * 256 + 4 * lane;
-    f32x4 sink;
-    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(sink) : "v"(wp) : "memory");
-  }
-  // the wave's slice of [W1 | W2]: features 16 w + r, chunk c (k = 16 c + 4 q .. + 3; c >= 8 is W2)
-  float4 wr[NCH];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) wr[c] = ld4(g.w[0][c >> 3] + (size_t)(16 * w + r) * g.ld_w + 16 * (c & 7) + 4 * q);
-  const int j = 16 * w + 4 * q;       // the lane's columns
-  const float4 bb = add4(ld4(g.b1 + j), ld4(g.b2 + j));
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): both tiles and the weights are in (the builtin form: see proj_ws_kernel)
-  __builtin_amdgcn_s_barrier();
-
-  for (int i = 0; i < my_tiles; ++i) {
-    const int T = b + i * G;
-    const int row = 16 * T + r;
-    const bool live = row < g.n;
-    const int nd = min(row, g.n - 1);
-    float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.p_prev) pp = ld4(g.p_prev + (size_t)nd * g.ld_out0 + j);
-    int orow = -1;
-    if (EPI == EPI_FWD_NORM && g.rows_out) orow = g.rows_out_pos[nd];
-    const bool ahead = i + 2 < my_tiles;
-
-    const float *cur = lds + (i % NSLOT) * SLOT + lane * 4;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 bf[4];
-    bf[0] = *reinterpret_cast<const float4 *>(cur);
-    bf[1] = *reinterpret_cast<const float4 *>(cur + 256);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      if (c + 2 < NCH) bf[(c + 2) & 3] = *reinterpret_cast<const float4 *>(cur + (c + 2) * 256);
-      if ((c == 1 || c == 3) && ahead) stage_piece(i + 2, c >> 1);   // the next-but-one tile's two pieces, in the shadow of the MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-      const float4 bc = bf[c & 3];
-      acc = mfma16(wr[c].x, bc.x, acc);
-      acc = mfma16(wr[c].y, bc.y, acc);
-      acc = mfma16(wr[c].z, bc.z, acc);
-      acc = mfma16(wr[c].w, bc.w, acc);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // tile i + 1 (requested a whole tile ago), this tile's operands and the previous tile's stores: all but the two pieces just requested
-    if (ahead)
-      wait_vmcnt<2>();
-    else
-      wait_vmcnt<0>();
-
-    const float4 pv = add4(make_float4(acc[0], acc[1], acc[2], acc[3]), bb);
-    float4 o = make_float4(elu1(pv.x), elu1(pv.y), elu1(pv.z), elu1(pv.w));
-    if (g.p_prev) o = add4(pp, scale4(g.decay, o));
-    float den = 1.f;
-    if (EPI == EPI_FWD_NORM) {
-      // F.normalize: this lane's block (w) of row r goes to LDS; behind the barrier every lane adds its row's eight blocks in block order,
-      // then the two shuffles over q of the other forms
-      float *pt = part + (i & 1) * 512;
-      pt[(r * 4 + q) * 8 + w] = sumsq4(o);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      const float4 s0 = *reinterpret_cast<const float4 *>(pt + (r * 4 + q) * 8);
-      const float4 s1 = *reinterpret_cast<const float4 *>(pt + (r * 4 + q) * 8 + 4);
-      float ss = 0.f;
-      ss = __fadd_rn(ss, s0.x);
-      ss = __fadd_rn(ss, s0.y);
-      ss = __fadd_rn(ss, s0.z);
-      ss = __fadd_rn(ss, s0.w);
-      ss = __fadd_rn(ss, s1.x);
-      ss = __fadd_rn(ss, s1.y);
-      ss = __fadd_rn(ss, s1.z);
-      ss = __fadd_rn(ss, s1.w);
-      ss += __shfl_xor(ss, 16, 64);
-      ss += __shfl_xor(ss, 32, 64);
-      den = fmaxf(sqrtf(ss), 1e-12f);
-    } else {
-      __builtin_amdgcn_s_barrier();   // every wave has read this tile's slot and has the next tile's pieces in
-    }
-    if (live) {
-      const size_t off = (size_t)nd * g.ld_out0 + j;
-      st4(g.out0 + off, pv);
-      st4(g.x_next + off, EPI == EPI_FWD_NORM ? unit4(den, o) : o);
-      if (EPI == EPI_FWD_NORM && orow >= 0) st4(g.rows_out + (size_t)orow * g.ld_out0 + j, unit4(den, o));
-      if (EPI == EPI_FWD_NORM && w == 0 && q == 0) g.inv_den[nd] = 1.f / den;
-    }
-  }
-}
-
 // Measured dead end, for the record: a weights-resident variant for d <= 128 ([W1|W2] = 128 KB DMA'd into LDS once per
 // workgroup, 8 independent waves per CU, each holding its 16-node [AX|AM] block in registers, fragment reads one chunk
 // ahead, no barrier in the loop): 32.9 us vs 31.4 us at N = 29,960, 202 vs 210 us at N = 240k.  Per-wave timestamps
@@ -993,13 +869,6 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
       // staged tiles while those fit the chip in one round (<= 256 tiles of 128 nodes: 31.3 vs 28.5 us at N = 32,768), faster from the
       // first tile beyond (N = 36,000: 33.2 vs 46.7 us -- the staged tiles' second round), 8-19 % faster from 45k rows on, 0.63-0.64 of
       // the fp32-MFMA peak against 0.57-0.58 at 250k - 1M rows (profiles/r05_proj_ws_bench.txt, r05_proj_ws_crossover.txt).
-      if (K().gemm_ws == 2 && K().gemm_variant == 2 && d == 128 && g.K == 256 && g.J == 128 && !g.rows && g.in1 && (!g.rows_out || g.rows_out_pos)) {
-        const int wgs8 = std::min(ceil_div(g.n, 16), std::max(1, K().gemm_ws_wgs / 2));
-        const size_t lds8w = (size_t)(3 * 16 * 256 + 2 * 512) * sizeof(float);
-        hipLaunchKernelGGL((proj_ws8_kernel<EPI>), dim3(wgs8), dim3(512), lds8w, st, g, K().gemm_ws_mode);
-        GSS_LAUNCH_CHECK("proj_ws8_kernel");
-        return GSS_OK;
-      }
       const bool ws = K().gemm_ws == 1 || (K().gemm_ws < 0 && g.n >= kWsMinRows);
       if (ws && K().gemm_variant == 2 && d == 128 && g.K == 256 && g.J == 128 && !g.rows && g.in1 && (!g.rows_out || g.rows_out_pos)) {
         const int ntiles = ceil_div(g.n, 16);

@@ -38,9 +38,6 @@ for n in [int(v) for v in (sys.argv[1:] or ["29960", "250000", "1000000"])]:
             ("weight-stationary 512 wgs, stagger 6", dict(gemm_ws=1, gemm_ws_wgs=512, gemm_ws_stagger=6)),
             ("weight-stationary 512 wgs, stagger 8", dict(gemm_ws=1, gemm_ws_wgs=512, gemm_ws_stagger=8)),
             ("weight-stationary 256 wgs", dict(gemm_ws=1, gemm_ws_wgs=256, gemm_ws_stagger=0)),
-            ("8 waves x 16 features, 256 wgs", dict(gemm_ws=2, gemm_ws_wgs=512)),
-            ("8 waves x 16 features, 128 wgs", dict(gemm_ws=2, gemm_ws_wgs=256)),
-            ("8 waves x 16 features, 256 wgs, no warm-up", dict(gemm_ws=2, gemm_ws_wgs=512, gemm_ws_mode=0)),
             ("weight-stationary 768 wgs, stagger 4", dict(gemm_ws=1, gemm_ws_wgs=768, gemm_ws_stagger=4))]
     res, ref = {}, None
     for rnd in range(4):
