@@ -213,50 +213,110 @@ __global__ __launch_bounds__(256) void bits_set_list_kernel(uint32_t *__restrict
 }
 
 // The set bits of P word ranges, in ascending order, as a list: bit j of range q is slot slot_off[q] + j; the list holds map[slot]
-// (map != NULL) or slot + add.  out_off[q + 1] = entries up to and including range q.  One workgroup (the bitmaps are a few thousand
-// words; both sides of an exchange run it over the same bits, so their counts and orders agree by construction).
-__global__ __launch_bounds__(1024) void bits_compact_kernel(const uint32_t *__restrict__ words, int P, const int64_t *__restrict__ woff,
-                                                            const int64_t *__restrict__ slot_off, const int32_t *__restrict__ map, int32_t add,
-                                                            int32_t *__restrict__ out, int64_t *__restrict__ out_off) {
+// (map != NULL) or slot + add.  out_off[q + 1] = entries up to and including range q.  Both sides of an exchange run it over the same
+// bits, so their counts and orders agree by construction.  Three launches (round 5; one workgroup walking the whole bitmap took 1-2 ms at
+// RMAT 10M, where a rank's halo is 10^5 words -- as long as everything the request phase is meant to hide under): the ranges are cut into
+// blocks of 1024 words (never across a range), (1) every block counts its bits, (2) one workgroup turns the counts into block bases and
+// the ranges' offsets, (3) every block lists its bits behind its base.
+constexpr int kCompactWords = 1024;
+// block `blk` of the concatenated block sequence -> its range q and first word (P is small: a linear walk)
+__device__ __forceinline__ void compact_block(int blk, int P, const int64_t *__restrict__ woff, int &q_out, int64_t &w_first, int64_t &w_end) {
+  int q = 0, first_blk = 0;
+  for (; q < P; ++q) {
+    const int nb = (int)((woff[q + 1] - woff[q] + kCompactWords - 1) / kCompactWords);
+    if (blk < first_blk + nb) break;
+    first_blk += nb;
+  }
+  q_out = q;
+  w_first = woff[q] + (int64_t)(blk - first_blk) * kCompactWords;
+  w_end = woff[q + 1];
+}
+
+__global__ __launch_bounds__(1024) void bits_count_kernel(const uint32_t *__restrict__ words, int P, const int64_t *__restrict__ woff,
+                                                          int32_t *__restrict__ block_tot) {
   __shared__ int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int q;
+  int64_t w0, w1;
+  compact_block((int)blockIdx.x, P, woff, q, w0, w1);
+  const int64_t w = w0 + tid;
+  int c = w < w1 ? __popc(words[w]) : 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if (lane == 0) wave_tot[wv] = c;
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+    for (int k = 0; k < 16; ++k) t += wave_tot[k];
+    block_tot[blockIdx.x] = t;
+  }
+}
+
+// one workgroup: exclusive scan of the block counts (in place: block_tot[blk] becomes the block's base), the ranges' offsets
+__global__ __launch_bounds__(1024) void bits_scan_kernel(int P, const int64_t *__restrict__ woff, int nblk, int32_t *__restrict__ block_tot,
+                                                         int64_t *__restrict__ base_out, int64_t *__restrict__ out_off) {
+  __shared__ long long wave_tot[16];
   __shared__ long long run;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) {
-    run = 0;
-    out_off[0] = 0;
-  }
+  if (tid == 0) run = 0;
   __syncthreads();
-  for (int q = 0; q < P; ++q) {
-    const int64_t w0 = woff[q], w1 = woff[q + 1], s0 = slot_off[q];
-    for (int64_t wb = w0; wb < w1; wb += 1024) {
-      const int64_t w = wb + tid;
-      uint32_t bits = w < w1 ? words[w] : 0u;
-      const int c = __popc(bits);
-      int incl = c;
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-      }
-      if (lane == 63) wave_tot[wv] = incl;
-      __syncthreads();
-      long long pos = run + incl - c;
-      for (int k = 0; k < wv; ++k) pos += wave_tot[k];
-      const int64_t slot_base = s0 + (w - w0) * 32;
-      while (bits) {
-        const int bpos = __ffs(bits) - 1;
-        bits &= bits - 1;
-        const int64_t slot = slot_base + bpos;
-        out[pos++] = map ? map[slot] : (int32_t)(slot + add);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        int t = 0;
-        for (int k = 0; k < 16; ++k) t += wave_tot[k];
-        run += t;
-      }
-      __syncthreads();
+  for (int b0 = 0; b0 < nblk; b0 += 1024) {
+    const int blk = b0 + tid;
+    const long long c = blk < nblk ? block_tot[blk] : 0;
+    long long incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
     }
-    if (tid == 0) out_off[q + 1] = run;
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    long long pos = run + incl - c;
+    for (int k = 0; k < wv; ++k) pos += wave_tot[k];
+    if (blk < nblk) base_out[blk] = pos;
+    __syncthreads();
+    if (tid == 0) {
+      long long t = 0;
+      for (int k = 0; k < 16; ++k) t += wave_tot[k];
+      run += t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    base_out[nblk] = run;
+    out_off[0] = 0;
+    int first_blk = 0;
+    for (int q = 0; q < P; ++q) {   // a range ends where its last block does
+      first_blk += (int)((woff[q + 1] - woff[q] + kCompactWords - 1) / kCompactWords);
+      out_off[q + 1] = base_out[first_blk];
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void bits_write_kernel(const uint32_t *__restrict__ words, int P, const int64_t *__restrict__ woff,
+                                                          const int64_t *__restrict__ slot_off, const int32_t *__restrict__ map, int32_t add,
+                                                          const int64_t *__restrict__ base, int32_t *__restrict__ out) {
+  __shared__ int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int q;
+  int64_t w0, w1;
+  compact_block((int)blockIdx.x, P, woff, q, w0, w1);
+  const int64_t w = w0 + tid;
+  uint32_t bits = w < w1 ? words[w] : 0u;
+  const int c = __popc(bits);
+  int incl = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  long long pos = base[blockIdx.x] + incl - c;
+  for (int k = 0; k < wv; ++k) pos += wave_tot[k];
+  const int64_t slot_base = slot_off[q] + (w - woff[q]) * 32;
+  while (bits) {
+    const int bpos = __ffs(bits) - 1;
+    bits &= bits - 1;
+    const int64_t slot = slot_base + bpos;
+    out[pos++] = map ? map[slot] : (int32_t)(slot + add);
   }
 }
 
@@ -487,11 +547,30 @@ int bits_set_list(uint32_t *bits, const int32_t *list, int64_t n, void *stream) 
   return GSS_OK;
 }
 
-int bits_compact(const uint32_t *words, int P, const int64_t *d_woff, const int64_t *d_slot_off, const int32_t *map, int32_t add, int32_t *out,
-                 int64_t *d_out_off, void *stream) {
-  GSS_REQUIRE(words && d_woff && d_slot_off && out && d_out_off && P >= 1, "bits_compact: bad argument");
-  hipLaunchKernelGGL(bits_compact_kernel, dim3(1), dim3(1024), 0, as_stream(stream), words, P, d_woff, d_slot_off, map, add, out, d_out_off);
-  GSS_LAUNCH_CHECK("bits_compact_kernel");
+int bits_compact(const uint32_t *words, int P, const int64_t *d_woff, const int64_t *h_woff, const int64_t *d_slot_off, const int32_t *map, int32_t add,
+                 int32_t *out, int64_t *d_out_off, void *stream) {
+  GSS_REQUIRE(words && d_woff && h_woff && d_slot_off && out && d_out_off && P >= 1, "bits_compact: bad argument");
+  hipStream_t st = as_stream(stream);
+  int64_t nblk = 0;
+  for (int q = 0; q < P; ++q) nblk += (h_woff[q + 1] - h_woff[q] + kCompactWords - 1) / kCompactWords;
+  GSS_REQUIRE(nblk < (int64_t)INT32_MAX, "bits_compact: %lld blocks", (long long)nblk);
+  // counts (int32) and bases (int64, one more than blocks) of the blocks: stream-ordered scratch
+  char *tmp = nullptr;
+  const size_t tot_bytes = ((size_t)nblk * sizeof(int32_t) + 15) / 16 * 16;
+  GSS_HIP(hipMallocAsync((void **)&tmp, tot_bytes + sizeof(int64_t) * ((size_t)nblk + 1), st));
+  int32_t *block_tot = reinterpret_cast<int32_t *>(tmp);
+  int64_t *base = reinterpret_cast<int64_t *>(tmp + tot_bytes);
+  if (nblk > 0) {
+    hipLaunchKernelGGL(bits_count_kernel, dim3((unsigned)nblk), dim3(1024), 0, st, words, P, d_woff, block_tot);
+    GSS_LAUNCH_CHECK("bits_count_kernel");
+  }
+  hipLaunchKernelGGL(bits_scan_kernel, dim3(1), dim3(1024), 0, st, P, d_woff, (int)nblk, block_tot, base, d_out_off);
+  GSS_LAUNCH_CHECK("bits_scan_kernel");
+  if (nblk > 0) {
+    hipLaunchKernelGGL(bits_write_kernel, dim3((unsigned)nblk), dim3(1024), 0, st, words, P, d_woff, d_slot_off, map, add, base, out);
+    GSS_LAUNCH_CHECK("bits_write_kernel");
+  }
+  GSS_HIP(hipFreeAsync(tmp, st));
   return GSS_OK;
 }
 

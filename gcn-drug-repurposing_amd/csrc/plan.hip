@@ -615,8 +615,8 @@ int plan_halo_requests_enqueue(gss_plan *p, gss_plan::LazyHalo &z, const gss_pla
                                         z.w_recv_off.data(), 1, st))
       return rc;
   }
-  if (int rc = bits_compact(z.reqw, P, d_wsend_off, d_send_off, h.d_send_rows, 0, z.send_list, z.d_cnt, stream)) return rc;
-  if (int rc = bits_compact(z.needw, P, d_wrecv_off, d_recv_off, nullptr, n, z.recv_list, z.d_cnt + P1, stream)) return rc;
+  if (int rc = bits_compact(z.reqw, P, d_wsend_off, z.w_send_off.data(), d_send_off, h.d_send_rows, 0, z.send_list, z.d_cnt, stream)) return rc;
+  if (int rc = bits_compact(z.needw, P, d_wrecv_off, z.w_recv_off.data(), d_recv_off, nullptr, n, z.recv_list, z.d_cnt + P1, stream)) return rc;
   GSS_HIP(hipMemcpyAsync(z.h_cnt, z.d_cnt, sizeof(int64_t) * 2 * P1, hipMemcpyDeviceToHost, st));
   return GSS_OK;
 }

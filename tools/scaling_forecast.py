@@ -40,6 +40,7 @@ ap.add_argument("--layers", type=int, default=2)
 ap.add_argument("--batch", type=int, default=2048)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--rccl-default", type=int, default=1)
+ap.add_argument("--cache-layer1", type=int, default=0, help="1: the plans keep layer 1's two SpMM results (their inputs are constants) -- what train.py runs; its lazy step is then the trainer's step")
 ap.add_argument("--row-weight", type=int, default=None, help="the partition's cost of a row besides its entries (default: shards.row_weight_for(d, layers), what train.py and bench.py pass)")
 args = ap.parse_args()
 lib = pkg.load()
@@ -82,7 +83,8 @@ def run_world(world):
                 shard = build_shard(make_source(), comms[rank], need_transpose=L > 1, device="cuda:0", **kw)
                 lo, hi = shard.part.rows(rank)
                 x_loc = feats(lo, hi) if feats else shard_rows(shard, X)
-                eng = shard_engine(shard, x_loc, params, comms[rank], num_layers=L, layer_decay=0.3, alpha=1.0, lr=3e-4, max_batch=B)
+                eng = shard_engine(shard, x_loc, params, comms[rank], num_layers=L, layer_decay=0.3, alpha=1.0, lr=3e-4, max_batch=B,
+                                   cache_layer1=bool(args.cache_layer1))
                 idx = [torch.from_numpy(b).cuda() for b in batches]
                 sync = torch.cuda.current_stream().synchronize
                 for k in range(2):
@@ -176,7 +178,7 @@ def floor_us(bytes_in, rows_total, max_pair_rows):
 
 
 from gcn_drug_repurposing_amd.shards import row_weight_for as _rwf  # noqa: E402
-res = {"workload": args.workload, "n": n, "d": d, "layers": L, "batch": B, "reps": args.reps, "row_weight": _rwf(d, L) if args.row_weight is None else args.row_weight, "rccl_default_knobs": bool(args.rccl_default),
+res = {"workload": args.workload, "n": n, "d": d, "layers": L, "batch": B, "reps": args.reps, "cache_layer1": bool(args.cache_layer1), "row_weight": _rwf(d, L) if args.row_weight is None else args.row_weight, "rccl_default_knobs": bool(args.rccl_default),
        "assumed_latency_us_per_collective": LATENCY_US, "xgmi_link_GBs": XGMI_LINK_GBS,
        "what_this_is": "a FORECAST from per-rank kernel times measured with each rank alone on ONE MI355X (recorded exchange payloads replayed by device "
                        "copies) + collectives priced at the xGMI floor of their most loaded pair + an ASSUMED latency per collective; no two-device run exists",
