@@ -44,7 +44,7 @@ int gss_abi_version(void);
  * NULL (the default) switches it off; no production path sets it. */
 int gss_debug_set_stamp_buffer(void *device_buffer);
 /* measurement aid (tools/ab_live.py): changes one KERNEL-SELECTION knob ("gemm_lines", "spmm_pair", "wgrad_deep", "gemm_hoist",
- * "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "spmm_slices", "spmm_pin", "spmm_fly", "gemm_rows_split",
+ * "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "gemm_nt_cap", "spmm_slices", "spmm_pin", "spmm_fly", "gemm_rows_split",
  * "gemm_ws", "gemm_ws_wgs", "gemm_ws_stagger", "gemm_ws_mode") in a live plan's snapshot, so that one plan -- the same buffers at the same addresses --
  * can be timed under alternating settings; knobs that size a workspace or steer the plan's bookkeeping are refused (GSS_EINVAL).
  * Not thread-safe against gss_debug_set_option on another thread. */
