@@ -99,6 +99,7 @@ struct RcclComm final : gss_comm {
   }
   int dead() const { return fail(GSS_ECOMM, "RCCL communicator of rank %d was aborted after an earlier failure", rank); }
   int check(ncclComm_t h) {
+    if (aborted.load()) return dead();   // another thread aborted while this call was inside RCCL: the handle is gone, do not touch it
     ncclResult_t st = ncclSuccess;
     const ncclResult_t r = ncclCommGetAsyncError(h, &st);
     if (r == ncclSuccess && (st == ncclSuccess || st == ncclInProgress)) return GSS_OK;
