@@ -80,4 +80,34 @@ inline int build_segments(const int32_t *rowptr, int32_t n_rows, int waves, int 
   return build_segments_items(items.data(), items.size(), waves, gpw_log2, seg_edges, segs);
 }
 
+// Giant rows (spmm.hip GiantRows): rows with more than `thr` stored entries are cut into chunks of thr / 4.  Three item lists over the rows of
+// one CSR: `shortv` = every other row as it is; `chunks` = one item per chunk (its "row" is the chunk's index, its entries a range of the
+// ORIGINAL arrays); `finish` = one item per giant row over a [rows] x [chunks] matrix of ones (first = its first chunk, len = its chunks);
+// chunk_row[k] = the row chunk k belongs to.  Returns the number of giant rows.
+struct GiantItems {
+  std::vector<SegItem> shortv, chunks, finish;
+  std::vector<int32_t> chunk_row;
+};
+inline int32_t giant_items(const int32_t *rowptr, int32_t n_rows, int32_t thr, GiantItems &out) {
+  out = GiantItems{};
+  if (thr <= 0) return 0;
+  const int32_t chunk = thr / 4 > 0 ? thr / 4 : 1;
+  int32_t n_giant = 0;
+  for (int32_t r = 0; r < n_rows; ++r) {
+    const int32_t len = rowptr[r + 1] - rowptr[r];
+    if (len <= thr) {
+      out.shortv.push_back({r, rowptr[r], len});
+      continue;
+    }
+    ++n_giant;
+    const int32_t c0 = (int32_t)out.chunk_row.size();
+    for (int32_t b0 = 0; b0 < len; b0 += chunk) {
+      out.chunks.push_back({(int32_t)out.chunk_row.size(), rowptr[r] + b0, std::min(chunk, len - b0)});
+      out.chunk_row.push_back(r);
+    }
+    out.finish.push_back({r, c0, (int32_t)out.chunk_row.size() - c0});
+  }
+  return n_giant;
+}
+
 }  // namespace gss

@@ -786,35 +786,30 @@ static int csr_giant_rows(const gss_csr *a, gss_giant_rows **out) {
   m->giant = nullptr;
   m->giant_threshold = thr;
   if (thr <= 0 || m->h_rowptr.empty()) return GSS_OK;
-  const int32_t chunk = thr / 4;
   const int32_t *rp = m->h_rowptr.data();
   int64_t n_giant = 0;
   for (int32_t r = 0; r < a->n_rows; ++r) n_giant += (rp[r + 1] - rp[r]) > thr;
   if (n_giant == 0) return GSS_OK;
+  GiantItems items;
+  (void)giant_items(rp, a->n_rows, thr, items);     // segments.h: host-only, checked under ASan / UBSan by tests/native/segments_check.cpp
   gss_giant_rows *g = new gss_giant_rows();
-  std::vector<int32_t> chunk_row;
   giant_view_init(g->chunks, a, 0, a->n_cols);
   giant_view_init(g->shortv, a, a->n_rows, a->n_cols);
   giant_view_init(g->finish, a, a->n_rows, 0);
-  for (int32_t r = 0; r < a->n_rows; ++r) {
-    const int32_t len = rp[r + 1] - rp[r];
-    if (len <= thr) {
-      g->shortv.item_row.push_back(r);
-      g->shortv.item_first.push_back(rp[r]);
-      g->shortv.item_len.push_back(len);
-      continue;
+  auto fill = [](gss_csr &v, const std::vector<SegItem> &src) {
+    v.item_row.reserve(src.size());
+    v.item_first.reserve(src.size());
+    v.item_len.reserve(src.size());
+    for (const SegItem &it : src) {
+      v.item_row.push_back(it.row);
+      v.item_first.push_back(it.first);
+      v.item_len.push_back(it.len);
     }
-    const int32_t c0 = (int32_t)chunk_row.size();
-    for (int32_t b0 = 0; b0 < len; b0 += chunk) {
-      g->chunks.item_row.push_back((int32_t)chunk_row.size());
-      g->chunks.item_first.push_back(rp[r] + b0);
-      g->chunks.item_len.push_back(std::min(chunk, len - b0));
-      chunk_row.push_back(r);
-    }
-    g->finish.item_row.push_back(r);
-    g->finish.item_first.push_back(c0);
-    g->finish.item_len.push_back((int32_t)chunk_row.size() - c0);
-  }
+  };
+  fill(g->shortv, items.shortv);
+  fill(g->chunks, items.chunks);
+  fill(g->finish, items.finish);
+  const std::vector<int32_t> &chunk_row = items.chunk_row;
   g->n_giant = (int32_t)n_giant;
   g->n_chunks = (int32_t)chunk_row.size();
   g->chunks.n_rows = g->n_chunks;
