@@ -41,9 +41,10 @@ PMC_FILE_RMAT10M = "r04_spmm_pmc_rmat10m.json"
 MFMA_F32_PEAK_TFLOPS = 157.3
 GUIDE_HBM_STREAM_TBS = 6.3   # MI355X_MICROARCH.md: "8 TB/s peak (spec); ~6.3 TB/s achievable"
 GUIDE_MALL_STREAM_TBS = 8.6  # MI355X_MICROARCH.md: 38 MB table, uniformly random 512-B rows served by the Infinity Cache
-# the bare gather stream of a workload's own col[] array (col[] streamed, one 512-B / 1-KB row gathered per entry, nothing else): the rate at which
+# the bare gather stream of a workload's own col[] array (col[] streamed, one 512-B / 1-KB row gathered per entry as 256-B slices pinned to XCDs, nothing else): the rate at which
 # the cache hierarchy serves this graph's gathers, measured with tools/micro/gather_hub_lds.py (H = 0 rows) on the GPU box
-GATHER_CEILING = {("whole_graph", 128): {"TBs": 19.37, "source": "profiles/r03_gather_hub_lds_whole_graph.txt: 506 MB of gathers in 26.1 us"}}
+GATHER_CEILING = {("whole_graph", 128): {"TBs": 19.42, "source": "profiles/r05_gather_ceiling.txt: 506 MB of gathers in 26.1 us (r03: 19.37)"},
+                  ("whole_graph_pathway", 256): {"TBs": 19.02, "source": "profiles/r05_gather_ceiling.txt: 1,012 MB of gathers in 53.2 us"}}
 XGMI_LINK_GBS = 153.0        # one xGMI link, one direction (7 links per GPU, one per peer in an 8-GPU node)
 COLLECTIVE_TIMEOUT_S = 300.0 # a stream that does not drain for this long = a peer stopped taking part: abort and exit non-zero
 

@@ -6,7 +6,7 @@ LDS (H = 320: 80 KB, two workgroups per CU; H = 640: 160 KB, one) and then walks
 from LDS when col < H, from global memory otherwise; 4 row fetches in flight per lane group, as in spmm_balanced_kernel.  Gathers
 only (no values, no reduction, no stores): what the memory system gives for this access stream, with and without the tile.
 Prints the share of gathers served by LDS, the time per pass and the gathered bytes per second.  Tools only, not shipped.
-usage: gather_hub_lds.py [whole_graph | rmat:<n>:<m>]"""
+usage: gather_hub_lds.py [whole_graph | whole_graph_pathway | rmat:<n>:<m>] [d (default 128; other widths: the bare stream only, H = 0)]"""
 import ctypes as C, os, subprocess, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -75,8 +75,8 @@ lib = C.CDLL(os.path.join(tmp, "g.so"))
 lib.run.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
 lib.run.restype = C.c_int
 what = sys.argv[1] if len(sys.argv) > 1 else "whole_graph"
-if what == "whole_graph":
-    adj, _, _ = synth.whole_graph_standin(1)
+if what in ("whole_graph", "whole_graph_pathway"):
+    adj, _, _ = synth.whole_graph_standin(1, pathway_edges=what.endswith("pathway"))
     a = (adj + sp.eye(adj.shape[0], format="csr")).tocsr()
     a.sort_indices()
     n, nnz = a.shape[0], a.nnz
@@ -94,7 +94,7 @@ else:
     u = torch.rand(m, generator=g, device="cuda", dtype=torch.float64)
     cd = (n ** u - 1).clamp_(0, n - 1).to(torch.int32)      # log-uniform ids: P(col < k) = log(k+1) / log(n)
     nnz = m
-d = 128
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 x = torch.randn(n, d, device="cuda"); out = torch.zeros(1024, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 def timeit(fn):
@@ -104,8 +104,8 @@ def timeit(fn):
     for _ in range(20): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 20 * 1e3
-print(f"{what}: N={n} nnz={nnz} d={d}; gathers per pass {nnz} x 512 B = {nnz * 512 / 1e6:.0f} MB", flush=True)
-for H, blocks_list in ((0, (512, 1024, 2048)), (160, (512, 1024)), (320, (512,)), (640, (256,))):
+print(f"{what}: N={n} nnz={nnz} d={d}; gathers per pass {nnz} x {d * 4} B = {nnz * d * 4 / 1e6:.0f} MB", flush=True)
+for H, blocks_list in (((0, (512, 1024, 2048)), (160, (512, 1024)), (320, (512,)), (640, (256,))) if d == 128 else ((0, (512, 1024, 2048)),)):
     share = float((cd < H).float().mean()) if H else 0.0
     for blocks in blocks_list:
         for fly in ((4, 8) if H == 0 else (4, 14, 18)):
