@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void gemm_nt_lds_kernel(GemmArgs 
     for (int u = 0; u < NT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // the epilogue's own operands, requested before the first chunk (one 16-node tile per wave; with two the registers are better spent)
-  constexpr bool HOIST = EPI != EPI_SPLIT && MT == 1 && WAVES <= 4;
+  constexpr bool HOIST = EPI != EPI_SPLIT && MT == 1 && WAVES <= 4 && NT <= 8;   // (a 256-feature tile row: 32 more float4 would not fit)
   FwdPre<NT> pre;
   if (HOIST && g.hoist) fwd_prefetch<NT, EPI, LINES>(g, node_base + 16 * (MT * w) + r, j0, q, pre);
 
@@ -827,6 +827,7 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
   g.stamps = g_gemm_stamps;
   {
     int nt = (d % 128 == 0) ? 8 : (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
+    if (EPI == EPI_FWD_NORM && d == 256) nt = 16;   // the fused row norm needs a row's features in one tile
     if (K().gemm_nt_cap > 0 && EPI != EPI_FWD_NORM)   // debug knob "gemm_nt_cap": narrower feature tiles (the fused normalise needs whole rows)
       while (nt > K().gemm_nt_cap) nt >>= 1;
     // few node rows (the top layer's batch-row input gradient: 2048 rows): narrower feature tiles so that the grid covers the chip
@@ -907,6 +908,19 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
       GSS_LAUNCH_CHECK("gemm_nt_lds_kernel (8 waves)");
       return GSS_OK;
     }
+    if constexpr (EPI == EPI_FWD_NORM) {
+      if (nt == 16 && !g.rows) {
+        // d = 256, last layer (round 5): 128-node tiles of ALL 256 features, so that F.normalize (and E_B) come out of the epilogue and the
+        // stand-alone row normalisation -- a 12 us launch that re-reads and re-writes the [N][256] result -- and the E_B gather go away.
+        // Config 3: 21 -> 19 launches, 1.2396 -> 1.2312 ms per step (64-node tiles: 1.2394); the tile itself is 11 us slower than the
+        // two-column-tile form it replaces (256 registers, one wave per SIMD), which is why this is all it buys.
+        dim3 gridn(ceil_div(g.n, 128), 1);
+        const size_t ldsn = 4 * (size_t)(128 * 16 + 256 * 16) * sizeof(float);
+        hipLaunchKernelGGL((gemm_nt_lds_kernel<16, 2, EPI_FWD_NORM, 4, false, true>), gridn, dim3(256), lds_request(gemm_nt_lds_kernel<16, 2, EPI_FWD_NORM, 4, false, true>, ldsn), st, g);
+        GSS_LAUNCH_CHECK("gemm_nt_lds_kernel (256 features, fused row norm)");
+        return GSS_OK;
+      }
+    }
     // passes without a row list write whole 128-B lines (fwd_epilogue_lines; a row list keeps the MFMA layout: its rows are
     // scattered, and the lazy step's contract -- the bits of the full pass -- holds because both forms add a row's squares in one order)
     if (!g.rows && K().gemm_lines && nt >= 2) {
@@ -978,14 +992,14 @@ int dense_fwd(int32_t n, int32_t d, const float *ax, const float *am, const floa
 }
 
 // last layer: P as usual, but the residual mix is row-normalised on the fly: e = normalize(p_prev + decay elu(p))
-bool dense_fwd_norm_available(int32_t d) { return d == 128 || d == 64 || d == 32 || d == 16; }
+bool dense_fwd_norm_available(int32_t d) { return d == 256 || d == 128 || d == 64 || d == 32 || d == 16; }
 
 int dense_fwd_norm(int32_t n, int32_t d, const float *ax, const float *am, const float *w1, const float *b1, const float *w2,
                    const float *b2, const float *p_prev, float decay, float *p, float *e, float *inv_den, void *stream, const int32_t *row_list,
                    float *rows_out, const int32_t *rows_out_pos) {
   if (int rc = check_d(d)) return rc;
   GSS_REQUIRE(n >= 0 && ax && am && w1 && b1 && w2 && b2 && p && e && inv_den, "dense_fwd_norm: null operand");
-  GSS_REQUIRE(dense_fwd_norm_available(d), "dense_fwd_norm: needs d in {16, 32, 64, 128}");
+  GSS_REQUIRE(dense_fwd_norm_available(d), "dense_fwd_norm: needs d in {16, 32, 64, 128, 256}");
   GemmArgs g{};
   g.n = n;
   g.K = 2 * d;
