@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PMC_FILE = "r05_spmm_pmc.json"
 PMC_FALLBACK = "r04_spmm_pmc.json"
-PMC_FILE_RMAT10M = "r04_spmm_pmc_rmat10m.json"
+PMC_FILE_RMAT10M = "r05_spmm_pmc_rmat10m.json"
 MFMA_F32_PEAK_TFLOPS = 157.3
 GUIDE_HBM_STREAM_TBS = 6.3   # MI355X_MICROARCH.md: "8 TB/s peak (spec); ~6.3 TB/s achievable"
 GUIDE_MALL_STREAM_TBS = 8.6  # MI355X_MICROARCH.md: 38 MB table, uniformly random 512-B rows served by the Infinity Cache

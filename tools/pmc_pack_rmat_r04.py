@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PMC = os.path.join(ROOT, "gpurun_out", "pmc")
 n, m, h, ns = (int(v) for v in sys.argv[1:5])
 REPS = 3
+ROUND = os.environ.get("PMC_ROUND", "r04")     # tools/pmc_rmat_r05.sh sets r05
 nnz, d = m + n, 128
 alg = 8 * nnz + 4 * (n + 1) + 8 * n * d
 out = {"note": "rocprofv3 --pmc, one counter group per pass (tools/pmc_run.sh), tools/spmm_two_pass.py base / two: counters summed over the "
@@ -19,7 +20,7 @@ for tag, what in (("base", "single pass (the product's kernel: H = 65,536 hubs d
                   ("fwd1", "single pass with the Hadamard epilogue (AX = A_hat x, M = AX (.) x): the bench line's `roofline` kernel; algorithmic bytes + 4 N d"),
                   ("two", f"two passes over a column split at H = {h}: hot entries with {ns} XCD-pinned slices of {d * 4 // ns} B, cold entries streaming")):
     acc, dur = collections.defaultdict(float), 0.0
-    for dd in glob.glob(os.path.join(PMC, f"r04_rmat_{tag}_*")):
+    for dd in glob.glob(os.path.join(PMC, f"{ROUND}_rmat_{tag}_*")):
         for f in glob.glob(dd + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
                 if "spmm_balanced" in r["Kernel_Name"]:
@@ -45,7 +46,7 @@ if "base" in out["cases"]:
     out["hbm_traffic"]["plain"] = {"traffic_bytes_per_launch": out["cases"]["base"]["traffic_bytes_per_product"]}
 if "fwd1" in out["cases"]:
     out["hbm_traffic"]["fwd1"] = {"traffic_bytes_per_launch": out["cases"]["fwd1"]["traffic_bytes_per_product"]}
-json.dump(out, open(os.path.join(ROOT, "profiles", "r04_spmm_pmc_rmat10m.json" if n == 10000000 else f"r04_spmm_pmc_rmat_{n}.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{ROUND}_spmm_pmc_rmat10m.json" if n == 10000000 else f"{ROUND}_spmm_pmc_rmat_{n}.json"), "w"), indent=1)
 for tag, c in out["cases"].items():
     print(f"{tag:5s} traffic {c['traffic_bytes_per_product'] / 1e9:8.3f} GB = {c['traffic_over_alg']:.2f} x alg, L2 hit {c['l2_hit_rate']}, "
           f"{c['us_per_product_profiled']:.1f} us, alg {c['alg_TBps']:.3f} TB/s = {c['alg_frac_of_8TBps']:.3f} of 8")
