@@ -35,9 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PMC_FILE = "r05_spmm_pmc.json"
-PMC_FALLBACK = "r04_spmm_pmc.json"
-PMC_FILE_RMAT10M = "r05_spmm_pmc_rmat10m.json"
+PMC_FILE = "r06_spmm_pmc.json"             # tools/pmc_pack_r06.py: counters per SpMM mode at configs 2, 3 and 5 + the spmm.hip hash they were taken with
 MFMA_F32_PEAK_TFLOPS = 157.3
 GUIDE_HBM_STREAM_TBS = 6.3   # MI355X_MICROARCH.md: "8 TB/s peak (spec); ~6.3 TB/s achievable"
 GUIDE_MALL_STREAM_TBS = 8.6  # MI355X_MICROARCH.md: 38 MB table, uniformly random 512-B rows served by the Infinity Cache
@@ -214,7 +212,7 @@ def main():
     ap.add_argument("--spinup-time", type=float, default=0.3, help="seconds of untimed steps BEFORE the W warm-up steps, to bring the GPU to "
                     "its working clocks (a 5-step warm-up is 1.6 ms at this size); reported as spinup_steps")
     ap.add_argument("--set", action="append", default=[], metavar="KNOB=VALUE", help="gss_debug_set_option before anything runs (A/B runs of "
-                    "a kernel variant, e.g. --set xcd_remap=0); listed in the JSON line as `knobs`")
+                    "a kernel variant, e.g. --set gemm_variant=3); listed in the JSON line as `knobs`")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -554,32 +552,89 @@ def main():
     out["roofline_plain"] = roof("spmm_fwd", "spmm_balanced_kernel<PLAIN> (AM = A_hat . M, forward)", 0,
                                  "8 nnz + 4 (N+1) + 4 N d (M) + 4 N d (AM)")
     single = world == 1 and not sharded
+    # ---- the backward SpMMs (SURVEY 8(d)(i) "fwd and bwd reported separately") ----
+    # spmm_bwd2 = the top layer's second backward hop  dP = c (t + A_hat^T u) (.) ELU'(P) + residual on the batch rows  (SPMM_BWD2S): a full
+    #   product over A_hat^T whose epilogue streams three more N x d operands: 8 nnz + 4 (N+1) + 4 N d (u, gathered) + 4 N d (t) + 4 N d (P) +
+    #   4 N d (dP) + 4 B d (the compact residual).  (From 100k nodes on it skips neighbours whose row of u is zero: fewer bytes than this.)
+    # spmm_bwd1 = the top layer's first backward hop, batch-sparse (SPMM_BWD1S): the kernel streams the whole index (it must see every column
+    #   id) but gathers only for entries whose neighbour is a batch row.  Algorithmic bytes = what a product restricted to those entries needs:
+    #   8 hits + 4 (N+1) + 2 * 4 B d (the compact g_am / g_ax) + 4 streams of d floats over the R rows that have such an entry or are batch rows
+    #   (x_in and ax read, u and t written).  hits and R are counted on the device for the last timed batch.
+    # spmm_bwd1_dense / spmm_bwd2_dense (L >= 3): the N-row hops of the layers below: 8 nnz + 4 (N+1) + 6 N d / 5-6 N d streams.
+    bwd_hits = bwd_rows = None
+    if L > 1 and world == 1 and getattr(engine.graph, "at", None) is not None:
+        at_ = engine.graph.at
+        ids = idx_all[int(offs[args.warmup + args.steps - 1]):int(offs[args.warmup + args.steps])].long()
+        if getattr(engine, "node_map", None) is not None:
+            ids = engine.node_map.long()[ids]
+        mark = torch.zeros(n_loc, dtype=torch.bool, device="cuda")
+        mark[ids] = True
+        hit = mark[at_.col[:at_.nnz].long()]
+        bwd_hits = int(hit.sum().item())
+        cnt_ = (at_.rowptr[1:] - at_.rowptr[:-1]).long()
+        row_hit = torch.zeros(n_loc, dtype=torch.bool, device="cuda")
+        row_hit[torch.repeat_interleave(torch.arange(n_loc, device="cuda"), cnt_)[hit]] = True
+        bwd_rows = int((row_hit | mark).sum().item())
+        del mark, hit, row_hit, cnt_
+
+    def roof_bytes(cls, kernel, alg, what, extra=None):
+        us = class_us(cls) if prof.get(cls, (0, 0))[1] else None
+        if us is None or us <= 0:
+            return None
+        ach = alg / (us * 1e-6) / 1e9
+        r = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+             "traffic_source": None, "alg_bytes_per_launch": alg, "alg_bytes_model": what, "avg_launch_us": us,
+             "avg_launch_us_raw_event_bracket": prof[cls][0] / prof[cls][1] * 1e3, "launches": prof[cls][1]}
+        if extra:
+            r.update(extra)
+        return r
+
+    if L > 1 and world == 1:
+        nnz_t = int(engine.graph.at.nnz)
+        base_t = 8 * nnz_t + 4 * (n_loc + 1)
+        out["roofline_bwd2"] = roof_bytes("spmm_bwd2", "spmm_balanced_kernel<BWD2S> (dP = c (t + A_hat^T u) (.) ELU'(P) + batch-row residual; the top layer's second backward hop)",
+                                          base_t + 4 * n_loc * d * 4 + 4 * B * d, "8 nnz + 4 (N+1) + 4 N d (u) + 4 N d (t) + 4 N d (P) + 4 N d (dP) + 4 B d (residual)"
+                                          + ("; the kernel skips neighbours whose row of u is zero (graphs of >= 100k nodes): it moves fewer bytes than this" if n >= 100000 else ""))
+        if bwd_hits is not None:
+            alg1 = 8 * bwd_hits + 4 * (n_loc + 1) + 8 * B * d + 16 * bwd_rows * d
+            out["roofline_bwd1"] = roof_bytes("spmm_bwd1", "spmm_balanced_kernel<BWD1S> (u, t from A_hat^T restricted to batch-row neighbours; the top layer's first backward hop)",
+                                              alg1, "8 hits + 4 (N+1) + 2 * 4 B d (compact g_am, g_ax) + 4 * 4 R d (x_in, ax read; u, t written on the R live rows)",
+                                              {"hits": bwd_hits, "live_rows": bwd_rows,
+                                               "executed_bytes_model": 8 * nnz_t + 4 * (n_loc + 1) + 8 * B * d + 8 * n_loc * d + 8 * bwd_rows * d,
+                                               "executed_bytes_note": "what the kernel streams: the whole index (8 nnz), u and t written for every row (zeros "
+                                                                      "included, unless the plan tracks non-zero rows: graphs of >= 100k nodes), x_in / ax for the live rows"})
+        if L > 2:
+            out["roofline_bwd1_dense"] = roof_bytes("spmm_bwd1_dense", "spmm_balanced_kernel<BWD1> (u = g_ax + (A_hat^T g_am) (.) x, t = (A_hat^T g_am) (.) ax; N-row hop)",
+                                                    base_t + 4 * n_loc * d * 6, "8 nnz + 4 (N+1) + 4 N d x (g_am gathered, g_ax, x_in, ax read; u, t written)")
+            out["roofline_bwd2_dense"] = roof_bytes("spmm_bwd2_dense", "spmm_balanced_kernel<BWD2> (dP = c (t + A_hat^T u) (.) ELU'(P) [+ residual]; N-row hop)",
+                                                    base_t + 4 * n_loc * d * 4, "8 nnz + 4 (N+1) + 4 N d x (u gathered, t, P read; dP written) [+ 4 N d per residual read / gx written at L > 3]")
     if world == 1:
-        pmc = next((os.path.join(ROOT, "profiles", f) for f in (PMC_FILE, PMC_FALLBACK) if os.path.exists(os.path.join(ROOT, "profiles", f))), None)
-        pmc_rmat = os.path.join(ROOT, "profiles", PMC_FILE_RMAT10M)
-        if args.workload == "rmat:10000000:200000000" and d == 128 and os.path.exists(pmc_rmat):
-            # BASELINE config 5 on one GPU: the counters of the same two kernels at this size (tools/profile_r04.sh)
-            z = json.load(open(pmc_rmat))
-            for key, name in (("roofline", "fwd1"), ("roofline_plain", "plain")):
-                if out[key] and name in z.get("hbm_traffic", {}):
-                    out[key]["traffic"] = z["hbm_traffic"][name]["traffic_bytes_per_launch"]
-                    out[key]["traffic_source"] = f"offline rocprofv3 --pmc profile of the same kernels on this workload: profiles/{PMC_FILE_RMAT10M}"
-        if args.workload == "whole_graph" and d == 128 and pmc:
-            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel on this workload, corrected as MI355X_MICROARCH.md
-            # prescribes.  Counters cannot be read from inside bench.py: the figure comes from an OFFLINE profile of the
-            # same command (tools/pmc_run.sh), not from this run
-            z = json.load(open(pmc))
-            for key, name in (("roofline", "fwd1"), ("roofline_plain", "plain")):
-                if out[key] and name in z.get("hbm_traffic", {}):
-                    out[key]["traffic"] = z["hbm_traffic"][name]["traffic_bytes_per_launch"]
-                    out[key]["traffic_source"] = f"offline rocprofv3 --pmc profile of the same command: profiles/{os.path.basename(pmc)}"
-        if args.workload == "whole_graph_pathway" and d == 256 and pmc:
-            # BASELINE config 3: the counters of the d = 256 SpMMs on this graph (tools/profile_r05.sh)
-            z = json.load(open(pmc))
-            for key, name in (("roofline", "fwd1"), ("roofline_plain", "plain")):
-                if out[key] and name in z.get("hbm_traffic_config3", {}):
-                    out[key]["traffic"] = z["hbm_traffic_config3"][name]["traffic_bytes_per_launch"]
-                    out[key]["traffic_source"] = f"offline rocprofv3 --pmc profile of the same kernels on this workload: profiles/{os.path.basename(pmc)}"
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per SpMM mode on this workload, corrected as MI355X_MICROARCH.md prescribes.  Counters cannot be read
+        # from inside bench.py: the figures come from an OFFLINE profile (tools/profile_r06.sh -> tools/pmc_pack_r06.py), which records the sha256
+        # of the spmm.hip it measured.  A file taken with another spmm.hip than this library's is NOT used (traffic stays null and says why).
+        pmc_path = os.path.join(ROOT, "profiles", PMC_FILE)
+        wl_key = {"whole_graph": "config2", "whole_graph_pathway": "config3", "rmat:10000000:200000000": "config5"}.get(args.workload)
+        want_d = {"config2": 128, "config3": 256, "config5": 128}.get(wl_key)
+        lib_hash = lib_.gss_source_hash(b"spmm.hip")
+        lib_hash = lib_hash.decode() if lib_hash else None
+        if wl_key and d == want_d and os.path.exists(pmc_path):
+            z = json.load(open(pmc_path))
+            rec_hash = z.get("source_hash", {}).get("spmm.hip")
+            for key, name in (("roofline", "fwd1"), ("roofline_plain", "plain"), ("roofline_bwd1", "bwd1s"), ("roofline_bwd2", "bwd2s"),
+                              ("roofline_bwd1_dense", "bwd1"), ("roofline_bwd2_dense", "bwd2")):
+                r = out.get(key)
+                c = z.get(wl_key, {}).get(name)
+                if not r or not c:
+                    continue
+                if rec_hash != lib_hash:
+                    r["traffic_source"] = (f"profiles/{PMC_FILE} was taken with spmm.hip {str(rec_hash)[:12]}, this library is {str(lib_hash)[:12]}: "
+                                           "stale counters are not reported (re-run tools/profile_r06.sh)")
+                    continue
+                r["traffic"] = c["traffic_bytes_per_launch"]
+                r["traffic_over_alg"] = c["traffic_bytes_per_launch"] / r["alg_bytes_per_launch"]
+                r["l2_hit_rate"] = c.get("l2_hit_rate")
+                r["traffic_source"] = (f"offline rocprofv3 --pmc profile of the same kernel on this workload, spmm.hip {rec_hash[:12]} (= this library's): "
+                                       f"profiles/{PMC_FILE} [{wl_key}][{name}]")
         # Which bound binds.  `frac` above is the prescribed one: compulsory bytes against HBM.  A cache-resident
         # graph (config 2 / 3: the operand fits the Infinity Cache) is bound by the rate at which the L2s serve row gathers -- SURVEY
         # 8(d)'s bytes_gather = 8 nnz + 4 (N+1) + 4 nnz d + 4 N d per result, against the bare gather stream of the same col[] array
@@ -608,7 +663,7 @@ def main():
         # nnz / t_SpMM per launch, forward and backward kinds separately.  spmm_bwd1 at L = 2 is the sparsity-aware
         # top-layer hop (it visits only entries whose neighbour is a batch row), counted at nnz like the rest
         out["spmm_kernel_edges_per_s_by_kind"] = {k: nnz / (class_us(k) * 1e-6)
-                                                  for k in ("spmm_fwd_hadamard", "spmm_fwd", "spmm_bwd1", "spmm_bwd2")
+                                                  for k in ("spmm_fwd_hadamard", "spmm_fwd", "spmm_bwd1", "spmm_bwd2", "spmm_bwd1_dense", "spmm_bwd2_dense")
                                                   if prof.get(k, (0, 0))[1] and class_us(k)}
         # fp32-MFMA kernels: achieved TFLOP/s against the 157.3 TF dense fp32-matrix peak
         mf = {}

@@ -9,7 +9,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgssgcn.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -54,6 +54,7 @@ _P, _I32, _I64, _F, _D, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_d
 SIGNATURES = {
     "gss_abi_version": (C.c_int, []),
     "gss_last_error": (C.c_char_p, []),
+    "gss_source_hash": (C.c_char_p, [C.c_char_p]),
     "gss_normalize_adj": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P]),
     "gss_rowsum_dinv": (C.c_int, [_I32, _P, _P, _P, _P, _P]),
     "gss_rowsum_check": (C.c_int, [_I32, _P, _P, _P, _P]),
@@ -146,18 +147,70 @@ SIGNATURES = {
 
 
 PROF_CLASSES = ("spmm_fwd_hadamard", "spmm_fwd", "spmm_bwd1", "spmm_bwd2", "dense_fwd", "dgrad", "wgrad", "wgrad_batch",
-                "loss", "rownorm", "elementwise", "adam", "comm", "comm_batch", "comm_grads")
+                "loss", "rownorm", "elementwise", "adam", "comm", "comm_batch", "comm_grads", "spmm_bwd1_dense", "spmm_bwd2_dense")
+
+
+def source_hashes():
+    """sha256 of every source the Makefile hashes into the library (csrc/*.hip, csrc/*.h, include/gssgcn.h), by file name, + "*" = all of them
+    concatenated in the Makefile's order -- what gss_source_hash must return for a library built from this tree"""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "gssgcn.h"))
+    out, every = {}, hashlib.sha256()
+    for f in files:
+        data = open(f, "rb").read()
+        out[os.path.basename(f)] = hashlib.sha256(data).hexdigest()
+        every.update(data)
+    out["*"] = every.hexdigest()
+    return out
+
+
+def library_is_current():
+    """does the built library carry the hashes of the sources in this tree?  (dlopen only: no GPU needed)"""
+    if not os.path.exists(LIB_PATH):
+        return False
+    import torch  # noqa: F401  (torch's HIP runtime has to be in the process before this library is: see load())
+    try:
+        lib = C.CDLL(LIB_PATH)
+        fn = lib.gss_source_hash
+    except (OSError, AttributeError):
+        return False
+    fn.restype, fn.argtypes = C.c_char_p, [C.c_char_p]
+    for name, want in source_hashes().items():
+        got = fn(name.encode())
+        if got is None or got.decode() != want:
+            return False
+    return True
 
 
 def build(verbose: bool = False) -> str:
-    """Compile libgssgcn.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if verbose or res.returncode != 0:
-        print(res.stdout[-4000:])
-        print(res.stderr[-4000:])
-    if res.returncode != 0:
-        raise GssError("building libgssgcn.so failed (hipcc --offload-arch=gfx950); see output above")
+    """Compile libgssgcn.so for gfx950 with hipcc (cross-compiles without a GPU).  An incremental `make` trusts timestamps, and the built
+    library travels to the GPU box while being git-ignored: a stale .so with fresh timestamps would be reused silently.  So the library
+    carries the sha256 of its sources (gss_source_hash) and this function checks them against the tree after the incremental build; a
+    mismatch -- or GSS_REBUILD=1 -- forces `make -B`.  Says which it did."""
+    jobs = str(min(8, os.cpu_count() or 1))
+
+    def make(*extra):
+        res = subprocess.run(["make", "-C", CSRC, "-j", jobs, *extra], capture_output=True, text=True)
+        if verbose or res.returncode != 0:
+            print(res.stdout[-4000:])
+            print(res.stderr[-4000:])
+        if res.returncode != 0:
+            raise GssError("building libgssgcn.so failed (hipcc --offload-arch=gfx950); see output above")
+
+    if os.environ.get("GSS_REBUILD") == "1":
+        make("-B")
+        how = "full rebuild (GSS_REBUILD=1)"
+    else:
+        make()
+        how = "incremental make"
+        if not library_is_current():
+            make("-B")
+            how = "full rebuild (the incrementally built library's source hashes did not match the tree)"
+    if not library_is_current():
+        raise GssError("libgssgcn.so does not carry the hashes of the sources in this tree even after a full rebuild")
+    print(f"libgssgcn.so: {how}; source hashes match the tree")
     return LIB_PATH
 
 

@@ -64,7 +64,7 @@ struct RcclComm final : gss_comm {
   std::mutex mu;
   std::atomic<bool> aborted{false};
   std::atomic<bool> failed{false};   // check_async has reported an error: ncclCommDestroy could wait for the dead peer
-  std::atomic<int> in_rccl{0};       // enqueues currently inside an RCCL call (the destructor waits for them, abort() does not)
+  std::atomic<int> in_rccl{0};       // enqueues currently inside an RCCL call (the destructor waits for them; abort() for at most 100 ms)
   struct Use {                       // an enqueue's hold on the communicator: pointer snapshot + in-flight count
     RcclComm &c;
     ncclComm_t h = nullptr;
@@ -93,9 +93,20 @@ struct RcclComm final : gss_comm {
     comm = nullptr;
     return h;
   }
-  void abort() override {
+  void abort() override { abort_from(0); }
+  // ncclCommAbort FREES the communicator, and enqueues on other threads may hold a snapshot of it (Use).  Order: raise `aborted` and take
+  // the pointer out first -- from here on every new Use gets no handle --, then give the enqueues that are inside RCCL right now a
+  // bounded time to leave (one that is not stalled drains within microseconds: this closes the window between check()'s test of
+  // `aborted` and its ncclCommGetAsyncError), and only when that deadline passes abort underneath them -- that is the stalled peer,
+  // the case abort() exists for: ncclCommAbort raises the flag RCCL's host-side wait loops poll and the stalled call returns.
+  // `own` = enqueues the CALLER itself holds (check() aborts from inside its own Use).
+  void abort_from(int own) {
     if (aborted.exchange(true)) return;
-    if (ncclComm_t h = take()) (void)ncclCommAbort(h);   // frees the communicator; a call stalled inside RCCL sees the flag and returns
+    ncclComm_t h = take();
+    if (!h) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (in_rccl.load() > own && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(100)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    (void)ncclCommAbort(h);
   }
   int dead() const { return fail(GSS_ECOMM, "RCCL communicator of rank %d was aborted after an earlier failure", rank); }
   int check(ncclComm_t h) {
@@ -106,7 +117,7 @@ struct RcclComm final : gss_comm {
     if (aborted.load()) return dead();   // another thread aborted while this call was inside RCCL
     const ncclResult_t bad = r != ncclSuccess ? r : st;
     failed.store(true);
-    abort();
+    abort_from(1);   // (this call's own Use)
     return fail(GSS_ECOMM, "RCCL asynchronous error on rank %d of %d: %s (communicator aborted)", rank, world, ncclGetErrorString(bad));
   }
   // an RCCL call's own return code: after abort() from another thread it is that abort speaking
@@ -256,7 +267,11 @@ struct CommLog {
     r.bytes = bytes;
     if (bytes) {
       GSS_HIP(hipMalloc(&r.buf, bytes));
-      GSS_HIP(hipMemcpyAsync(r.buf, src, bytes, hipMemcpyDeviceToDevice, st));
+      const hipError_t e = hipMemcpyAsync(r.buf, src, bytes, hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) {
+        (void)hipFree(r.buf);
+        return fail(GSS_EHIP, "local comm record: hipMemcpyAsync -> %s", hipGetErrorString(e));
+      }
     }
     recs.push_back(r);
     return GSS_OK;

@@ -19,28 +19,15 @@ constexpr int kWave = 64;
 struct Knobs {
   int spmm_variant = 2;      // 1 = row per wave, 2 = nnz-balanced segments (default; shards and the lazy step need it)
   int spmm_slices = 0;       // 0 = automatic feature slicing (launch_balanced)
-  int spmm_pair = 1;         // balanced SpMM, lane groups of <= 16 lanes: (col, val) pairs two per lane and trip (whole-line index loads)
   int spmm_pin = 0;          // with a manual spmm_slices: slices pinned to XCDs (1) or time-separated (0)
   int spmm_hot = -1;         // overrides every CSR's hot set with rows [0, value) (-1 = the CSR's own, 0 = none)
-  int spmm_fly = 4;          // row gathers in flight per lane group on the large-table path (4 or 8)
   int seg_edges = 32;        // entries per SpMM segment (CSR handles created afterwards)
   int spmm_giant = 32768;    // balanced SpMM, dense modes: rows with more stored entries than this are cut into chunks of a quarter of it that
                              // other workgroups sum (spmm.hip GiantRows); 0 = never.  CSR handles look at it with their first launch
   int gemm_variant = 2;      // projection tile shape: 2 = by width and row count (default), 3 = 128-node tiles of four waves forced, 5 = of eight waves forced
-  int gemm_nt_cap = 0;       // cap of the feature tile width (16-feature units), 0 = none
-  int gemm_small_nt = 2;     // narrowest feature tile for small problems, 0 = never narrow
-  int gemm_rows_split = 1;   // forward projection over a short row list: 4 waves per 16 listed rows that split the features (0 = one wave per tile)
-  int wgrad_deep = 2;        // weight-gradient reduce: Adam's state / the batch ids requested first, slabs fetched sixteen at a time (1 = eight; 0 = four, state fetched late)
-  int gemm_lines = 1;        // forward projection's epilogue in whole 128-B lines (neighbouring lanes swap feature blocks first; 0 = the MFMA layout's half lines)
-  int gemm_hoist = 1;        // forward projection: biases / previous layer's P / batch-position map requested ahead of the K loop (0 = in the epilogue)
   int gemm_ws = -1;          // d = 128 forward projection without a row list: weight-stationary persistent kernel (proj_ws_kernel) -- -1 = from
                              // kWsMinRows = 32,769 rows on (dense.hip: more 128-node tiles than CUs -- the staged tiles would need a second round), 0 = never, 1 = always
-  int gemm_ws_wgs = 512;     // its persistent workgroups (two per CU)
-  int gemm_ws_mode = 1;      // bit 0: its L2 warm-up pass, bit 1: its weights fetched in whole 128-B lines (lanes trade halves afterwards)
-  int gemm_ws_stagger = 4;   // its second generation of workgroups (linear id >= 256) starts this many x 512 cycles late (0 = together)
-  int wgrad_variant = 1;     // 1 = operands by direct loads from L2, 2 = by LDS-DMA into a per-wave ring, one trip ahead (same bits)
   int wgrad_wgs = 256;       // workgroups of a full-size weight-gradient launch (sizes the plan's partial buffer)
-  int xcd_remap = 1;         // workgroups that share input rows on one XCD
   int loss_wgs = 256;        // workgroups the loss sweep's grid aims at
   int sparse_bits_rows = 100000;  // operand rows from which a plan keeps the bitmaps of the sparsity-aware backward hops
   int lazy_halo = -1;        // sharded lazy step: fetch only the boundary rows of the top layer's M that the batch rows read (-1 = graphs of >= 262,144 nodes, 0 = never, 1 = always)

@@ -47,8 +47,6 @@ struct GemmArgs {
                                  // rows_out[rows_out_pos[r]] where that is >= 0 (the batch-position map: E_B of a FULL step)
   float *rows_out;      // EPI_FWD_NORM over a row list (nullable): the unit-norm row of tile row t ALSO goes to rows_out[t] -- the lazy step's
                         // tile rows are the batch positions, so this IS E_B = emb[idx] (model.py:216-217) without a gather launch
-  int xcd_remap;        // renumber the workgroups so that those sharing input rows sit on one XCD (xcd_ids below)
-  int hoist;            // the epilogue's operands are requested ahead of the K loop (knob "gemm_hoist", default 1)
   unsigned long long *stamps;  // diagnostic (gss_debug_set_stamp_buffer, NULL in production): per wave {start, loop begin, loop end, end} in
                                // 100 MHz wall-clock ticks + {linear workgroup id, HW_ID}; tools/gemm_stamps.py reads it
 };
@@ -288,7 +286,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // rows (the column tiles of one node tile in the projections, the output tiles of one node slice in the weight gradient) are
 // therefore renumbered so that they land on one XCD, next to each other in dispatch order: `spread` indexes the groups (its
 // neighbours go to different XCDs), `share` the members of a group.  Linear id L -> (spread, share); the last (n_spread mod 8)
-// groups keep the plain order.  Knob "xcd_remap" (default 1).
+// groups keep the plain order.  (The plain numbering measured 1-3 % slower in three live sweeps; the knob went in round 6.)
 struct XcdIds {
   int spread, share;
 };
@@ -336,7 +334,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void gemm_nt_lds_kernel(GemmArgs 
     stamp[4] = (unsigned long long)linear;
     stamp[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | ((16 - 1) << 11));
   }
-  const XcdIds id = xcd_ids(linear, (int)gridDim.x, (int)gridDim.y, g.xcd_remap != 0);
+  const XcdIds id = xcd_ids(linear, (int)gridDim.x, (int)gridDim.y, true);
   const int node_base = id.spread * BM;
   const int j0 = id.share * BN;
   const int jh = j0 >= g.jsplit ? 1 : 0;
@@ -385,7 +383,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void gemm_nt_lds_kernel(GemmArgs 
   // the epilogue's own operands, requested before the first chunk (one 16-node tile per wave; with two the registers are better spent)
   constexpr bool HOIST = EPI != EPI_SPLIT && MT == 1 && WAVES <= 4 && NT <= 8;   // (a 256-feature tile row: 32 more float4 would not fit)
   FwdPre<NT> pre;
-  if (HOIST && g.hoist) fwd_prefetch<NT, EPI, LINES>(g, node_base + 16 * (MT * w) + r, j0, q, pre);
+  if (HOIST) fwd_prefetch<NT, EPI, LINES>(g, node_base + 16 * (MT * w) + r, j0, q, pre);
 
   for (int c = 0; c < PF && c < nchunk; ++c) stage(c);
   if (STAMP && stamp && lane == 0) stamp[1] = wall_clock64();
@@ -455,7 +453,6 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void gemm_nt_lds_kernel(GemmArgs 
           st4(g.out1 + (size_t)orow * g.ld_out1 + (j - g.jsplit), v);
       }
     } else if (HOIST) {
-      if (!g.hoist) fwd_prefetch<NT, EPI, LINES>(g, nd, j0, q, pre);      // (knob gemm_hoist = 0: fetched here, as until round 4)
       fwd_epilogue<NT, EPI, LINES>(g, acc[t], pre, j0, q);
     } else {
       fwd_epilogue<NT, EPI, LINES>(g, acc[t], nd, j0, q);
@@ -514,7 +511,7 @@ __global__ __launch_bounds__(256) void gemm_rows_split_kernel(GemmArgs g) {
   for (int u = 0; u < NTW; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // wave 0 runs the whole row's epilogue: its operands are requested now (see FwdPre)
   FwdPre<NT> pre;
-  if (w == 0 && g.hoist) fwd_prefetch<NT, EPI>(g, node_base + r, 0, q, pre);
+  if (w == 0) fwd_prefetch<NT, EPI>(g, node_base + r, 0, q, pre);
   for (int c = 0; c < PF && c < nchunk; ++c) stage(c);
   for (int ci = 0; ci < nchunk; ++ci) {
     const int younger = min(PF - 1, nchunk - 1 - ci);
@@ -555,7 +552,6 @@ __global__ __launch_bounds__(256) void gemm_rows_split_kernel(GemmArgs g) {
     const float4 v = dump[u * 64 + lane];
     row[u] = (f32x4){v.x, v.y, v.z, v.w};
   }
-  if (!g.hoist) fwd_prefetch<NT, EPI>(g, node_base + r, 0, q, pre);
   fwd_epilogue<NT, EPI>(g, row, pre, 0, q);
 }
 
@@ -577,12 +573,15 @@ __global__ __launch_bounds__(256) void gemm_rows_split_kernel(GemmArgs g) {
 // Every output accumulates chunk by chunk, e = 0..3 inside, as in gemm_nt_lds_kernel: bit-identical results (tests/test_gpu_ops.py).
 // vmcnt bookkeeping: a wave's vector-memory operations complete in issue order (loads, stores and LDS-DMA alike), so "all but the 4
 // youngest" at the end of a tile's MFMAs is "everything except the DMA pieces of the tile after next", whatever stores are in flight.
+constexpr int kWsWorkgroups = 512;        // its persistent workgroups: two per CU (256 / 768 measured slower, profiles/r05_proj_ws_bench.txt)
+constexpr int kWsStagger = 4;             // its second generation of workgroups (linear id >= 256) starts this many x 512 cycles late (0 / 2 / 6 / 8 measured slower)
 struct WsStamp {
   unsigned long long t[24];   // [0] start, [1] weights + first tile ready, [2 + 2 i] MFMAs of tile i done, [3 + 2 i] its stores issued (i < 9),
 };                            // [20] linear id, [21] HW_ID, [22] tiles, [23] XCC_ID
 
-template <int EPI, bool STAMP, bool WLINES>
-__global__ __launch_bounds__(256, 1) void proj_ws_kernel(GemmArgs g, int stagger, WsStamp *stamps, int flags) {
+template <int EPI, bool STAMP>
+__global__ __launch_bounds__(256, 1) void proj_ws_kernel(GemmArgs g, WsStamp *stamps) {
+  constexpr int stagger = kWsStagger;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NCH = 16;             // 16-wide chunks of K = 2 d = 256
   constexpr int SLOT = NCH * 256;     // floats of one tile: 16 rows x 256 k as 16 fragment blocks of 1 KB
@@ -630,7 +629,7 @@ __global__ __launch_bounds__(256, 1) void proj_ws_kernel(GemmArgs g, int stagger
   // Infinity Cache's latency): every CU pulling the same 128 KB of weights that way took 5 us, with 8 workgroups on the chip as with
   // 256.  So each wave first touches ONE KB of [W1 | W2] -- the 32 CUs x 4 waves of an XCD (workgroups b, b + 8, ... share one) a
   // different KB each -- and waits: one round trip later the whole matrix sits in the XCD's L2 and the real loads below are L2 hits.
-  if (flags & 1) {
+  {
     const int slice = ((b >> 3) & 31) * 4 + w;   // 0 .. 127: KB of W1 (< 64) or W2
     const float *wp = g.w[0][slice >> 6] + (size_t)(slice & 63) * 256 + 4 * lane;
     f32x4 sink;
@@ -639,46 +638,17 @@ __global__ __launch_bounds__(256, 1) void proj_ws_kernel(GemmArgs g, int stagger
   if (STAMP && stamp && lane == 0) stamp->t[19] = wall_clock64();
   // the wave's slice of [W1 | W2]: block u (features 32 w + 16 u + r), chunk c (k = 16 c + 4 q .. + 3; c >= 8 is W2)
   float4 wr[2][NCH];
-  if constexpr (WLINES) {
-    // in WHOLE 128-B lines: an instruction reads 8 rows x 128 B (lanes r < 8 chunk 2 p of row r & 7, lanes r >= 8 chunk 2 p + 1 of the
-    // same rows), a second one the block's other 8 rows, and the halves of a 16-lane row trade places (DPP row_ror:8, no LDS)
-    const bool lo8 = r < 8;
-    auto rot8 = [](const float4 &v) {
-      float4 o;
-      o.x = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.x), 0x128, 0xF, 0xF, true));
-      o.y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.y), 0x128, 0xF, 0xF, true));
-      o.z = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.z), 0x128, 0xF, 0xF, true));
-      o.w = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v.w), 0x128, 0xF, 0xF, true));
-      return o;
-    };
-    float4 la[2][NCH / 2], lb[2][NCH / 2];
+  // (fetching them in whole 128-B lines, the halves of a 16-lane row traded by DPP -- round 5's gemm_ws_mode bit 1 -- measured no faster and
+  //  was removed in round 6)
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int pc = 0; pc < NCH / 2; ++pc) {   // pc = 4 kh + p: chunk pair (2 p, 2 p + 1) of W1 (kh = 0) / W2
-        const float *base = g.w[0][pc >> 2] + (size_t)(32 * w + 16 * u + (r & 7)) * g.ld_w + 16 * (2 * (pc & 3) + (r >> 3)) + 4 * q;
-        la[u][pc] = ld4(base);
-        lb[u][pc] = ld4(base + (size_t)8 * g.ld_w);
-      }
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int pc = 0; pc < NCH / 2; ++pc) {
-        const float4 ra = rot8(la[u][pc]), rb = rot8(lb[u][pc]);
-        wr[u][2 * pc] = lo8 ? la[u][pc] : rb;
-        wr[u][2 * pc + 1] = lo8 ? ra : lb[u][pc];
-      }
-  } else {
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-        wr[u][c] = ld4(g.w[0][c >> 3] + (size_t)(32 * w + 16 * u + r) * g.ld_w + 16 * (c & 7) + 4 * q);
-  }
+    for (int c = 0; c < NCH; ++c)
+      wr[u][c] = ld4(g.w[0][c >> 3] + (size_t)(32 * w + 16 * u + r) * g.ld_w + 16 * (c & 7) + 4 * q);
   const int j = 32 * w + (odd ? 16 : 0) + 4 * q;   // the lane's columns in the whole-line layout (both rows of its pair)
   const float4 bb = add4(ld4(g.b1 + j), ld4(g.b2 + j));
   // second-generation workgroups (those that double up on the CUs, by dispatch order: speed only) start late
-  if (stagger > 0 && b >= 256)
+  if (b >= 256)
     for (int k = 0; k < stagger; ++k) __builtin_amdgcn_s_sleep(8);
   // everything requested so far is in: both tiles and the weights.  The BUILTIN form, so that hipcc's own wait-count pass sees the
   // weight loads complete here -- with an asm wait it would put its wait for them in front of the loop's first MFMA, where it also
@@ -811,8 +781,6 @@ __global__ __launch_bounds__(256, 1) void proj_ws_kernel(GemmArgs g, int stagger
 // all workgroups reach the store phase together.
 
 // debug knob "wgrad_wgs": workgroups of a full-size weight-gradient launch (one per CU)   [knob wgrad_wgs, common.h Knobs]
-// debug knob "xcd_remap": workgroups that share input rows on one XCD (xcd_ids)   [knob xcd_remap, common.h Knobs]
-// debug knob "gemm_small_nt": narrowest feature tile (in 16-feature units) for small problems, 0 = never narrow   [knob gemm_small_nt, common.h Knobs]
 
 unsigned long long *g_gemm_stamps = nullptr;   // gss_debug_set_stamp_buffer: diagnostic only, process-wide, not a knob
 
@@ -822,18 +790,14 @@ template <int EPI>
 static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
   if (g_in.n <= 0) return GSS_OK;
   GemmArgs g = g_in;
-  g.xcd_remap = K().xcd_remap;
-  g.hoist = K().gemm_hoist;
   g.stamps = g_gemm_stamps;
   {
     int nt = (d % 128 == 0) ? 8 : (d % 64 == 0) ? 4 : (d % 32 == 0) ? 2 : 1;
     if (EPI == EPI_FWD_NORM && d == 256) nt = 16;   // the fused row norm needs a row's features in one tile
-    if (K().gemm_nt_cap > 0 && EPI != EPI_FWD_NORM)   // debug knob "gemm_nt_cap": narrower feature tiles (the fused normalise needs whole rows)
-      while (nt > K().gemm_nt_cap) nt >>= 1;
     // few node rows (the top layer's batch-row input gradient: 2048 rows): narrower feature tiles so that the grid covers the chip
     // (64-node x 128-feature tiles give 64 workgroups at B = 2048, d = 128; 32-feature tiles 256)
-    if (EPI == EPI_SPLIT && K().gemm_small_nt > 0)
-      while (nt > K().gemm_small_nt && (int64_t)ceil_div(g.n, 64) * (g.J / (16 * nt)) < 256) nt >>= 1;
+    if (EPI == EPI_SPLIT)
+      while (nt > 2 && (int64_t)ceil_div(g.n, 64) * (g.J / (16 * nt)) < 256) nt >>= 1;
     // 64-node tiles give 2-3 co-resident workgroups per CU (epilogue traffic overlaps MFMA); at d >= 256 the
     // W-staging redundancy of small tiles costs more than that buys (measured, tools/gemm_bench.py), and so it does once
     // the grid is many waves of workgroups deep (d = 128: N = 1M 791 -> 753 us, N = 4M 3061 -> 2913 us with 128-node tiles)
@@ -841,7 +805,7 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
     if (EPI != EPI_SPLIT && g.rows && (int64_t)ceil_div(g.n, 64) * (g.J / (16 * nt)) < 256) {
       // forward over a short row list: 16 listed rows per workgroup.  Whole rows of 64 / 128 / 256 features: 4 waves that split the
       // features (gemm_rows_split_kernel, same bits); other widths: one wave per 16 x 16 nt tile
-      if (EPI != EPI_SPLIT && g.J == d && g.jsplit == d && (d == 64 || d == 128 || d == 256) && K().gemm_rows_split) {
+      if (EPI != EPI_SPLIT && g.J == d && g.jsplit == d && (d == 64 || d == 128 || d == 256)) {
         dim3 gridr(ceil_div(g.n, 16));
         const size_t ldsr = 4 * (size_t)(16 * 16 + d * 16) * sizeof(float);
         if (d == 64)
@@ -873,18 +837,13 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
       const bool ws = K().gemm_ws == 1 || (K().gemm_ws < 0 && g.n >= kWsMinRows);
       if (ws && K().gemm_variant == 2 && d == 128 && g.K == 256 && g.J == 128 && !g.rows && g.in1 && (!g.rows_out || g.rows_out_pos)) {
         const int ntiles = ceil_div(g.n, 16);
-        const int wgs = std::min(ntiles, K().gemm_ws_wgs);
+        const int wgs = std::min(ntiles, kWsWorkgroups);
         const size_t ldsw = (size_t)(3 * 16 * 256 + 2 * 512) * sizeof(float);
-        const int mode = K().gemm_ws_mode;   // bit 0: L2 warm-up pass, bit 1: the weights in whole lines
         WsStamp *sp = reinterpret_cast<WsStamp *>(g.stamps);   // diagnostic (gss_debug_set_stamp_buffer; tools/proj_ws_stamps.py): 24 x 8 bytes per wave
-        if (sp && (mode & 2))
-          hipLaunchKernelGGL((proj_ws_kernel<EPI, true, true>), dim3(wgs), dim3(256), ldsw, st, g, K().gemm_ws_stagger, sp, mode);
-        else if (sp)
-          hipLaunchKernelGGL((proj_ws_kernel<EPI, true, false>), dim3(wgs), dim3(256), ldsw, st, g, K().gemm_ws_stagger, sp, mode);
-        else if (mode & 2)
-          hipLaunchKernelGGL((proj_ws_kernel<EPI, false, true>), dim3(wgs), dim3(256), ldsw, st, g, K().gemm_ws_stagger, sp, mode);
+        if (sp)
+          hipLaunchKernelGGL((proj_ws_kernel<EPI, true>), dim3(wgs), dim3(256), ldsw, st, g, sp);
         else
-          hipLaunchKernelGGL((proj_ws_kernel<EPI, false, false>), dim3(wgs), dim3(256), ldsw, st, g, K().gemm_ws_stagger, sp, mode);
+          hipLaunchKernelGGL((proj_ws_kernel<EPI, false>), dim3(wgs), dim3(256), ldsw, st, g, sp);
         GSS_LAUNCH_CHECK("proj_ws_kernel");
         return GSS_OK;
       }
@@ -896,7 +855,7 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
       GSS_LAUNCH_CHECK("gemm_nt_lds_kernel (stamped)");
       return GSS_OK;
     }
-    if ((K().gemm_variant == 5 || (K().gemm_variant == 2 && d == 128)) && nt == 8 && !g.rows && K().gemm_lines && EPI != EPI_SPLIT) {
+    if ((K().gemm_variant == 5 || (K().gemm_variant == 2 && d == 128)) && nt == 8 && !g.rows && EPI != EPI_SPLIT) {
       // 128-node tiles as EIGHT waves of 16 nodes (round 4): the weights are staged once per 128 nodes as with MT = 2, but a wave keeps
       // the 16-node tile's 104-110 registers (no hoisted operands, the whole-line epilogue), so two such workgroups share a CU: 16
       // waves per CU instead of 8.  Same MFMA order per output, same bits.  d = 128 (tools/gemm_w8_ab.py): 28.0 vs 30.2 us (64-node
@@ -923,7 +882,7 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
     }
     // passes without a row list write whole 128-B lines (fwd_epilogue_lines; a row list keeps the MFMA layout: its rows are
     // scattered, and the lazy step's contract -- the bits of the full pass -- holds because both forms add a row's squares in one order)
-    if (!g.rows && K().gemm_lines && nt >= 2) {
+    if (!g.rows && nt >= 2) {
       constexpr int E = EPI;
 #define GSS_GEMM_LINES(NTV)                                                                             \
   case NTV:                                                                                             \
@@ -1066,7 +1025,6 @@ int dense_bwd_input(int32_t n, int32_t d, const float *dp, const float *w1t, con
 // set costs more in registers than the exposed latency it covers (the SIMD's partner wave already covers it).
 
 constexpr int kWgWaves = 8;
-constexpr size_t kWgradRingLds = (size_t)kWgWaves * 2 * 2 * 4 * 1024;   // RING: 8 waves x 2 trips x (4 + 4) fragment blocks of 1 KB = 128 KB
 
 struct WgradArgs {
   int n, d;
@@ -1075,22 +1033,17 @@ struct WgradArgs {
   float *part_w;  // [nslices][d][2d]
   float *part_b;  // [nslices][d]
   int rows_per_slice;
-  int xcd_remap;
 };
 
 // Two problems may share one launch (grid.y = ns0 + slices of the second): the top layer's batch-row gradient is 64
 // latency-bound workgroups on its own (10 us) and rides along with a full-N launch for free.
-// RING (round 3, knob wgrad_variant = 2): the operand rows of a trip arrive by LDS-DMA in a per-wave private ring (2 trips x 8
-// fragment blocks of 1 KB: 16 KB per wave, 128 KB per workgroup), requested one trip ahead of the MFMAs that consume them and read back
-// with one conflict-free ds_read_b128 per lane -- the operand fetch from L2 then sits under the previous trip's 64 MFMAs instead of in
-// front of its own (the direct-load form parks a wave at s_waitcnt for a quarter of its life: SQ_WAIT_ANY 26 %).  No
-// barrier in the loop: a wave stages and reads only its own rows.  The MFMA order is untouched, so the results keep their bits.
-template <bool RING>
+// (An LDS-DMA ring for the operand rows, one trip ahead -- round 3's wgrad_variant 2 -- measured 2-3 % slower in three live sweeps and was
+// removed in round 6: profiles/r03_wgrad_variant_ab.txt, r04_knob_sweep_live.txt, r05_knob_sweep_live_config3.txt.)
 __global__ __launch_bounds__(64 * kWgWaves) void wgrad_tn_kernel(WgradArgs g0, WgradArgs g1, int ns0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // grid = (output tiles, node slices): the output tiles of a slice read the same dP / Z rows
   const XcdIds id = xcd_ids((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)gridDim.y, (int)gridDim.x, true);
-  const int bx = g0.xcd_remap ? id.share : (int)blockIdx.x, by = g0.xcd_remap ? id.spread : (int)blockIdx.y;
+  const int bx = id.share, by = id.spread;
   const bool second = by >= ns0;
   const WgradArgs &g = second ? g1 : g0;
   // the two waves of a SIMD run the same program in lockstep; a static priority for one half (MI355X guide, item 4)
@@ -1119,58 +1072,6 @@ __global__ __launch_bounds__(64 * kWgWaves) void wgrad_tn_kernel(WgradArgs g0, W
   // four row-steps per trip: all 8 operand loads are issued first (branch-free: rows beyond the slice read a
   // valid row and are multiplied by 0), then the 64 MFMAs run while the next trip's loads are in flight
   constexpr int U = 4;
-  if (RING && !g.rows) {   // (the batch-row problem gathers Z rows through an index: it keeps the direct loads below)
-    constexpr int D = 2;                                   // trips in flight
-    const int wu = __builtin_amdgcn_readfirstlane(w);   // wave-uniform: the LDS destination of a DMA travels in M0 (an SGPR)
-    const unsigned ring = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem + (unsigned)wu * (D * 2 * U * 1024);
-    const float *ringf = reinterpret_cast<const float *>(smem) + (size_t)wu * (D * 2 * U * 256);
-    const int first = __builtin_amdgcn_readfirstlane(r0) + 4 * wu;
-    const int step = 4 * kWgWaves * U;
-    const int r1u = __builtin_amdgcn_readfirstlane(r1);
-    const int ntrips = first < r1u ? (r1u - first + step - 1) / step : 0;
-    auto issue = [&](int t) {
-      const int base = first + t * step;
-      const unsigned slot = __builtin_amdgcn_readfirstlane(ring + (unsigned)((t % D) * 2 * U * 1024));
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int row = base + u * 4 * kWgWaves + q;
-        const int rc = row < r1 ? row : r1 - 1;
-        glds16(g.dp + (size_t)rc * g.d + ac, slot + (unsigned)(u * 1024));
-        glds16(z + (size_t)rc * g.d + zc, slot + (unsigned)((U + u) * 1024));
-      }
-    };
-    for (int t = 0; t < D && t < ntrips; ++t) issue(t);
-    for (int t = 0; t < ntrips; ++t) {
-      if (t + 1 < ntrips)
-        wait_vmcnt<2 * U>();      // trip t has landed once at most the 2 U requests of trip t + 1 are outstanding
-      else
-        wait_vmcnt<0>();
-      const float *slot = ringf + (size_t)(t % D) * (2 * U * 256);
-      float4 a4[U], b4[U];
-      float msk[U];
-      const int base = first + t * step;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        a4[u] = *reinterpret_cast<const float4 *>(slot + u * 256 + lane * 4);
-        b4[u] = *reinterpret_cast<const float4 *>(slot + (U + u) * 256 + lane * 4);
-        msk[u] = (base + u * 4 * kWgWaves + q) < r1 ? 1.f : 0.f;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments are in registers: the slot may be refilled
-      if (t + D < ntrips) issue(t + D);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const float4 am = scale4(msk[u], a4[u]);
-        cs = add4(cs, am);
-        const float av[4] = {am.x, am.y, am.z, am.w};
-        const float bv[4] = {b4[u].x, b4[u].y, b4[u].z, b4[u].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int e2 = 0; e2 < 4; ++e2) acc[e][e2] = mfma16(av[e], bv[e2], acc[e][e2]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else
   for (int base = r0 + 4 * w; base < r1; base += 4 * kWgWaves * U) {
     float4 a4[U], b4[U];
     float msk[U];
@@ -1198,7 +1099,6 @@ __global__ __launch_bounds__(64 * kWgWaves) void wgrad_tn_kernel(WgradArgs g0, W
     }
   }
 
-  if (RING) __syncthreads();   // the reduction slots below alias the rings: every wave is done reading its own first
   // tree reduction over the 8 waves (fixed order): 4..7 -> 0..3, 2..3 -> 0..1, 1 -> 0
   for (int half = kWgWaves / 2; half >= 1; half >>= 1) {
     if (w >= half && w < 2 * half) {
@@ -1297,7 +1197,8 @@ __device__ __forceinline__ float adam_update(float p, float g, float &m, float &
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int d, int nslices, const float *__restrict__ part_w,
                                                             const float *__restrict__ part_b, float *__restrict__ gw1,
                                                             float *__restrict__ gw2, float *__restrict__ gb, float *__restrict__ gb2,
-                                                            int accumulate, FusedAdam ad, int deep) {
+                                                            int accumulate, FusedAdam ad) {
+  constexpr int deep = 2;   // Adam's state / the batch ids requested first, slabs fetched sixteen at a time (the shallower forms of rounds 3-4 went in round 6)
   // 64 consecutive outputs per workgroup; wave w sums slices w, w+4, ... (4 loads in flight), LDS adds the 4
   // wave sums in wave order -> fixed summation order
   __shared__ float red[4][64];
@@ -1429,7 +1330,7 @@ int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const 
   *nslices_out = ns;
   float *pw = (float *)ws + (size_t)slice0 * d * 2 * d;
   float *pb = (float *)ws + (size_t)total_slices * d * 2 * d + (size_t)slice0 * d;
-  WgradArgs g{n, d, dp, ax, am, rows, pw, pb, rps, K().xcd_remap};
+  WgradArgs g{n, d, dp, ax, am, rows, pw, pb, rps};
   if (n == 0) {  // empty shard: its slices must still read as zero
     GSS_HIP(hipMemsetAsync(pw, 0, sizeof(float) * (size_t)ns * d * 2 * d, st));
     GSS_HIP(hipMemsetAsync(pb, 0, sizeof(float) * (size_t)ns * d, st));
@@ -1437,12 +1338,7 @@ int wgrad_partial(int32_t n, int32_t d, const float *dp, const float *ax, const 
   }
   if (d % 64 == 0) {
     const int tiles = (d / 64) * (2 * d / 64);
-    if (K().wgrad_variant == 2)
-      hipLaunchKernelGGL(wgrad_tn_kernel<true>, dim3(tiles, ns), dim3(64 * kWgWaves), lds_request(wgrad_tn_kernel<true>, kWgradRingLds),
-                         st, g, g, ns);
-    else
-      hipLaunchKernelGGL(wgrad_tn_kernel<false>, dim3(tiles, ns), dim3(64 * kWgWaves),
-                         lds_request(wgrad_tn_kernel<false>, 4 * 16 * 64 * sizeof(float4)), st, g, g, ns);
+    hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns), dim3(64 * kWgWaves), lds_request(wgrad_tn_kernel, 4 * 16 * 64 * sizeof(float4)), st, g, g, ns);
     GSS_LAUNCH_CHECK("wgrad_tn_kernel");
   } else {
     hipLaunchKernelGGL(wgrad_simple_kernel, dim3(ceil_div((int64_t)d * 2 * d + d, 256), ns), dim3(256), 0, st, g);
@@ -1469,15 +1365,11 @@ int wgrad_partial_pair(int32_t d, int32_t n0, const float *dp0, const float *ax0
   *ns0_out = ns0;
   *ns1_out = ns1;
   float *base_w = (float *)ws, *base_b = (float *)ws + (size_t)total_slices * d * 2 * d;
-  WgradArgs g0{n0, d, dp0, ax0, am0, rows0, base_w + (size_t)slice0_0 * d * 2 * d, base_b + (size_t)slice0_0 * d, rps0, K().xcd_remap};
-  WgradArgs g1{n1, d, dp1, ax1, am1, rows1, base_w + (size_t)slice0_1 * d * 2 * d, base_b + (size_t)slice0_1 * d, rps1, K().xcd_remap};
+  WgradArgs g0{n0, d, dp0, ax0, am0, rows0, base_w + (size_t)slice0_0 * d * 2 * d, base_b + (size_t)slice0_0 * d, rps0};
+  WgradArgs g1{n1, d, dp1, ax1, am1, rows1, base_w + (size_t)slice0_1 * d * 2 * d, base_b + (size_t)slice0_1 * d, rps1};
   const int tiles = (d / 64) * (2 * d / 64);
-  if (K().wgrad_variant == 2)
-    hipLaunchKernelGGL(wgrad_tn_kernel<true>, dim3(tiles, ns0 + ns1), dim3(64 * kWgWaves),
-                       lds_request(wgrad_tn_kernel<true>, kWgradRingLds), as_stream(stream), g0, g1, ns0);
-  else
-    hipLaunchKernelGGL(wgrad_tn_kernel<false>, dim3(tiles, ns0 + ns1), dim3(64 * kWgWaves),
-                       lds_request(wgrad_tn_kernel<false>, 4 * 16 * 64 * sizeof(float4)), as_stream(stream), g0, g1, ns0);
+  hipLaunchKernelGGL(wgrad_tn_kernel, dim3(tiles, ns0 + ns1), dim3(64 * kWgWaves), lds_request(wgrad_tn_kernel, 4 * 16 * 64 * sizeof(float4)),
+                     as_stream(stream), g0, g1, ns0);
   GSS_LAUNCH_CHECK("wgrad_tn_kernel");
   return GSS_OK;
 }
@@ -1491,7 +1383,7 @@ static int wgrad_reduce_launch(int32_t d, void *ws, int total_slices, int nslice
   int nblk = ceil_div((int64_t)d * 2 * d + d, 64);
   if (ad.enabled && ad.pos_clear) nblk = std::max(nblk, ceil_div(ad.b, 256));
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), d, nslices, pw, pb, gw1, gw2, gb, gb2,
-                     accumulate, ad, K().wgrad_deep);
+                     accumulate, ad);
   GSS_LAUNCH_CHECK("wgrad_reduce_kernel");
   return GSS_OK;
 }

@@ -547,30 +547,47 @@ int bits_set_list(uint32_t *bits, const int32_t *list, int64_t n, void *stream) 
   return GSS_OK;
 }
 
+size_t bits_compact_scratch_bytes(int P, const int64_t *h_woff) {
+  int64_t nblk = 0;
+  for (int q = 0; q < P; ++q) nblk += (h_woff[q + 1] - h_woff[q] + kCompactWords - 1) / kCompactWords;
+  return ((size_t)nblk * sizeof(int32_t) + 15) / 16 * 16 + sizeof(int64_t) * ((size_t)nblk + 1);
+}
+
 int bits_compact(const uint32_t *words, int P, const int64_t *d_woff, const int64_t *h_woff, const int64_t *d_slot_off, const int32_t *map, int32_t add,
-                 int32_t *out, int64_t *d_out_off, void *stream) {
+                 int32_t *out, int64_t *d_out_off, void *stream, void *scratch, size_t scratch_bytes) {
   GSS_REQUIRE(words && d_woff && h_woff && d_slot_off && out && d_out_off && P >= 1, "bits_compact: bad argument");
   hipStream_t st = as_stream(stream);
   int64_t nblk = 0;
   for (int q = 0; q < P; ++q) nblk += (h_woff[q + 1] - h_woff[q] + kCompactWords - 1) / kCompactWords;
   GSS_REQUIRE(nblk < (int64_t)INT32_MAX, "bits_compact: %lld blocks", (long long)nblk);
-  // counts (int32) and bases (int64, one more than blocks) of the blocks: stream-ordered scratch
-  char *tmp = nullptr;
+  // counts (int32) and bases (int64, one more than blocks) of the blocks: the caller's scratch (a plan carves it from its slab: nothing is
+  // allocated inside a step), or stream-ordered scratch for a caller without one
   const size_t tot_bytes = ((size_t)nblk * sizeof(int32_t) + 15) / 16 * 16;
-  GSS_HIP(hipMallocAsync((void **)&tmp, tot_bytes + sizeof(int64_t) * ((size_t)nblk + 1), st));
+  const size_t need = tot_bytes + sizeof(int64_t) * ((size_t)nblk + 1);
+  char *tmp = static_cast<char *>(scratch);
+  const bool own = !tmp || scratch_bytes < need;
+  if (own) GSS_HIP(hipMallocAsync((void **)&tmp, need, st));
   int32_t *block_tot = reinterpret_cast<int32_t *>(tmp);
   int64_t *base = reinterpret_cast<int64_t *>(tmp + tot_bytes);
+  hipError_t e = hipSuccess;
+  const char *what = "";
   if (nblk > 0) {
     hipLaunchKernelGGL(bits_count_kernel, dim3((unsigned)nblk), dim3(1024), 0, st, words, P, d_woff, block_tot);
-    GSS_LAUNCH_CHECK("bits_count_kernel");
+    e = hipGetLastError();
+    what = "bits_count_kernel";
   }
-  hipLaunchKernelGGL(bits_scan_kernel, dim3(1), dim3(1024), 0, st, P, d_woff, (int)nblk, block_tot, base, d_out_off);
-  GSS_LAUNCH_CHECK("bits_scan_kernel");
-  if (nblk > 0) {
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(bits_scan_kernel, dim3(1), dim3(1024), 0, st, P, d_woff, (int)nblk, block_tot, base, d_out_off);
+    e = hipGetLastError();
+    what = "bits_scan_kernel";
+  }
+  if (e == hipSuccess && nblk > 0) {
     hipLaunchKernelGGL(bits_write_kernel, dim3((unsigned)nblk), dim3(1024), 0, st, words, P, d_woff, d_slot_off, map, add, base, out);
-    GSS_LAUNCH_CHECK("bits_write_kernel");
+    e = hipGetLastError();
+    what = "bits_write_kernel";
   }
-  GSS_HIP(hipFreeAsync(tmp, st));
+  if (own) (void)hipFreeAsync(tmp, st);     // on the error paths too
+  if (e != hipSuccess) return fail(GSS_EHIP, "launch %s -> %s", what, hipGetErrorString(e));
   return GSS_OK;
 }
 

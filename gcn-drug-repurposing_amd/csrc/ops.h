@@ -122,7 +122,8 @@ int send_slot_bits(const uint32_t *bits, const int32_t *send_rows, int P, const 
 int bits_clear(uint32_t *bits, int64_t first, int64_t last, void *stream);          // bits [first, last) := 0
 int bits_set_list(uint32_t *bits, const int32_t *list, int64_t n, void *stream);    // bits[list[k]] := 1
 int bits_compact(const uint32_t *words, int P, const int64_t *d_woff, const int64_t *h_woff, const int64_t *d_slot_off, const int32_t *map, int32_t add,
-                 int32_t *out, int64_t *d_out_off, void *stream);
+                 int32_t *out, int64_t *d_out_off, void *stream, void *scratch = nullptr, size_t scratch_bytes = 0);
+size_t bits_compact_scratch_bytes(int P, const int64_t *h_woff);   // what bits_compact needs as scratch for these word offsets
 int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,
                      const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream,
                      const uint32_t *posbits = nullptr, uint32_t *nzbits_out = nullptr, int skip_zero_rows = 0);

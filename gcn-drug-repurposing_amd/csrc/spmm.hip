@@ -51,7 +51,6 @@ struct SpmmEpi {
                                 // under a row bitmap, whose second pass carries the same bitmap as posbits)
   BatchPrep prep;               // SPMM_FWD1, prep.idx != NULL: the launch has one workgroup more than segment blocks -- its first --, which
   int prep_block;               // prepares the batch (see BatchPrep) instead of multiplying
-  int pair_index;               // narrow lane groups take their (col, val) pairs two per lane and trip: whole-line index loads (knob "spmm_pair")
   int pos_row_limit;            // SPMM_BWD2S / SPMM_BWD2, > 0: t, the residual and pos_row are defined for output rows below it only (a shard's
                                 // own rows; the rows behind them -- the boundary rows of the in-place transposed A_hat -- have none)
   const int32_t *row_alias;     // SPMM_PLAIN, optional (the chunk pass of GiantRows): the row filters (pos, rowbits) are looked up at
@@ -279,7 +278,7 @@ __device__ __forceinline__ bool row_mark_nonzero(const SpmmEpi &ep, int row, boo
   return !live;
 }
 
-template <int MODE, int LPR_LOG2, int VPL, bool NARROW, int FLY = 4>
+template <int MODE, int LPR_LOG2, int VPL, bool NARROW>
 __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, const int4 *__restrict__ segs, int d4,
                                                                    const float *__restrict__ x, SpmmEpi ep, int rowstride_f, int pin_ns, int3 hot) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -394,7 +393,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   typedef int int2u __attribute__((ext_vector_type(2), aligned(4)));
   typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
   const bool sparse_walk = MODE == SPMM_BWD1S || (MODE == SPMM_BWD2S && ep.posbits) || (MODE == SPMM_PLAIN && ep.gather_bits);
-  if (LPR <= 16 && FLY == 4 && ep.pair_index && !sparse_walk) {
+  if (LPR <= 16 && !sparse_walk) {
     auto load2 = [&](int idx, int &c0, int &c1, float &w0, float &w1) __attribute__((always_inline)) {
       c0 = c1 = 0;
       w0 = w1 = 0.f;
@@ -456,7 +455,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
     }
     const int ce = base + li;
     const int cnt = min(LPR, e1 - base);  // <= 0 once this group is done
-    constexpr int kFly = FLY;
+    constexpr int kFly = 4;   // (8 in flight measured 3-9 % slower at RMAT 10M and no faster at config 2 / 3 in three sweeps; the knob went in round 6)
     if (MODE == SPMM_BWD1S || (MODE == SPMM_BWD2S && ep.posbits) || (MODE == SPMM_PLAIN && ep.gather_bits)) {
       // row-sparse operand.  BWD1S: only neighbours that are batch rows contribute (about B/N of the entries): look the neighbour up in
       // the node -> compact-row map (behind the bitmap when there is one).  BWD2S with a bitmap: only neighbours whose row of u may be
@@ -647,7 +646,6 @@ int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks
   return GSS_OK;
 }
 
-// debug knob "spmm_fly": row gathers in flight per lane group on the large-table path (4 or 8)   [knob spmm_fly, common.h Knobs]
 // debug knob "spmm_hot_rows": overrides every CSR's hot set with rows [0, value) (-1 = use the CSR's own, 0 = none)   [knob spmm_hot, common.h Knobs]
 // 0 = automatic (see launch_balanced)   [knob spmm_slices, common.h Knobs]
 // with a manual "spmm_slices": slices pinned to XCDs (1) or time-separated (0)   [knob spmm_pin, common.h Knobs]
@@ -663,19 +661,15 @@ static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool p
   SpmmEpi ep = ep_in;
   const bool prep = MODE == SPMM_FWD1 && ep.prep.idx != nullptr;
   ep.prep_block = 0;
-  ep.pair_index = K().spmm_pair;
   const int extra = prep ? 1 : 0;             // the batch preparation rides as one more workgroup, the first of the launch
   int3 hot = make_int3(a->hot_own, a->hot_halo0, a->hot_halo1);
   if (K().spmm_hot >= 0) hot = K().spmm_hot > 0 ? make_int3(K().spmm_hot, 0, 0) : make_int3(-1, 0, 0);
   // the hot / cold split pays where the table is far beyond the caches; below that every row is "hot"
   if ((double)a->n_cols * d4_slice * nslices * 16.0 < 256.0 * 1024 * 1024 && K().spmm_hot < 0) hot = make_int3(-1, 0, 0);
-  const bool narrow = (double)a->n_cols * d4_slice * nslices * 16.0 < 4.0e9 && a->n_cols < (1 << 24) && hot.x < 0 && K().spmm_fly == 4;
+  const bool narrow = (double)a->n_cols * d4_slice * nslices * 16.0 < 4.0e9 && a->n_cols < (1 << 24) && hot.x < 0;
   if (narrow)
     hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, true>), pin ? dim3(nblk * nslices + extra) : dim3(nblk + extra, nslices), dim3(kBalThreads),
                        lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, make_int3(-1, 0, 0));
-  else if (K().spmm_fly == 8)
-    hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, false, 8>), pin ? dim3(nblk * nslices + extra) : dim3(nblk + extra, nslices), dim3(kBalThreads),
-                       lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, hot);
   else
     hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, false>), pin ? dim3(nblk * nslices + extra) : dim3(nblk + extra, nslices), dim3(kBalThreads),
                        lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, hot);
@@ -740,7 +734,42 @@ struct gss_giant_rows {
   gss_csr chunks{}, shortv{}, finish{};
   int32_t *d_chunk_row = nullptr, *d_fin_col = nullptr;
   float *d_fin_val = nullptr;
+  // the chunks' partial sums [n_chunks][d]: one buffer per stream the handle is used on (a plan's pipelined / overlapped hops run products
+  // of one matrix on two streams), grown to the widest d seen -- nothing is allocated per product
+  struct Scratch {
+    hipStream_t st;
+    float *buf;
+    size_t floats;
+  };
+  std::vector<Scratch> scratch;
+  int scratch_for(hipStream_t st, size_t floats, float **out) {
+    for (Scratch &s : scratch)
+      if (s.st == st) {
+        if (s.floats < floats) {
+          GSS_HIP(hipStreamSynchronize(st));   // (a product of a narrower d may still read it)
+          GSS_HIP(hipFree(s.buf));
+          s.buf = nullptr;
+          s.floats = 0;
+          GSS_HIP(hipMalloc((void **)&s.buf, sizeof(float) * floats));
+          s.floats = floats;
+        }
+        *out = s.buf;
+        return GSS_OK;
+      }
+    float *b = nullptr;
+    GSS_HIP(hipMalloc((void **)&b, sizeof(float) * floats));
+    scratch.push_back(Scratch{st, b, floats});
+    *out = b;
+    return GSS_OK;
+  }
+  size_t scratch_bytes() const {
+    size_t t = 0;
+    for (const Scratch &s : scratch) t += sizeof(float) * s.floats;
+    return t;
+  }
   ~gss_giant_rows() {
+    for (Scratch &s : scratch)
+      if (s.buf) (void)hipFree(s.buf);
     for (gss_csr *v : {&chunks, &shortv, &finish})
       for (int k = 0; k < 5; ++k)
         if (v->d_segs[k]) (void)hipFree(v->d_segs[k]);
@@ -839,8 +868,8 @@ template <int MODE>
 static int launch_giant(const gss_csr *a, gss_giant_rows *g, int d4, const float *x, const SpmmEpi &ep, hipStream_t st) {
   (void)a;
   float *scratch = nullptr;
-  GSS_HIP(hipMallocAsync((void **)&scratch, sizeof(float) * 4 * (size_t)d4 * (size_t)g->n_chunks, st));
-  int rc = GSS_OK;
+  int rc = g->scratch_for(st, 4 * (size_t)d4 * (size_t)g->n_chunks, &scratch);
+  if (rc != GSS_OK) return rc;
   {
     // 1. the chunks' partial sums; only chunks of rows the caller's product computes at all
     SpmmEpi pe{};
@@ -861,7 +890,6 @@ static int launch_giant(const gss_csr *a, gss_giant_rows *g, int d4, const float
     fe.prep = BatchPrep{};
     rc = launch_balanced<MODE>(&g->finish, d4, scratch, fe, st);
   }
-  (void)hipFreeAsync(scratch, st);
   return rc;
 }
 

@@ -124,10 +124,11 @@ class GssEngine:
         return float(out.value)
 
     def activation(self, layer: int, which: str) -> torch.Tensor:
-        """copy of AX / AM / P of a layer (parity tests)"""
-        src = self.lib.gss_plan_activation(self.handle, layer, {"AX": 0, "AM": 1, "P": 2}[which])
+        """copy of AX / AM / P of a layer, or of the gradient buffers the last backward pass left: "dP" = the bottom layer's pre-activation
+        gradient [n][d] (L >= 2), "dP_batch" = the top layer's on the batch rows, in batch order [max_batch][d] (parity tests)"""
+        src = self.lib.gss_plan_activation(self.handle, layer, {"AX": 0, "AM": 1, "P": 2, "dP": 3, "dP_batch": 4}[which])
         assert src, (layer, which)
-        out = torch.empty(self.n, self.d, dtype=torch.float32, device=self.x.device)
+        out = torch.empty(self.max_batch if which == "dP_batch" else self.n, self.d, dtype=torch.float32, device=self.x.device)
         _lib.check(self.lib.gss_memcpy_d2d(out.data_ptr(), src, out.numel() * 4, _lib.current_stream()), "gss_memcpy_d2d")
         return out
 

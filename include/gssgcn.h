@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GSS_ABI_VERSION 5   /* 5 (round 5): gss_rowsum_check, gss_plan_sync_stats, gss_comm_local_mode / gss_comm_local_log, gss_csr_giant_rows; 4 (round 4): gss_shard_desc gained a_loc_t, gss_plan_comm_stats, gss_knn_topk_rows */
+#define GSS_ABI_VERSION 6   /* 6 (round 6): gss_source_hash; the access-shape knobs whose sweeps said "default holds" twice are gone; 5 (round 5): gss_rowsum_check, gss_plan_sync_stats, gss_comm_local_mode / gss_comm_local_log, gss_csr_giant_rows; 4 (round 4): gss_shard_desc gained a_loc_t, gss_plan_comm_stats, gss_knn_topk_rows */
 
 #define GSS_OK 0
 #define GSS_EINVAL (-22)   /* bad argument (shape, null pointer, unsupported d) */
@@ -39,13 +39,17 @@ typedef struct gss_plan gss_plan; /* activations + workspace of one training rep
 typedef struct gss_comm gss_comm; /* the communicator of a node-range sharded job (RCCL over xGMI, or in-process ranks) */
 
 int gss_abi_version(void);
+/* sha256 (lower-case hex) of a source file the library was built from -- "spmm.hip", "dense.hip", "common.h", "gssgcn.h" ... --, of all of
+ * them concatenated in name order ("*" or NULL), or NULL for any other name.  Evidence under profiles/ records the hashes of the kernels it
+ * measured; bench.py drops a counter file whose recorded spmm.hip hash is not this library's, __graft_entry__.build() rebuilds a library
+ * whose hashes are not the tree's (a stale .so with fresh timestamps cannot pass for a current one). */
+const char *gss_source_hash(const char *file);
 /* Diagnostic builds of a measurement only (tools/gemm_stamps.py): while a device buffer is set, every wave of a projection launch
  * (gss_dense_fwd) stores its wall-clock stamps {start, loop begin, loop end, end} + {workgroup id, HW_ID} there (6 x 8 bytes per wave).
  * NULL (the default) switches it off; no production path sets it. */
 int gss_debug_set_stamp_buffer(void *device_buffer);
-/* measurement aid (tools/ab_live.py): changes one KERNEL-SELECTION knob ("gemm_lines", "spmm_pair", "wgrad_deep", "gemm_hoist",
- * "gemm_variant", "xcd_remap", "wgrad_variant", "gemm_small_nt", "gemm_nt_cap", "spmm_slices", "spmm_pin", "spmm_fly", "gemm_rows_split",
- * "gemm_ws", "gemm_ws_wgs", "gemm_ws_stagger", "gemm_ws_mode") in a live plan's snapshot, so that one plan -- the same buffers at the same addresses --
+/* measurement aid (tools/ab_live.py): changes one KERNEL-SELECTION knob ("gemm_variant", "gemm_ws", "spmm_slices", "spmm_pin") in a live
+ * plan's snapshot, so that one plan -- the same buffers at the same addresses --
  * can be timed under alternating settings; knobs that size a workspace or steer the plan's bookkeeping are refused (GSS_EINVAL).
  * Not thread-safe against gss_debug_set_option on another thread. */
 int gss_plan_debug_set_option(gss_plan *plan, const char *name, int value);
@@ -472,8 +476,8 @@ float *gss_plan_adam_buffer(gss_plan *p, int32_t moment, int32_t tensor);
 enum {
   GSS_PROF_SPMM_FWD_HAD = 0, /* AX = A x with fused Hadamard epilogue */
   GSS_PROF_SPMM_FWD = 1,     /* AM = A M */
-  GSS_PROF_SPMM_BWD1 = 2,
-  GSS_PROF_SPMM_BWD2 = 3,
+  GSS_PROF_SPMM_BWD1 = 2,    /* the top layer's first backward hop, batch-sparse (SPMM_BWD1S) */
+  GSS_PROF_SPMM_BWD2 = 3,    /* the top layer's second backward hop with the batch rows' residual folded in (SPMM_BWD2S) */
   GSS_PROF_DENSE_FWD = 4,
   GSS_PROF_DGRAD = 5,
   GSS_PROF_WGRAD = 6,        /* N-row weight gradient (+ its reduce) */
@@ -485,34 +489,31 @@ enum {
   GSS_PROF_COMM = 12,        /* sharded plans: boundary-row exchanges of the SpMM hops (pack kernel + grouped send / recv) */
   GSS_PROF_COMM_BATCH = 13,  /* sharded plans: the batch-row all-reduce(s) of the loss */
   GSS_PROF_COMM_GRADS = 14,  /* sharded plans: the all-reduce of the four weight gradients */
-  GSS_PROF_CLASSES = 15
+  GSS_PROF_SPMM_BWD1_DENSE = 15,  /* (round 6) an N-row first backward hop: layers below the top one at L >= 3, the phase-wise entry points */
+  GSS_PROF_SPMM_BWD2_DENSE = 16,  /* (round 6) an N-row second backward hop */
+  GSS_PROF_CLASSES = 17
 };
 int gss_plan_profile(gss_plan *p, int enable);
 int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void *stream);
-/* tuning/debug knobs (A/B runs inside one process): "spmm_variant" = 1 (whole-row gather, wave per row) or
- * 2 (nnz-balanced segments, default); "spmm_slices" = 0 (automatic, default) or 1..8 time-separated feature
- * slices in the balanced SpMM; "spmm_seg_edges" = entries per SpMM segment (default 32; applies to gss_csr handles
- * created afterwards); "spmm_giant" = stored entries above which a row is summed chunk by chunk across workgroups (default 32768, 0 = never;
- * gss_csr_giant_rows); "gemm_variant" = projection tile shape: 2 (by width and row count; default), 3 (128-node tiles of four
- * waves forced), 5 (128-node tiles of eight waves forced); "gemm_ws" = -1 (default: from 32,769 rows on -- more 128-node tiles than CUs) / 0 / 1: the d = 128 forward projection as the
- * weight-stationary persistent kernel (same bits; "gemm_ws_wgs", "gemm_ws_stagger", "gemm_ws_mode" shape its launch); "spmm_pin" = with a manual "spmm_slices": slices time-separated (0, default) or pinned to XCDs (1); the automatic policy pins operands of <= 64 MB; "spmm_fly" = 4 (default) / 8 row gathers in flight per lane group; "spmm_hot_rows" = -1 (default: what
- * gss_csr_set_hot declared) or a row count; "gemm_small_nt", "gemm_nt_cap" = narrowest / widest feature tile of the projections in
- * 16-feature units (0 = automatic); "xcd_remap" = 0 / 1 (default): workgroups that read the same rows share an XCD (dense kernels);
+/* tuning/debug knobs (A/B runs inside one process; 17 of them since round 6 -- the access-shape variants whose sweeps said "default holds" in
+ * two or more rounds were removed from the kernels): "spmm_variant" = 1 (whole-row gather, wave per row) or
+ * 2 (nnz-balanced segments, default); "spmm_slices" = 0 (automatic, default) or 1..8 feature slices in the balanced SpMM, "spmm_pin" = with a
+ * manual "spmm_slices": slices time-separated (0, default) or pinned to XCDs (1) -- the automatic policy pins operands of <= 64 MB;
+ * "spmm_hot_rows" = -1 (default: what gss_csr_set_hot declared) or a row count; "spmm_seg_edges" = entries per SpMM segment (default 32;
+ * applies to gss_csr handles created afterwards); "spmm_giant" = stored entries above which a row is summed chunk by chunk across workgroups
+ * (default 32768, 0 = never; gss_csr_giant_rows); "gemm_variant" = projection tile shape: 2 (by width and row count; default), 3 (128-node
+ * tiles of four waves forced), 5 (128-node tiles of eight waves forced); "gemm_ws" = -1 (default: from 32,769 rows on -- more 128-node
+ * tiles than CUs) / 0 / 1: the d = 128 forward projection as the weight-stationary persistent kernel (same bits);
  * "wgrad_wgs", "loss_wgs" = workgroups of a full-size weight-gradient launch / the loss sweep (default 256 = one per CU; set
  * before plans are created); "sparse_bits_rows" = operand rows from which a plan keeps the bitmaps of the sparsity-aware backward hops
- * (default 100000); "wgrad_variant" = 1 (default) / 2 (operands through an LDS-DMA ring), "ppr_fused" = 1 (default) / 0 (separate update
- * pass of the diffusion profiles); "gemm_rows_split" = 1 (default) / 0: the forward projection over a short row list (lazy step)
- * by four waves per 16 rows that split the features / by one wave; "lazy_halo" = -1 (default: graphs of >= 262,144 nodes) / 0 / 1: sharded plans fetch subsets of the
- * boundary rows where a hop reads a subset (gss_plan_lazy_halo_rows; every rank of a job must use the same value), "lazy_halo_u" = -1 / 0 / 1 the same for u in the second backward hop (see gss_plan_lazy_halo_rows); "halo_recompute" = -1 (default: on) / 0 / 1: sharded plans recompute layer 2's boundary input rows from layer 1's constant AX / AM (fetched once)
- * instead of exchanging them every step (same bits; every rank of a job must use the same value); "loss_dgrad" = -1 (default: on shards only) / 0 / 1: the
+ * (default 100000); "ppr_fused" = 1 (default) / 0 (separate update pass of the diffusion profiles);
+ * "lazy_halo" = -1 (default: graphs of >= 262,144 nodes, but never over RCCL, where it stays opt-in) / 0 / 1: sharded plans fetch subsets of the
+ * boundary rows where a hop reads a subset (gss_plan_lazy_halo_rows), "lazy_halo_u" = -1 / 0 / 1 the same for u in the second backward hop (see gss_plan_lazy_halo_rows); "halo_recompute" = -1 (default: on) / 0 / 1: sharded plans recompute layer 2's boundary input rows from layer 1's constant AX / AM (fetched once)
+ * instead of exchanging them every step (same bits); "loss_dgrad" = -1 (default: on shards only) / 0 / 1: the
  * loss finish and the batch rows' input gradient in one launch instead of two (same bits; on a shard it spares a collective); "prep_side" = 1 (default) / 0: on one GPU a step's batch preparation rides in its
  * first forward SpMM launch and E_B comes out of the top layer's projection (no batch_prepare / gather launch; same bits);
- * "spmm_pair" = 1 (default) / 0: lane groups of <= 16 lanes (XCD-pinned 256-B slices) take their (col, val) pairs two per lane and trip, whole-line
- * index loads (same bits);
- * "gemm_lines" = 1 (default) / 0: projections without a row list read and write their epilogue in whole 128-B cache lines (the lanes of an
- * even / odd node pair swap feature blocks first; same bits); "wgrad_deep" = 2 (default) / 1 / 0: the weight-gradient reduce fetches its partial slabs
- * sixteen / eight / four at a time and requests Adam's state first (same bits); "gemm_hoist" = 1 (default) / 0: the forward projection
- * requests its epilogue operands ahead of the K loop (same bits);
+ * JOB-WIDE knobs -- "lazy_halo", "lazy_halo_u", "halo_recompute", "loss_slab" -- must have the same value on every rank:
+ * gss_plan_create_sharded compares them across the ranks (one all-reduce of min / max) and fails by name when they differ;
  * "loss_slab" = -1 (default: batches of >= 8192
  * rows) / 0 / 1: sharded plans sweep the B x B loss as row slabs (rank r the i tiles r, r + P, ...; one more all-reduce of B d + 1
  * floats) instead of replicating it on every rank (every rank of a job must use the same value; results agree to rounding).  Every setting computes the same results (some in a different summation order); the defaults are

@@ -81,3 +81,28 @@ def test_workspace_bounds_cover_every_shorter_batch(lib):
             assert cap == max(sizes)
     # the case that motivated it: the tail batch of N = 29,960 at B = 2048, and one just below B
     assert lib.gss_loss_workspace_bytes(2032, 128) > lib.gss_loss_workspace_bytes(2048, 128)
+
+
+def test_library_carries_the_hashes_of_the_sources_in_the_tree(lib):
+    """gss_source_hash: the library a test run (and the GPU box) loads was built from exactly the sources in this tree -- a stale .so with
+    fresh timestamps is caught here and rebuilt by __graft_entry__.build(); evidence files record these hashes (bench.py compares)"""
+    import gcn_drug_repurposing_amd as pkg
+    want = pkg._lib.source_hashes()
+    assert {"spmm.hip", "dense.hip", "plan.hip", "common.h", "gssgcn.h", "*"} <= set(want)
+    for name, h in want.items():
+        got = lib.gss_source_hash(name.encode())
+        assert got is not None and got.decode() == h, f"{name}: the library was built from another version of this file; run __graft_entry__.build()"
+    assert lib.gss_source_hash(None).decode() == want["*"]
+    assert lib.gss_source_hash(b"no_such_file.hip") is None
+    assert pkg._lib.library_is_current()
+
+
+def test_removed_knobs_are_refused_by_name(lib):
+    """round 6 pruned the access-shape knobs: 17 remain, the removed names are errors, not silent no-ops"""
+    for name in ("gemm_ws_mode", "gemm_ws_stagger", "gemm_ws_wgs", "wgrad_variant", "spmm_fly", "gemm_small_nt", "gemm_nt_cap",
+                 "gemm_lines", "gemm_hoist", "gemm_rows_split", "wgrad_deep", "spmm_pair", "xcd_remap"):
+        assert lib.gss_debug_set_option(name.encode(), 1) != 0, name
+        assert name in lib.gss_last_error().decode()
+    text = open(os.path.join(ROOT, "gcn-drug-repurposing_amd", "csrc", "common.h")).read()
+    body = text[text.index("struct Knobs {"):text.index("};", text.index("struct Knobs {"))]
+    assert len(re.findall(r"^  int \w+ = ", body, flags=re.M)) <= 20

@@ -261,8 +261,9 @@ def test_config5_rmat_500k_10m_properties_and_step_vs_cpu_port(rmat_mid):
 
 def test_config5_rmat_10m_200m_full_size_sampled_rows():
     """BASELINE config 5 at FULL size on one GPU (the device row source builds it in ~20 s): exactly 210M stored entries, SpMM
-    adjointness over the whole graph, and a sample of rows of A_hat's row sums, of AX = A_hat X and of the first layer's P
-    recomputed on the host in fp64 from the device's own CSR rows (a full host oracle at this size would take minutes)."""
+    adjointness over the whole graph, and a sample of rows of A_hat's row sums, of AX = A_hat X, of AM = A_hat (AX (.) X) (a dozen of them over
+    both hops from X alone) and of the first layer's P recomputed on the host in fp64 from the device's own CSR rows (a full host oracle at
+    this size would take minutes); the four weight gradients against an fp64 re-summation of the plan's own dP / AX / AM over all 10M rows."""
     from gcn_drug_repurposing_amd import _lib
     from gcn_drug_repurposing_amd.dist import local_comms
     from gcn_drug_repurposing_amd.shards import RmatSource, build_shard, gaussian_rows, shard_engine
@@ -311,6 +312,55 @@ def test_config5_rmat_10m_200m_full_size_sampled_rows():
         ref_p = got_ax @ w1.T + AM[r].cpu().numpy().astype(np.float64) @ w2.T
         worst = max(worst, np.abs(P[r].cpu().numpy() - ref_p).max() / max(1.0, np.abs(ref_p).max()))
     assert worst < 1e-5
+    # (round 6) the SECOND hop at full size: AM = A_hat (AX (.) X), modules/model.py:168-169.
+    #  (i) every sampled row from the device's AX rows of its neighbours (M = AX (.) X in fp32 as the kernel's epilogue forms it, the sum in fp64);
+    #  (ii) a dozen rows from X ALONE: both hops recomputed in fp64 on the host from the device's CSR rows (the neighbours' rows included)
+    Xd = eng.x
+    worst_am = 0.0
+    for r in rows:
+        e0, e1 = int(rp[r]), int(rp[r + 1])
+        c = col[e0:e1].long()
+        v = val[e0:e1].cpu().numpy().astype(np.float64)
+        m_rows = (AX[c] * Xd[c]).cpu().numpy().astype(np.float64)
+        ref_am = v @ m_rows
+        worst_am = max(worst_am, np.abs(AM[r].cpu().numpy() - ref_am).max() / max(1.0, np.abs(ref_am).max()))
+    assert worst_am < 1e-5, worst_am
+    two_hop = [int(r) for r in rows if rp[r + 1] - rp[r] <= 64][::max(1, len(rows) // 12)][:12]
+    assert len(two_hop) >= 8
+    worst_2 = 0.0
+    for r in two_hop:
+        e0, e1 = int(rp[r]), int(rp[r + 1])
+        c = col[e0:e1].cpu().numpy().astype(np.int64)
+        v = val[e0:e1].cpu().numpy().astype(np.float64)
+        ref_am = np.zeros(d)
+        for cj, vj in zip(c, v):
+            f0, f1 = int(rp[cj]), int(rp[cj + 1])
+            cc = col[f0:f1].cpu().numpy().astype(np.int64)
+            vv = val[f0:f1].cpu().numpy().astype(np.float64)
+            ax_c = vv @ X[cc].astype(np.float64)
+            ref_am += vj * (ax_c * X[cj].astype(np.float64))
+        worst_2 = max(worst_2, np.abs(AM[r].cpu().numpy() - ref_am).max() / max(1.0, np.abs(ref_am).max()))
+    assert worst_2 < 1e-5, worst_2
+    # the weight gradients at full size (train.py:183): dW1 = dP_top^T AX_1[batch rows] + dP_0^T AX_0 (dW2 with AM, db = column sums of both dP),
+    # recomputed in fp64 from the plan's own dP / AX / AM buffers in chunks of 1M rows (torch on the device as an independent summation):
+    # checks the 10M-row reductions of wgrad_tn_kernel + wgrad_reduce_kernel, which the 500k case does not reach
+    del AX, AM, P
+    dP0 = eng.activation(0, "dP")
+    dPb = eng.activation(0, "dP_batch")[:B].double()
+    brow = eng.node_map.long()[torch.from_numpy(idx).cuda().long()]
+    ref_w1 = dPb.t() @ eng.activation(L - 1, "AX")[brow].double()
+    ref_w2 = dPb.t() @ eng.activation(L - 1, "AM")[brow].double()
+    ref_b = dPb.sum(0)
+    for which, acc in (("AX", ref_w1), ("AM", ref_w2)):
+        Z = eng.activation(0, which)
+        for s0 in range(0, n, 1 << 20):
+            acc += dP0[s0:s0 + (1 << 20)].double().t() @ Z[s0:s0 + (1 << 20)].double()
+        del Z
+    for s0 in range(0, n, 1 << 20):
+        ref_b += dP0[s0:s0 + (1 << 20)].double().sum(0)
+    for got, ref, name in ((eng.grads[0], ref_w1, "dW1"), (eng.grads[2], ref_w2, "dW2"), (eng.grads[1], ref_b, "db1"), (eng.grads[3], ref_b, "db2")):
+        err = (got.double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+        assert err < 1e-5, (name, err)
     # row sums of A_hat of the sampled rows against D^-1/2 (A + I) D^-1/2 recomputed from the unit-weight structure
     deg = np.diff(rp).astype(np.float64)                                             # row sums of A + I (unit weights)
     for r in rows[::8]:

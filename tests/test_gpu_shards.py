@@ -633,3 +633,60 @@ def test_knn_row_source_builds_the_rows_of_the_reference_graph(world, relabel):
     [t.join(300) for t in ts]
     assert not errors, errors
     assert done[0] == world
+
+
+def test_a_rank_whose_job_wide_knob_differs_is_refused_by_name():
+    """lazy_halo / lazy_halo_u / halo_recompute / loss_slab decide WHICH collectives a step enqueues; ranks that
+    disagree would wait for each other in different collectives.  gss_plan_create_sharded compares them over the job's communicator and
+    fails on every rank, naming the knob -- world 3 as threads: rank 0's plan snapshots halo_recompute = 0 and waits in the all-gather,
+    then the process default goes back to -1 and ranks 1, 2 create theirs."""
+    import time
+    import gcn_drug_repurposing_amd as pkg
+    from gcn_drug_repurposing_amd.dist import local_comms
+    from gcn_drug_repurposing_amd.shards import ScipySource, build_shard, shard_engine, shard_rows
+    lib = pkg.load()
+    g = load_golden("edge_n600_d128_L2")
+    adj = golden_csr(g, "A")
+    n, d = adj.shape[0], 128
+    X = np.random.RandomState(0).randn(n, d).astype(np.float32)
+    np.random.seed(3)
+    p0 = O.init_layer_weights(d, 1e-2)
+    world = 3
+    comms = local_comms(world)
+    shards = _threaded(world, lambda rank: build_shard(ScipySource(adj), comms[rank], need_transpose=True, device="cuda:0"), comms)
+    errors, started = [None] * world, threading.Event()
+
+    def create(rank):
+        torch.cuda.set_device(0)
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                if rank == 0:
+                    started.set()
+                shard_engine(shards[rank], shard_rows(shards[rank], X), p0, comms[rank], num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-3, max_batch=64)
+        except Exception as e:  # noqa: BLE001
+            errors[rank] = str(e)
+
+    try:
+        assert lib.gss_debug_set_option(b"halo_recompute", 0) == 0
+        t0 = threading.Thread(target=create, args=(0,))
+        t0.start()
+        started.wait(60)
+        time.sleep(3.0)              # rank 0 has taken its snapshot (the first thing plan creation does) and waits for its peers
+    finally:
+        assert lib.gss_debug_set_option(b"halo_recompute", -1) == 0
+    rest = [threading.Thread(target=create, args=(r,)) for r in (1, 2)]
+    [t.start() for t in rest]
+    [t.join(300) for t in [t0] + rest]
+    assert all(e is not None for e in errors), errors
+    assert all("halo_recompute" in e and "same value on every rank" in e for e in errors), errors
+    # the same job with agreeing knobs still builds and steps
+    comms2 = local_comms(world)
+    shards2 = _threaded(world, lambda rank: build_shard(ScipySource(adj), comms2[rank], need_transpose=True, device="cuda:0"), comms2)
+
+    def ok(rank):
+        eng = shard_engine(shards2[rank], shard_rows(shards2[rank], X), p0, comms2[rank], num_layers=2, layer_decay=0.3, alpha=1.0, lr=1e-3, max_batch=64)
+        eng.step(torch.from_numpy(np.arange(64, dtype=np.int32)).cuda(), 0.2)
+        return eng.loss.item()
+
+    losses = _threaded(world, ok, comms2)
+    assert len(set(losses)) == 1 and np.isfinite(losses[0])

@@ -29,8 +29,18 @@ from gcn_drug_repurposing_amd.dist import local_comms  # noqa: E402
 from gcn_drug_repurposing_amd.shards import RmatSource, ScipySource, build_shard, gaussian_rows, shard_engine  # noqa: E402
 
 XGMI_LINK_GBS = 153.0
-LATENCY_US = 25.0      # ASSUMED cost of one collective between devices beyond its bytes (launch + rendezvous); no 2-device run exists to measure it
-KERNEL_CLASSES = ("spmm_fwd_hadamard", "spmm_fwd", "spmm_bwd1", "spmm_bwd2", "dense_fwd", "dgrad", "wgrad", "wgrad_batch", "loss", "elementwise", "rownorm", "adam")
+# cost of one collective between devices beyond its bytes.  Round 6: MEASURED on the box's one real RCCL rank (tools/rccl_world1_latency.py ->
+# profiles/r06_rccl_world1_latency.json): the device-side bracket around one all-reduce / one grouped exchange of a world-1 communicator on the
+# caller's stream -- a LOWER BOUND (no peer, no rendezvous, no link latency).  Without that file: the 25 us rounds 4-5 assumed.
+LATENCY_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_rccl_world1_latency.json")
+if os.path.exists(LATENCY_FILE):
+    _lat = json.load(open(LATENCY_FILE))["per_collective_floor_us"]
+    LATENCY_US = {"exchange": float(_lat["exchange"]), "allreduce": float(_lat["allreduce"])}
+    LATENCY_SOURCE = "measured: world-1 RCCL communicator on one MI355X, device-side bracket per collective (profiles/r06_rccl_world1_latency.json) -- a lower bound"
+else:
+    LATENCY_US = {"exchange": 25.0, "allreduce": 25.0}
+    LATENCY_SOURCE = "ASSUMED 25 us per collective (no measurement on file)"
+KERNEL_CLASSES = ("spmm_fwd_hadamard", "spmm_fwd", "spmm_bwd1", "spmm_bwd2", "spmm_bwd1_dense", "spmm_bwd2_dense", "dense_fwd", "dgrad", "wgrad", "wgrad_batch", "loss", "elementwise", "rownorm", "adam")
 
 ap = argparse.ArgumentParser()
 ap.add_argument("workload")
@@ -40,12 +50,16 @@ ap.add_argument("--layers", type=int, default=2)
 ap.add_argument("--batch", type=int, default=2048)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--rccl-default", type=int, default=1)
+ap.add_argument("--lazy-halo", type=int, default=None, help="knob lazy_halo (over RCCL the subset exchange of the lazy step is opt-in: --rccl-default 1 sets 0 unless this says 1)")
 ap.add_argument("--cache-layer1", type=int, default=0, help="1: the plans keep layer 1's two SpMM results (their inputs are constants) -- what train.py runs; its lazy step is then the trainer's step")
 ap.add_argument("--row-weight", type=int, default=None, help="the partition's cost of a row besides its entries (default: shards.row_weight_for(d, layers), what train.py and bench.py pass)")
 args = ap.parse_args()
 lib = pkg.load()
 if args.rccl_default:
     assert lib.gss_debug_set_option(b"lazy_halo_u", 0) == 0
+    assert lib.gss_debug_set_option(b"lazy_halo", 1 if args.lazy_halo == 1 else 0) == 0     # (an RCCL job's default since round 6: off unless asked for)
+elif args.lazy_halo is not None:
+    assert lib.gss_debug_set_option(b"lazy_halo", args.lazy_halo) == 0
 d, L, B = args.d, args.layers, args.batch
 
 if args.workload.startswith("rmat:"):
@@ -179,9 +193,9 @@ def floor_us(bytes_in, rows_total, max_pair_rows):
 
 from gcn_drug_repurposing_amd.shards import row_weight_for as _rwf  # noqa: E402
 res = {"workload": args.workload, "n": n, "d": d, "layers": L, "batch": B, "reps": args.reps, "cache_layer1": bool(args.cache_layer1), "row_weight": _rwf(d, L) if args.row_weight is None else args.row_weight, "rccl_default_knobs": bool(args.rccl_default),
-       "assumed_latency_us_per_collective": LATENCY_US, "xgmi_link_GBs": XGMI_LINK_GBS,
+       "latency_us_per_collective": LATENCY_US, "latency_source": LATENCY_SOURCE, "lazy_halo": args.lazy_halo, "xgmi_link_GBs": XGMI_LINK_GBS,
        "what_this_is": "a FORECAST from per-rank kernel times measured with each rank alone on ONE MI355X (recorded exchange payloads replayed by device "
-                       "copies) + collectives priced at the xGMI floor of their most loaded pair + an ASSUMED latency per collective; no two-device run exists",
+                       "copies) + collectives priced at the xGMI floor of their most loaded pair + a per-collective latency (see latency_source); no two-device run exists",
        "worlds": {}}
 fit_rows = []
 for world in [int(v) for v in args.worlds.split(",")]:
@@ -199,7 +213,9 @@ for world in [int(v) for v in args.worlds.split(",")]:
         # latency: per COLLECTIVE the plan enqueued (gss_plan_comm_stats; the four weight gradients are one fused all-reduce but four
         # deliveries in the log), + the request phase's bitmap exchange where the lazy step's subset exchange is on
         n_launch = max(sum(r[f"collectives_{kind}"]) for r in ranks)
-        comm_us = sum(c["xgmi_floor_us"] for c in coll) + (LATENCY_US * n_launch if world > 1 else 0.0)
+        n_exch = max(r[f"collectives_{kind}"][0] for r in ranks)            # (boundary-row exchanges, batch all-reduces, weight-gradient all-reduces)
+        lat_us = LATENCY_US["exchange"] * n_exch + LATENCY_US["allreduce"] * (n_launch - n_exch)
+        comm_us = sum(c["xgmi_floor_us"] for c in coll) + (lat_us if world > 1 else 0.0)
         entry[kind] = {"kernel_ms_by_rank": kt.round(4).tolist(), "critical_rank": int(kt.argmax()), "kernel_ms_max": round(float(kt.max()), 4),
                        "kernel_ms_mean": round(float(kt.mean()), 4), "imbalance_max_over_mean": round(float(kt.max() / kt.mean()), 3),
                        "collectives": coll, "collectives_enqueued": n_launch, "collectives_us_at_floor_plus_latency": round(comm_us, 1),
