@@ -704,7 +704,9 @@ def main():
                                                "rank's stream (pack kernel + transfer for an exchange), the wait for the slowest peer included"}
         syncs = engine.sync_stats() if hasattr(engine, "sync_stats") else (0, 0)
         out["host_syncs_per_step"] = {"stream_drains": syncs[0] / args.steps, "request_stream_event_waits": syncs[1] / args.steps,
-                                      "note": "gss_plan_sync_stats over the profiled (full) steps: host waits that drain the caller's stream (the "
+                                      "note": "(counts the plan's own waits; a host-side backend -- in-process, host-staged -- also synchronises inside every collective, so "
+                                              "zero here means 'no drain' only over a device transport = RCCL) "
+                                              "gss_plan_sync_stats over the profiled (full) steps: host waits that drain the caller's stream (the "
                                               "sender-driven subset exchange of u, knob lazy_halo_u: off over RCCL) / host waits for an event of the "
                                               "plan's request stream while the caller's stream keeps running (the lazy step's subset exchange of M)"}
         mine = [own_ms_per_step, comm_ms, halo_bytes_a, halo_bytes_t, pair_a, pair_t, out["roofline"]["frac"] if out["roofline"] else 0.0,

@@ -875,6 +875,11 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
         // two-column-tile form it replaces (256 registers, one wave per SIMD), which is why this is all it buys.
         dim3 gridn(ceil_div(g.n, 128), 1);
         const size_t ldsn = 4 * (size_t)(128 * 16 + 256 * 16) * sizeof(float);
+        if (K().gemm_variant == 6) {   // EXPERIMENT (round 6): the same tile as eight waves of 16 nodes -- two waves per SIMD
+          hipLaunchKernelGGL((gemm_nt_lds_kernel<16, 1, EPI_FWD_NORM, 8, false, true, 2>), gridn, dim3(512), lds_request(gemm_nt_lds_kernel<16, 1, EPI_FWD_NORM, 8, false, true, 2>, ldsn), st, g);
+          GSS_LAUNCH_CHECK("gemm_nt_lds_kernel (256 features, fused row norm, 8 waves)");
+          return GSS_OK;
+        }
         hipLaunchKernelGGL((gemm_nt_lds_kernel<16, 2, EPI_FWD_NORM, 4, false, true>), gridn, dim3(256), lds_request(gemm_nt_lds_kernel<16, 2, EPI_FWD_NORM, 4, false, true>, ldsn), st, g);
         GSS_LAUNCH_CHECK("gemm_nt_lds_kernel (256 features, fused row norm)");
         return GSS_OK;

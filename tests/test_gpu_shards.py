@@ -462,7 +462,10 @@ def test_lazy_halo_fetches_only_what_the_batch_rows_read(world, case, relabel, s
     rows fetched is exactly the number of distinct boundary columns of the owned batch rows, and what the ranks fetch in total is
     what they send in total.  Round 5: the request phase of M's exchange runs ahead on the plan's request stream -- the host waits for
     its event, never for the caller's stream (gss_plan_sync_stats: no drain); u's sender-driven exchange still drains once per step, and
-    with lazy_halo_u = 0 -- what an RCCL job gets by default -- a step drains nothing at all, with the same bits."""
+    with lazy_halo_u = 0 a step's PLAN CODE drains nothing at all, with the same bits.  (gss_plan_sync_stats counts the plan's own
+    comm->sync calls.  The in-process backend used here also synchronises inside every collective -- exchange_rows on the request stream
+    waits for ev_rq_in, i.e. for the caller's stream -- so the "no drain" property is a property of DEVICE transports (RCCL), which this
+    counter can assert but this backend cannot exhibit)  Since round 6 the subset exchange is opt-in over RCCL."""
     import gcn_drug_repurposing_amd as pkg
     from gcn_drug_repurposing_amd.dist import local_comms
     from gcn_drug_repurposing_amd.shards import ScipySource, build_shard, shard_engine, shard_rows

@@ -31,24 +31,19 @@ for n in [int(v) for v in (sys.argv[1:] or ["29960", "250000", "1000000"])]:
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps * 1e3
     reps = 50 if n < 200000 else 8
-    cfgs = [("staged tiles (gemm_ws=0)", dict(gemm_ws=0)),
-            ("weight-stationary 512 wgs, stagger 4", dict(gemm_ws=1, gemm_ws_wgs=512, gemm_ws_stagger=4)),
-            ("weight-stationary 512 wgs, stagger 0", dict(gemm_ws=1, gemm_ws_wgs=512, gemm_ws_stagger=0)),
-            ("weight-stationary 512 wgs, stagger 2", dict(gemm_ws=1, gemm_ws_wgs=512, gemm_ws_stagger=2)),
-            ("weight-stationary 512 wgs, stagger 6", dict(gemm_ws=1, gemm_ws_wgs=512, gemm_ws_stagger=6)),
-            ("weight-stationary 512 wgs, stagger 8", dict(gemm_ws=1, gemm_ws_wgs=512, gemm_ws_stagger=8)),
-            ("weight-stationary 256 wgs", dict(gemm_ws=1, gemm_ws_wgs=256, gemm_ws_stagger=0)),
-            ("weight-stationary 768 wgs, stagger 4", dict(gemm_ws=1, gemm_ws_wgs=768, gemm_ws_stagger=4))]
+    # (round 6: the kernel's workgroup count, stagger and weight-fetch mode are constants now -- 512 / 4 / per-row loads after an L2 warm-up,
+    #  the optima of the round-5 sweep in profiles/r05_proj_ws_bench.txt)
+    cfgs = [("staged tiles (gemm_ws=0)", dict(gemm_ws=0)), ("weight-stationary (gemm_ws=1)", dict(gemm_ws=1))]
     res, ref = {}, None
     for rnd in range(4):
         for name, kw in cfgs:
-            setk(**{**dict(gemm_ws_mode=1), **kw})
+            setk(**kw)
             res.setdefault(name, []).append(timed(reps))
             if ref is None:
                 ref = (p.clone(), xn.clone())
             else:
                 assert torch.equal(p, ref[0]) and torch.equal(xn, ref[1]), f"{name}: bits differ"
-    setk(gemm_ws=-1, gemm_ws_wgs=512, gemm_ws_stagger=4, gemm_ws_mode=1)
+    setk(gemm_ws=-1)
     fl = 2.0 * n * 2 * d * d
     for name, ts in res.items():
         us = min(ts)

@@ -15,7 +15,6 @@ assert lib.gss_debug_set_option(b"gemm_ws", 1) == 0      # the stamps below are 
 for kv in sys.argv[2:]:
     k, v = kv.split("=")
     assert lib.gss_debug_set_option(k.encode(), int(v)) == 0, kv
-    if k == "gemm_ws_wgs": wgs = int(v)
 print("knobs:", sys.argv[2:])
 ax, am, pp = (torch.randn(n, d, device="cuda") for _ in range(3))
 w1, w2 = (torch.randn(d, d, device="cuda") * 0.05 for _ in range(2))

@@ -76,13 +76,14 @@ for name, fn in cases.items():
     print(f"{name:48s} enqueue -> completion {np.median(wall):7.1f} us (median; p10 {np.percentile(wall, 10):.1f}, p90 {np.percentile(wall, 90):.1f})   "
           f"device bracket {np.median(dev):7.1f} us   back to back {b2b:7.1f} us per call", flush=True)
 ref = res["trivial_kernel_for_reference"]["enqueue_to_completion_us"]["median"]
-floor = {k: max(0.0, v["device_event_bracket_us"]["median"]) for k, v in res.items() if k != "trivial_kernel_for_reference"}
+floor = {k: v["back_to_back_us_per_call"] for k, v in res.items() if k != "trivial_kernel_for_reference"}
 summary = {"what": "world-1 RCCL communicator on one MI355X: a LOWER BOUND of the per-collective cost between devices (no peer, no rendezvous, no link)",
            "d": d, "B": B, "rccl_ranks": comm.count(), "cases": res,
            "per_collective_floor_us": {"allreduce": max(v for k, v in floor.items() if k.startswith("allreduce")),
                                        "exchange": floor["exchange_rows_empty_group"]},
-           "note": "per_collective_floor_us = the device-side event bracket around one collective on the caller's stream (what it adds to a step whose "
-                   "kernels are enqueued back to back); enqueue_to_completion includes the host's own launch + wait (trivial kernel: %.1f us)" % ref}
+           "note": "per_collective_floor_us = what one collective adds to a stream of enqueued work at world 1 (back-to-back rate; the event bracket around a single "
+                   "call is dominated by the bracket's own cost: see the trivial kernel).  enqueue_to_completion includes the host's launch + wait (trivial kernel: "
+                   "%.1f us).  A collective between devices adds a rendezvous and a link round trip on top, which a one-GPU box cannot measure." % ref}
 print(json.dumps(summary))
 if out_json:
     json.dump(summary, open(out_json, "w"), indent=1)

@@ -216,10 +216,12 @@ for world in [int(v) for v in args.worlds.split(",")]:
         n_exch = max(r[f"collectives_{kind}"][0] for r in ranks)            # (boundary-row exchanges, batch all-reduces, weight-gradient all-reduces)
         lat_us = LATENCY_US["exchange"] * n_exch + LATENCY_US["allreduce"] * (n_launch - n_exch)
         comm_us = sum(c["xgmi_floor_us"] for c in coll) + (lat_us if world > 1 else 0.0)
+        comm_us_25 = sum(c["xgmi_floor_us"] for c in coll) + (25.0 * n_launch if world > 1 else 0.0)   # the constant rounds 4-5 assumed, for comparison
         entry[kind] = {"kernel_ms_by_rank": kt.round(4).tolist(), "critical_rank": int(kt.argmax()), "kernel_ms_max": round(float(kt.max()), 4),
                        "kernel_ms_mean": round(float(kt.mean()), 4), "imbalance_max_over_mean": round(float(kt.max() / kt.mean()), 3),
                        "collectives": coll, "collectives_enqueued": n_launch, "collectives_us_at_floor_plus_latency": round(comm_us, 1),
-                       "forecast_ms_per_step_no_overlap": round(float(kt.max()) + comm_us * 1e-3, 4)}
+                       "forecast_ms_per_step_no_overlap": round(float(kt.max()) + comm_us * 1e-3, 4),
+                       "forecast_ms_per_step_at_25us_per_collective": round(float(kt.max()) + comm_us_25 * 1e-3, 4)}
     res["worlds"][str(world)] = entry
     for r in ranks:
         boundary = r["halo_rows_a"] if L > 1 and world > 1 else 0

@@ -74,13 +74,11 @@ for h in (4096, 8192, 16384, 65536, 262144, 500000):
     bench(hub, xp, f"hub-first + cold rows non-temporal, H = {h} ({cs[h - 1].item():.2f} of the gathers hot)")
 lib.gss_debug_set_option(b"spmm_hot_rows", 0)
 # deeper gather queues and feature slicing on the relabelled graph
-for fly in (4, 8):
-    lib.gss_debug_set_option(b"spmm_fly", fly)
-    for ns in (1, 2, 4):
-        lib.gss_debug_set_option(b"spmm_slices", ns)
-        for h in (0, 65536):
-            lib.gss_debug_set_option(b"spmm_hot_rows", h)
-            bench(hub, xp, f"hub-first, {fly} gathers in flight, {ns} time-separated slice(s), H = {h}")
+# (8 gathers in flight -- knob spmm_fly, removed in round 6 -- measured 3-9 % slower here: profiles/r02_spmm_hot_cold_rmat10m.txt)
+for ns in (1, 2, 4):
+    lib.gss_debug_set_option(b"spmm_slices", ns)
+    for h in (0, 65536):
+        lib.gss_debug_set_option(b"spmm_hot_rows", h)
+        bench(hub, xp, f"hub-first, 4 gathers in flight, {ns} time-separated slice(s), H = {h}")
 lib.gss_debug_set_option(b"spmm_hot_rows", 0)
-lib.gss_debug_set_option(b"spmm_fly", 4)
 lib.gss_debug_set_option(b"spmm_slices", 0)
