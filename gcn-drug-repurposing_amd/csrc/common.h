@@ -19,7 +19,6 @@ constexpr int kWave = 64;
 struct Knobs {
   int spmm_variant = 2;      // 1 = row per wave, 2 = nnz-balanced segments (default; shards and the lazy step need it)
   int spmm_slices = 0;       // 0 = automatic feature slicing (launch_balanced)
-  int spmm_pre = 1;          // EXPERIMENT (round 6): the balanced SpMM requests its epilogue operands ahead of the gathers
   int spmm_pin = 0;          // with a manual spmm_slices: slices pinned to XCDs (1) or time-separated (0)
   int spmm_hot = -1;         // overrides every CSR's hot set with rows [0, value) (-1 = the CSR's own, 0 = none)
   int seg_edges = 32;        // entries per SpMM segment (CSR handles created afterwards)

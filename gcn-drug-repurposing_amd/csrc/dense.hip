@@ -848,6 +848,8 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
         return GSS_OK;
       }
     }
+    // (Measured, round 6: the N-row input gradient at d = 256 as 128 x 256 tiles of eight waves -- the shape that pays for the fused-norm
+    //  projection below -- is 1.0 us per step SLOWER than the 128 x 128 tiles of four waves: profiles/r06_ab_live_prefetch_and_norm8.txt.)
     dim3 grid(ceil_div(g.n, 64 * mt), g.J / (16 * nt));
     const size_t lds = 4 * (size_t)(64 * mt * 16 + 16 * nt * 16) * sizeof(float);
     if (g.stamps && EPI == EPI_FWD && nt == 8 && mt == 1) {   // diagnostic twin (tools/gemm_stamps.py): the d = 128 projection only
@@ -871,11 +873,12 @@ static int launch_gemm(const GemmArgs &g_in, int d, hipStream_t st) {
       if (nt == 16 && !g.rows) {
         // d = 256, last layer (round 5): 128-node tiles of ALL 256 features, so that F.normalize (and E_B) come out of the epilogue and the
         // stand-alone row normalisation -- a 12 us launch that re-reads and re-writes the [N][256] result -- and the E_B gather go away.
-        // Config 3: 21 -> 19 launches, 1.2396 -> 1.2312 ms per step (64-node tiles: 1.2394); the tile itself is 11 us slower than the
-        // two-column-tile form it replaces (256 registers, one wave per SIMD), which is why this is all it buys.
+        // Config 3: 21 -> 19 launches, 1.2396 -> 1.2312 ms per step.  Round 6: the tile runs as EIGHT waves of 16 nodes (206 registers, two
+        // waves per SIMD) instead of four waves of 32 (256 + 128 accumulation registers, one wave per SIMD): -8.2 us per step on one live
+        // plan (profiles/r06_ab_live_prefetch_and_norm8.txt), same MFMA order per output, same bits.  gemm_variant 3 forces the four-wave form.
         dim3 gridn(ceil_div(g.n, 128), 1);
         const size_t ldsn = 4 * (size_t)(128 * 16 + 256 * 16) * sizeof(float);
-        if (K().gemm_variant == 6) {   // EXPERIMENT (round 6): the same tile as eight waves of 16 nodes -- two waves per SIMD
+        if (K().gemm_variant != 3) {
           hipLaunchKernelGGL((gemm_nt_lds_kernel<16, 1, EPI_FWD_NORM, 8, false, true, 2>), gridn, dim3(512), lds_request(gemm_nt_lds_kernel<16, 1, EPI_FWD_NORM, 8, false, true, 2>, ldsn), st, g);
           GSS_LAUNCH_CHECK("gemm_nt_lds_kernel (256 features, fused row norm, 8 waves)");
           return GSS_OK;

@@ -53,7 +53,6 @@ struct SpmmEpi {
   int prep_block;               // prepares the batch (see BatchPrep) instead of multiplying
   int pos_row_limit;            // SPMM_BWD2S / SPMM_BWD2, > 0: t, the residual and pos_row are defined for output rows below it only (a shard's
                                 // own rows; the rows behind them -- the boundary rows of the in-place transposed A_hat -- have none)
-  int pre_epi;                  // EXPERIMENT knob spmm_pre: epilogue operands requested ahead of the gathers
   const int32_t *row_alias;     // SPMM_PLAIN, optional (the chunk pass of GiantRows): the row filters (pos, rowbits) are looked up at
                                 // row_alias[row] -- the row a chunk belongs to -- instead of row
 };
@@ -125,16 +124,13 @@ __device__ __forceinline__ void row_accumulate(const CsrView &a, const float *__
 
 __device__ __forceinline__ bool is_zero4(const float4 &v) { return v.x == 0.f && v.y == 0.f && v.z == 0.f && v.w == 0.f; }
 
-// use_pre: pre0 / pre1 are the epilogue's streamed operands a0 / a1 at `off`, requested by the caller ahead of the row's gathers (FWD1: a0;
-// BWD2 / BWD2S: a0 = t unless t_zero, a1 = p) -- the values are the same, one dependent round trip leaves the row's chain
 template <int MODE>
-__device__ __forceinline__ void row_epilogue(const SpmmEpi &ep, size_t off, float4 acc, long coff = -1, bool t_zero = false, bool use_pre = false,
-                                             float4 pre0 = float4{0.f, 0.f, 0.f, 0.f}, float4 pre1 = float4{0.f, 0.f, 0.f, 0.f}) {
+__device__ __forceinline__ void row_epilogue(const SpmmEpi &ep, size_t off, float4 acc, long coff = -1, bool t_zero = false) {
   if (MODE == SPMM_PLAIN) {
     st4(ep.o0 + off, acc);
   } else if (MODE == SPMM_FWD1) {
     st4(ep.o0 + off, acc);
-    st4(ep.o1 + off, mul4(acc, use_pre ? pre0 : ld4(ep.a0 + off)));
+    st4(ep.o1 + off, mul4(acc, ld4(ep.a0 + off)));
   } else if (MODE == SPMM_BWD1) {
     // u = g_ax + dm (.) x_in ; t = dm (.) ax
     st4(ep.o0 + off, add4(ld4(ep.a0 + off), mul4(acc, ld4(ep.a1 + off))));
@@ -154,15 +150,15 @@ __device__ __forceinline__ void row_epilogue(const SpmmEpi &ep, size_t off, floa
   } else if (MODE == SPMM_BWD2S) {
     // as SPMM_BWD2 with the residual gradient held compactly on the batch rows (coff < 0: not a batch row)
     // t_zero: the caller knows t's row is zero (posbits); with a zero sum as well the row's gradient is the residual alone
-    const float4 gx = t_zero ? acc : add4(use_pre ? pre0 : ld4(ep.a0 + off), acc);
-    float4 dp = (t_zero && is_zero4(acc)) ? make_float4(0.f, 0.f, 0.f, 0.f) : scale4(ep.c, mul4(gx, elu_grad4(use_pre ? pre1 : ld4(ep.a1 + off))));
+    const float4 gx = t_zero ? acc : add4(ld4(ep.a0 + off), acc);
+    float4 dp = (t_zero && is_zero4(acc)) ? make_float4(0.f, 0.f, 0.f, 0.f) : scale4(ep.c, mul4(gx, elu_grad4(ld4(ep.a1 + off))));
     if (coff >= 0) dp = add4(dp, ld4(ep.a2 + coff));
     st4(ep.o0 + off, dp);
     if (ep.o1) st4(ep.o1 + off, gx);
   } else {
     // gx = t + A u ; dp = c * gx (.) elu'(p) (+ res)      (t_zero: a row behind pos_row_limit -- neither t nor a residual there)
-    const float4 gx = t_zero ? acc : add4(use_pre ? pre0 : ld4(ep.a0 + off), acc);
-    float4 dp = scale4(ep.c, mul4(gx, elu_grad4(use_pre ? pre1 : ld4(ep.a1 + off))));
+    const float4 gx = t_zero ? acc : add4(ld4(ep.a0 + off), acc);
+    float4 dp = scale4(ep.c, mul4(gx, elu_grad4(ld4(ep.a1 + off))));
     if (ep.a2 && !t_zero) dp = add4(dp, ld4(ep.a2 + off));
     st4(ep.o0 + off, dp);
     if (ep.o1) st4(ep.o1 + off, gx);
@@ -356,22 +352,10 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   float4 acc[VPL];
 #pragma unroll
   for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // (round 6) the streamed epilogue operands of a row that one wave sums -- the Hadamard operand of FWD1; t and p of the second backward
-  // hop -- are requested HERE, ahead of the row's gathers: they used to be the last dependent round trip of the row's chain (descriptor ->
-  // index -> 8 trips of gathers -> epilogue loads -> stores).  The lanes that will run the epilogue are known from the descriptor alone.
-  constexpr bool PRE = VPL == 1 && (MODE == SPMM_FWD1 || MODE == SPMM_BWD2 || MODE == SPMM_BWD2S);
-  float4 pre0 = make_float4(0.f, 0.f, 0.f, 0.f), pre1 = pre0;   // (two values, not an array: an indexed local goes to scratch)
-  const bool pre_tz = PRE && row >= 0 ? row_t_zero<MODE>(ep, row) : false;
-  // (BWD2S under a row bitmap: a row whose t is zero reads p only when its sum is not -- nearly never at RMAT scale -- and keeps the late load)
-  const bool pre_on = PRE && ep.pre_epi && row >= 0 && (1 << (sd.w & 0xff)) <= GPW && (g & ((1 << (sd.w & 0xff)) - 1)) == 0 && li < d4 &&
-                      !(MODE == SPMM_BWD2S && pre_tz);
-  if (PRE && ep.pre_epi) {
-    // branch-free: a lane that will not run the epilogue reads the head of row 0 (a few redundant L1 hits) -- inside a divergent branch the
-    // compiler waits for the load at the branch's end, which puts the round trip back in front of the gathers
-    const size_t poff = pre_on ? ((size_t)row * rs4 + slice_f4 + li) * 4 : (size_t)(li & 3) * 4;
-    pre0 = ld4(ep.a0 + poff);
-    if (MODE != SPMM_FWD1) pre1 = ld4(ep.a1 + poff);
-  }
+  // (Measured dead end, round 6: requesting the epilogue's streamed operands -- the Hadamard operand of FWD1, t and p of the second backward hop
+  //  -- HERE, ahead of the row's gathers, so that they are not the last dependent round trip of the row's chain: +0.2 us per step at config 2,
+  //  -1.1 us of 1,231 at config 3 on one live plan (profiles/r06_ab_live_prefetch_and_norm8.txt).  The kernel is bound by the rate at which the
+  //  L2s serve gathers, not by the length of a row's chain.)
   // one row gather of this lane group: slice of row cc of the operand, zeros when !ok
   auto gather_row = [&](int cc, bool ok, float4 (&dst)[VPL]) __attribute__((always_inline)) {
     if (NARROW) {
@@ -552,7 +536,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   }
   if (pcount <= GPW) {
     if (row >= 0 && (g & (pcount - 1)) == 0) {
-      bool tz = PRE ? pre_tz : row_t_zero<MODE>(ep, row);
+      bool tz = row_t_zero<MODE>(ep, row);
       if (ep.y_in) {   // the other pass's partial sums of this row (two-pass product)
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
@@ -571,7 +555,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
         const int f4 = li + v * 64;
         if (f4 < d4) {
           const long coff = compact_off<MODE>(ep, row, rs4, slice_f4 + f4);
-          row_epilogue<MODE>(ep, ((size_t)row * rs4 + slice_f4 + f4) * 4, acc[v], coff, tz, PRE && pre_on, pre0, pre1);
+          row_epilogue<MODE>(ep, ((size_t)row * rs4 + slice_f4 + f4) * 4, acc[v], coff, tz);
         }
       }
     }
@@ -681,7 +665,6 @@ static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool p
   SpmmEpi ep = ep_in;
   const bool prep = MODE == SPMM_FWD1 && ep.prep.idx != nullptr;
   ep.prep_block = 0;
-  ep.pre_epi = K().spmm_pre;
   const int extra = prep ? 1 : 0;             // the batch preparation rides as one more workgroup, the first of the launch
   int3 hot = make_int3(a->hot_own, a->hot_halo0, a->hot_halo1);
   if (K().spmm_hot >= 0) hot = K().spmm_hot > 0 ? make_int3(K().spmm_hot, 0, 0) : make_int3(-1, 0, 0);
