@@ -73,6 +73,15 @@ out = {"note": "rocprofv3 --pmc, one counter group per pass with --kernel-trace 
                "Infinity-Cache hits are counted, so 'traffic' is what leaves the L2s, not DRAM bytes.  Durations are under the profiler.",
        "correction": "MI355X_MICROARCH.md section HBM: FETCH_SIZE x 2 (128-B requests tallied at 64 B on gfx950), WRITE_SIZE exact, both in KB",
        "source_hash": hashes}
+# configurations whose passes are not under gpurun_out/pmc here (collected in another job) are kept from the existing file -- if, and only
+# if, it was taken with the same spmm.hip
+OUT_PATH = os.path.join(ROOT, "profiles", "r06_spmm_pmc.json")
+if os.path.exists(OUT_PATH):
+    old = json.load(open(OUT_PATH))
+    if old.get("source_hash", {}).get("spmm.hip") == hashes["spmm.hip"]:
+        for cfg in CFG:
+            if cfg in old:
+                out[cfg] = old[cfg]
 for cfg, (tag, n, nnz, d, b) in CFG.items():
     acc, dur = read(tag)
     res = {}
@@ -100,8 +109,8 @@ for cfg, (tag, n, nnz, d, b) in CFG.items():
             res[name] = case(c, us / REPS_RMAT, alg_bytes(name, n, nnz, d, b),
                              f"{cfg}: one product ({name}) = chunk pass + product + finish pass of the giant rows, summed (tools/spmm_two_pass.py), N = {n}, nnz = {nnz}, d = {d}")
     if res:
-        out[cfg] = res
-json.dump(out, open(os.path.join(ROOT, "profiles", "r06_spmm_pmc.json"), "w"), indent=1)
+        out[cfg] = {**out.get(cfg, {}), **res}
+json.dump(out, open(OUT_PATH, "w"), indent=1)
 for cfg in CFG:
     for name, c in out.get(cfg, {}).items():
         ratio = f"{c['traffic_over_alg']:.2f} x alg" if c.get("traffic_over_alg") else "(alg bytes per batch: bench.py)"
