@@ -126,7 +126,7 @@ int bits_compact(const uint32_t *words, int P, const int64_t *d_woff, const int6
 size_t bits_compact_scratch_bytes(int P, const int64_t *h_woff);   // what bits_compact needs as scratch for these word offsets
 int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,
                      const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream,
-                     const uint32_t *posbits = nullptr, uint32_t *nzbits_out = nullptr, int skip_zero_rows = 0);
+                     const uint32_t *posbits = nullptr, uint32_t *nzbits_out = nullptr, int skip_zero_rows = 0, const uint32_t *live_rows = nullptr);
 // bitmap companion of a batch-position map: set (value 1) or clear (value 0) the words of ids[0..b) (negative ids skipped)
 int batch_bits(const int32_t *ids, int32_t b, uint32_t *bits, int set, void *stream);
 bool spmm_sparse_available();

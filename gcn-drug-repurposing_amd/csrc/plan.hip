@@ -35,6 +35,7 @@ struct gss_plan {
   uint32_t *posbits;  // bitmap of pos >= 0, kept only around the sparse backward SpMM and only for huge operands (else NULL)
   std::vector<size_t> guard_off;   // slab offsets of the guards behind the carved buffers
   uint32_t *needbits; // huge operands only (else NULL): gss_plan_step_lazy -- the rows of the top layer's AX / M that anything reads (batch + neighbours)
+  bool needbits_valid = false;   // needbits holds the set of the batch the running step was given (plan_step_impl's forward or backward built it)
   uint32_t *nzbits;   // huge operands only (else NULL): bit r set <=> row r of u (the top layer's A_hat^T operand) may be non-zero; written by the
                       // sparse hop, read by the hop after it (which then skips the zero rows); halo rows are always set
   float *w1t, *w2t;
@@ -822,6 +823,7 @@ int plan_prefetch_layer1(gss_plan *p, void *main_stream) {
 // lazy_rows != NULL (gss_plan_step_lazy): the top layer's A_hat M, projection, ELU, residual and normalisation are evaluated on the
 // lazy_b listed rows only (p->pos is their row mask) -- the rows the loss and the backward pass read
 int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = nullptr, int32_t lazy_b = 0) {
+  if (p) p->needbits_valid = false;   // (set again below when this pass marks the batch rows and their neighbours)
   GSS_REQUIRE(p, "plan_forward: null plan");
   const gss_plan_desc &D = p->desc;
   const int L = D.num_layers;
@@ -861,6 +863,7 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
         if (int rc = mark_rows_and_neighbours(p->a, lazy_rows, lazy_b, p->needbits, stream)) return rc;
         if (needed_only)
           if (int rc = bits_set_list(p->needbits, p->lz.send_list, p->lz.h_cnt[p->P], stream)) return rc;
+        p->needbits_valid = p->P == 1 || needed_only;   // own rows: complete (a shard without the request phase does not know its peers' batch rows)
       }
       {
         const uint32_t *rbits = (lazy_l && p->needbits) ? p->needbits : nullptr;
@@ -1141,10 +1144,23 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
         PROF(GSS_PROF_ELEMENTWISE);
         GSS_HIP(hipMemsetAsync(p->nzbits, 0, sizeof(uint32_t) * nz_words, st));
       }
+      // (round 6) huge graphs: the hop walks only the rows that can have a hit -- the batch rows and their neighbours, the set the lazy
+      // step's forward marked for this batch; a full step on one GPU marks it here (b rows of A_hat: microseconds against the 2.7 ms the
+      // hop spent streaming RMAT 10M's index for 45 k hits).  Whole-step entry points only (the same batch as the forward's).
+      const uint32_t *live_rows = nullptr;
+      if (p->needbits && deferred_slices) {
+        if (!p->needbits_valid && p->P == 1) {
+          PROF(GSS_PROF_ELEMENTWISE);
+          GSS_HIP(hipMemsetAsync(p->needbits, 0, sizeof(uint32_t) * (p->rows_a / 32 + 1), st));
+          if (int rc = mark_rows_and_neighbours(p->a, bv.rows, b, p->needbits, stream)) return rc;
+          p->needbits_valid = true;
+        }
+        if (p->needbits_valid) live_rows = p->needbits;
+      }
       {
         PROF(GSS_PROF_SPMM_BWD1);
         if (int rc = spmm_bwd1_sparse(p->at, D.d, p->gam_b, p->gax_b, p->pos, pos_row, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream, p->posbits,
-                                      track_nz ? p->nzbits : nullptr, track_nz && p->P == 1))
+                                      track_nz ? p->nzbits : nullptr, track_nz && p->P == 1, live_rows))
           return rc;
       }
       if (p->posbits) {

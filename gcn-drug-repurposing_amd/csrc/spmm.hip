@@ -49,6 +49,10 @@ struct SpmmEpi {
                                 // first pass of a two-pass SPMM_BWD2S, whose second pass carries the same bitmap as posbits)
   const uint32_t *rowbits;      // SPMM_PLAIN, optional: only rows whose bit is set are computed (the first pass of a two-pass SPMM_FWD1
                                 // under a row bitmap, whose second pass carries the same bitmap as posbits)
+                                // SPMM_BWD1S, optional (round 6): bit r set <=> row r is a batch row or a neighbour of one (the set the lazy
+                                // step's forward already marks).  A row whose bit is clear has no entry that can hit: its segments are not
+                                // walked (at RMAT 10M the hop streamed 1.68 GB of index to find 45 k entries); it is written as zeros, or
+                                // not at all under skip_zero_rows -- exactly what the walk would have produced
   BatchPrep prep;               // SPMM_FWD1, prep.idx != NULL: the launch has one workgroup more than segment blocks -- its first --, which
   int prep_block;               // prepares the batch (see BatchPrep) instead of multiplying
   int pos_row_limit;            // SPMM_BWD2S / SPMM_BWD2, > 0: t, the residual and pos_row are defined for output rows below it only (a shard's
@@ -335,6 +339,10 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   }
   if (MODE == SPMM_PLAIN && ep.rowbits && row >= 0 && !((ep.rowbits[(unsigned)frow >> 5] >> (frow & 31)) & 1u)) {
     row = -1;
+    e1 = e0;
+  }
+  if (MODE == SPMM_BWD1S && ep.rowbits && row >= 0 && !((ep.rowbits[(unsigned)row >> 5] >> (row & 31)) & 1u)) {
+    if (ep.skip_zero_rows && ep.nzbits_out) row = -1;   // (a single shard does not even write its dead rows: their clear bit in nzbits_out says so)
     e1 = e0;
   }
   const int plog = sd.w & 0xff;
@@ -955,11 +963,12 @@ int spmm_bwd1(const gss_csr *at, int32_t d, const float *g_am, const float *g_ax
 
 int spmm_bwd1_sparse(const gss_csr *at, int32_t d, const float *g_am_b, const float *g_ax_b, const int32_t *pos,
                      const int32_t *pos_row, const float *x_in, const float *ax, float *u, float *t, void *stream, const uint32_t *posbits,
-                     uint32_t *nzbits_out, int skip_zero_rows) {
+                     uint32_t *nzbits_out, int skip_zero_rows, const uint32_t *live_rows) {
   GSS_REQUIRE(g_am_b && g_ax_b && pos && pos_row && x_in && ax && u && t, "spmm_bwd1_sparse: null operand");
   GSS_REQUIRE(K().spmm_variant == 2, "spmm_bwd1_sparse needs the balanced SpMM (spmm_variant 2)");
   GSS_REQUIRE(!skip_zero_rows || nzbits_out, "spmm_bwd1_sparse: skipping the zero rows needs the bitmap that records them");
   SpmmEpi ep{g_ax_b, x_in, ax, u, t, 0.f, pos, pos_row, posbits, nzbits_out, skip_zero_rows};
+  ep.rowbits = live_rows;
   return launch_spmm<SPMM_BWD1S>(at, d, g_am_b, ep, stream);
 }
 

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """profiles/r06_scaling_forecast_*.json (tools/forecast_r06.sh -> tools/scaling_forecast.py) -> the markdown table of DESIGN.md section 8.
-usage: forecast_table.py <label>=<file> ..."""
+usage: forecast_table.py "<label>::<file>" ..."""
 import json
 import sys
 
 print("| config | step | world | slowest rank's kernels, ms | slowest / mean | collectives | forecast ms per step: collectives at the measured world-1 floor | ... at 25 µs each | vs world 1 (floor / 25 µs) |")
 print("|---|---|---|---|---|---|---|---|---|")
 for arg in sys.argv[1:]:
-    label, path = arg.split("=", 1)
+    label, path = arg.split("::", 1)
     z = json.load(open(path))
     base = z["worlds"].get("1")
     for kind in ("full", "lazy"):
