@@ -16,6 +16,7 @@ struct gss_csr {
   std::vector<int32_t> h_rowptr;  // host copy, used to build segment descriptors lazily
   int32_t *d_segs[5];             // balanced SpMM: int4 descriptors per lane group, by log2(groups per wave)
   int32_t n_seg_blocks[5];
+  int32_t *d_live[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // row-filtered launches over many workgroups: [0] = count, [1 ..] = the workgroups (segment blocks) that hold a row the filter lets through (spmm.hip live_blocks_kernel)
   // a VIEW (spmm.hip GiantRows): the schedule covers the listed rows / entry ranges of the borrowed arrays instead of every row of rowptr
   bool by_items = false;
   std::vector<int32_t> item_row, item_first, item_len;

@@ -253,6 +253,7 @@ __global__ __launch_bounds__(kLongThreads) void spmm_long_kernel(CsrView a, cons
 // debug knob "spmm_seg_edges" (applies to CSR handles created afterwards)   [knob seg_edges, common.h Knobs]
 constexpr int kBalThreads = 1024;  // 512-thread workgroups measured 5-30 % slower (hub rows get half the groups)
 constexpr int kBalWaves = kBalThreads / 64;
+constexpr int kListWorkgroups = 1024;   // persistent workgroups of a list launch (two rounds of the 512 that fit the chip)
 
 template <int MODE>
 __device__ __forceinline__ long compact_off(const SpmmEpi &ep, int row, int d4, int f4) {
@@ -282,37 +283,11 @@ __device__ __forceinline__ bool row_mark_nonzero(const SpmmEpi &ep, int row, boo
   return !live;
 }
 
+// one workgroup's share of a balanced product: the segments of block `sblk`, feature slice `sidx` (the body of spmm_balanced_kernel and of
+// its list form below)
 template <int MODE, int LPR_LOG2, int VPL, bool NARROW>
-__global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, const int4 *__restrict__ segs, int d4,
-                                                                   const float *__restrict__ x, SpmmEpi ep, int rowstride_f, int pin_ns, int3 hot) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float4 *part = reinterpret_cast<float4 *>(smem);  // [16 waves][d4]
-  // pin_ns > 0: 1-D grid, slice = blockIdx.x % pin_ns.  Workgroups go to the XCDs round-robin by linear id, so XCD k
-  // only ever gathers slice k % pin_ns and its L2 holds 1/pin_ns of the operand
-  // (a launch that carries the batch preparation has ONE workgroup more, dispatched FIRST: as the last one it would start when the
-  //  others are about to finish and lengthen the launch by its own chain of loads -- measured +2.9 us on the 31.9 us kernel)
-  const bool has_prep = MODE == SPMM_FWD1 && ep.prep.idx != nullptr;
-  const int bx = (int)blockIdx.x - (has_prep ? 1 : 0);
-  const int sblk = pin_ns > 0 ? bx / pin_ns : bx;
-  const int sidx = pin_ns > 0 ? bx % pin_ns : (int)blockIdx.y;
-  if (has_prep && blockIdx.x == 0) {
-    // the side job (workgroup-uniform branch): batch_prepare_kernel's body for the whole batch
-    if (blockIdx.y == 0) {
-      const BatchPrep &q = ep.prep;
-      for (int i = threadIdx.x; i < q.b; i += kBalThreads) {
-        const int id = q.node_map ? q.node_map[q.idx[i]] : q.idx[i];
-        const int rel = id - q.lo;
-        const bool mine = rel >= 0 && rel < q.nl;
-        const int op = q.gid2op ? q.gid2op[id] : (mine ? rel : -1);
-        if (q.rloc) q.rloc[i] = min(max(rel, 0), max(q.nl - 1, 0));
-        if (q.pid) q.pid[i] = op;
-        if (q.keep) q.keep[i] = mine ? 1.f : 0.f;
-        if (q.rlist) q.rlist[i] = mine ? rel : -1;
-        if (op >= 0) q.pos[op] = i;
-      }
-    }
-    return;
-  }
+__device__ __forceinline__ void spmm_balanced_block(const CsrView &a, const int4 *__restrict__ segs, int d4, const float *__restrict__ x, const SpmmEpi &ep,
+                                                    int rowstride_f, int sblk, int sidx, int3 hot, float4 *part) {
   constexpr int LPR = 1 << LPR_LOG2;
   constexpr int GPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
@@ -604,6 +579,87 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
   }
 }
 
+
+template <int MODE, int LPR_LOG2, int VPL, bool NARROW>
+__global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, const int4 *__restrict__ segs, int d4,
+                                                                   const float *__restrict__ x, SpmmEpi ep, int rowstride_f, int pin_ns, int3 hot) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *part = reinterpret_cast<float4 *>(smem);  // [16 waves][d4]
+  // pin_ns > 0: 1-D grid, slice = blockIdx.x % pin_ns.  Workgroups go to the XCDs round-robin by linear id, so XCD k
+  // only ever gathers slice k % pin_ns and its L2 holds 1/pin_ns of the operand
+  // (a launch that carries the batch preparation has ONE workgroup more, dispatched FIRST: as the last one it would start when the
+  //  others are about to finish and lengthen the launch by its own chain of loads -- measured +2.9 us on the 31.9 us kernel)
+  const bool has_prep = MODE == SPMM_FWD1 && ep.prep.idx != nullptr;
+  const int bx = (int)blockIdx.x - (has_prep ? 1 : 0);
+  const int sblk = pin_ns > 0 ? bx / pin_ns : bx;
+  const int sidx = pin_ns > 0 ? bx % pin_ns : (int)blockIdx.y;
+  if (has_prep && blockIdx.x == 0) {
+    // the side job (workgroup-uniform branch): batch_prepare_kernel's body for the whole batch
+    if (blockIdx.y == 0) {
+      const BatchPrep &q = ep.prep;
+      for (int i = threadIdx.x; i < q.b; i += kBalThreads) {
+        const int id = q.node_map ? q.node_map[q.idx[i]] : q.idx[i];
+        const int rel = id - q.lo;
+        const bool mine = rel >= 0 && rel < q.nl;
+        const int op = q.gid2op ? q.gid2op[id] : (mine ? rel : -1);
+        if (q.rloc) q.rloc[i] = min(max(rel, 0), max(q.nl - 1, 0));
+        if (q.pid) q.pid[i] = op;
+        if (q.keep) q.keep[i] = mine ? 1.f : 0.f;
+        if (q.rlist) q.rlist[i] = mine ? rel : -1;
+        if (op >= 0) q.pos[op] = i;
+      }
+    }
+    return;
+  }
+  spmm_balanced_block<MODE, LPR_LOG2, VPL, NARROW>(a, segs, d4, x, ep, rowstride_f, sblk, sidx, hot, part);
+}
+
+// ---- row-filtered products over MANY workgroups (round 6) ----------------------------------------------------------------------
+// A lazy step's top-layer products compute a few thousand rows of millions (the batch rows; the batch rows and their neighbours), and so
+// does the batch-sparse backward hop.  The filters above make the other rows' segments gather nothing -- but every workgroup is still
+// dispatched, and at RMAT 10M that IS the kernel: 1.8 ms for 440 k workgroups of which 0.4 % hold a row that passes (measured: the
+// batch-sparse hop after its row filter went in, profiles/r06_bench_rmat_10M_200M.json).  So: live_blocks_kernel lists the workgroups
+// (segment blocks) with at least one row the filter lets through -- one pass over the descriptors, any order: every row is still summed
+// by its own lane groups in its own order, the bits do not depend on the list's order -- and spmm_balanced_list_kernel, a fixed grid of
+// persistent workgroups, walks that list.  Used from kListMinBlocks workgroups on (knob spmm_list_blocks).
+struct LiveFilter {
+  const int32_t *pos;        // live <=> pos[frow] >= 0            (NULL: no row map)
+  const uint32_t *bits;      // live <=> bit frow set               (NULL: no bitmap)
+  const int32_t *row_alias;  // frow = row_alias[row]               (NULL: frow = row)
+};
+__global__ __launch_bounds__(256) void live_blocks_kernel(const int4 *__restrict__ segs, int nblk, int groups_per_block, LiveFilter f,
+                                                          int32_t *__restrict__ out) {   // out[0] = count (zeroed by the caller), out[1 ..] = blocks
+  const int lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per segment block
+  if (blk >= nblk) return;
+  bool live = false;
+  for (int k = lane; k < groups_per_block; k += 64) {
+    const int row = segs[(size_t)blk * groups_per_block + k].x;
+    if (row < 0) continue;
+    const int frow = f.row_alias ? f.row_alias[row] : row;
+    bool ok = true;
+    if (f.pos) ok = f.pos[frow] >= 0;
+    if (ok && f.bits) ok = ((f.bits[(unsigned)frow >> 5] >> (frow & 31)) & 1u) != 0u;
+    live |= ok;
+  }
+  if (__any(live) && lane == 0) out[1 + atomicAdd(&out[0], 1)] = blk;
+}
+
+template <int MODE, int LPR_LOG2, int VPL, bool NARROW>
+__global__ __launch_bounds__(kBalThreads) void spmm_balanced_list_kernel(CsrView a, const int4 *__restrict__ segs, int d4, const float *__restrict__ x,
+                                                                        SpmmEpi ep, int rowstride_f, int pin_ns, int3 hot,
+                                                                        const int32_t *__restrict__ live) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *part = reinterpret_cast<float4 *>(smem);
+  const int items = live[0] * (pin_ns > 0 ? pin_ns : 1);   // pinned slices: item i = (block i / ns, slice i % ns); gridDim.x is a multiple of ns, so a
+  for (int it = (int)blockIdx.x; it < items; it += (int)gridDim.x) {   // workgroup -- and with it its XCD -- keeps its slice
+    const int sblk = live[1 + (pin_ns > 0 ? it / pin_ns : it)];
+    const int sidx = pin_ns > 0 ? it % pin_ns : (int)blockIdx.y;
+    spmm_balanced_block<MODE, LPR_LOG2, VPL, NARROW>(a, segs, d4, x, ep, rowstride_f, sblk, sidx, hot, part);
+    __syncthreads();   // the next block reuses `part`
+  }
+}
+
 template <int MODE, int LPR_LOG2, int VPL>
 static int launch_spmm_t(const gss_csr *a, int d4, const float *x, const SpmmEpi &ep, hipStream_t st);
 
@@ -679,6 +735,34 @@ static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool p
   // the hot / cold split pays where the table is far beyond the caches; below that every row is "hot"
   if ((double)a->n_cols * d4_slice * nslices * 16.0 < 256.0 * 1024 * 1024 && K().spmm_hot < 0) hot = make_int3(-1, 0, 0);
   const bool narrow = (double)a->n_cols * d4_slice * nslices * 16.0 < 4.0e9 && a->n_cols < (1 << 24) && hot.x < 0;
+  // a row filter over many workgroups: list the workgroups that hold a row it lets through and walk the list with persistent workgroups
+  // (see live_blocks_kernel).  BWD1S: only when its dead rows are not written at all (else every row's zeros are this launch's to write).
+  if constexpr (MODE == SPMM_PLAIN || MODE == SPMM_FWD1 || MODE == SPMM_BWD1S) {
+    LiveFilter f{nullptr, nullptr, nullptr};
+    if (MODE == SPMM_PLAIN) f = LiveFilter{ep.pos, ep.rowbits, ep.row_alias};
+    if (MODE == SPMM_FWD1) f = LiveFilter{nullptr, ep.posbits, nullptr};
+    if (MODE == SPMM_BWD1S && ep.skip_zero_rows && ep.nzbits_out) f = LiveFilter{nullptr, ep.rowbits, nullptr};
+    const int list_min = K().spmm_list_blocks;
+    if ((f.pos || f.bits) && !prep && list_min > 0 && nblk >= list_min) {
+      gss_csr *m = const_cast<gss_csr *>(a);   // lazily allocated scratch of the handle (one stream at a time, like the handle's other caches)
+      const int k = 6 - LPR_LOG2;
+      if (!m->d_live[k]) GSS_HIP(hipMalloc((void **)&m->d_live[k], sizeof(int32_t) * ((size_t)nblk + 1)));
+      GSS_HIP(hipMemsetAsync(m->d_live[k], 0, sizeof(int32_t), st));
+      hipLaunchKernelGGL(live_blocks_kernel, dim3(ceil_div(nblk, 4)), dim3(256), 0, st, segs, nblk, kBalWaves * (64 >> LPR_LOG2), f, m->d_live[k]);
+      GSS_LAUNCH_CHECK("live_blocks_kernel");
+      int gx = std::min(nblk, kListWorkgroups);
+      if (pin) gx = std::max(nslices, gx / nslices * nslices);   // a multiple of the slice count: a workgroup keeps its slice
+      const dim3 grid = pin ? dim3(gx) : dim3(gx, nslices);
+      if (narrow)
+        hipLaunchKernelGGL((spmm_balanced_list_kernel<MODE, LPR_LOG2, VPL, true>), grid, dim3(kBalThreads), lds, st, v, segs, d4_slice, x, ep,
+                           d4_slice * nslices * 4, pin ? nslices : 0, make_int3(-1, 0, 0), (const int32_t *)m->d_live[k]);
+      else
+        hipLaunchKernelGGL((spmm_balanced_list_kernel<MODE, LPR_LOG2, VPL, false>), grid, dim3(kBalThreads), lds, st, v, segs, d4_slice, x, ep,
+                           d4_slice * nslices * 4, pin ? nslices : 0, hot, (const int32_t *)m->d_live[k]);
+      GSS_LAUNCH_CHECK("spmm_balanced_list_kernel");
+      return GSS_OK;
+    }
+  }
   if (narrow)
     hipLaunchKernelGGL((spmm_balanced_kernel<MODE, LPR_LOG2, VPL, true>), pin ? dim3(nblk * nslices + extra) : dim3(nblk + extra, nslices), dim3(kBalThreads),
                        lds, st, v, segs, d4_slice, x, ep, d4_slice * nslices * 4, pin ? nslices : 0, make_int3(-1, 0, 0));
@@ -783,8 +867,10 @@ struct gss_giant_rows {
     for (Scratch &s : scratch)
       if (s.buf) (void)hipFree(s.buf);
     for (gss_csr *v : {&chunks, &shortv, &finish})
-      for (int k = 0; k < 5; ++k)
+      for (int k = 0; k < 5; ++k) {
         if (v->d_segs[k]) (void)hipFree(v->d_segs[k]);
+        if (v->d_live[k]) (void)hipFree(v->d_live[k]);
+      }
     if (d_chunk_row) (void)hipFree(d_chunk_row);
     if (d_fin_col) (void)hipFree(d_fin_col);
     if (d_fin_val) (void)hipFree(d_fin_val);
@@ -1233,8 +1319,10 @@ void gss_csr_destroy(gss_csr *a) {
   if (!a) return;
   delete a->giant;
   if (a->d_long_rows) (void)hipFree(a->d_long_rows);
-  for (int k = 0; k < 5; ++k)
+  for (int k = 0; k < 5; ++k) {
     if (a->d_segs[k]) (void)hipFree(a->d_segs[k]);
+    if (a->d_live[k]) (void)hipFree(a->d_live[k]);
+  }
   delete a;
 }
 

@@ -230,6 +230,7 @@ def test_nonzero_row_bitmaps_of_the_sparse_backward_change_nothing(world, L):
 
     def run(bits_rows):
         assert lib.gss_debug_set_option(b"sparse_bits_rows", bits_rows) == 0
+        assert lib.gss_debug_set_option(b"spmm_list_blocks", 1 if bits_rows == 1 else 2048) == 0     # (round 6) and the list form of the filtered hop
         try:
             comms = local_comms(world)
 
@@ -247,6 +248,7 @@ def test_nonzero_row_bitmaps_of_the_sparse_backward_change_nothing(world, L):
             return _threaded(world, fn, comms)
         finally:
             lib.gss_debug_set_option(b"sparse_bits_rows", 100000)
+            lib.gss_debug_set_option(b"spmm_list_blocks", 2048)
 
     plain, bits = run(100000), run(1)
     for a, b in zip(plain, bits):
