@@ -495,8 +495,10 @@ enum {
 };
 int gss_plan_profile(gss_plan *p, int enable);
 int gss_plan_profile_read(gss_plan *p, double *ms_out, int64_t *count_out, void *stream);
-/* tuning/debug knobs (A/B runs inside one process; 17 of them since round 6 -- the access-shape variants whose sweeps said "default holds" in
- * two or more rounds were removed from the kernels): "spmm_variant" = 1 (whole-row gather, wave per row) or
+/* tuning/debug knobs (A/B runs inside one process; 18 of them since round 6 -- the access-shape variants whose sweeps said "default holds" in
+ * two or more rounds were removed from the kernels): "spmm_list_blocks" = workgroups from which a ROW-FILTERED balanced SpMM (the lazy step's
+ * top-layer products, the batch-sparse backward hop) lists the workgroups that hold a passing row and walks the list with persistent
+ * workgroups instead of dispatching every workgroup (default 2048; 0 = never; same bits); "spmm_variant" = 1 (whole-row gather, wave per row) or
  * 2 (nnz-balanced segments, default); "spmm_slices" = 0 (automatic, default) or 1..8 feature slices in the balanced SpMM, "spmm_pin" = with a
  * manual "spmm_slices": slices time-separated (0, default) or pinned to XCDs (1) -- the automatic policy pins operands of <= 64 MB;
  * "spmm_hot_rows" = -1 (default: what gss_csr_set_hot declared) or a row count; "spmm_seg_edges" = entries per SpMM segment (default 32;

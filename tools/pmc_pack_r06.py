@@ -25,21 +25,26 @@ REPS_RMAT = 3
 
 
 def mode_of(name):
-    m = re.search(r"spmm_balanced_kernel<(\d+),", name)
+    m = re.search(r"spmm_balanced(?:_list)?_kernel<(\d+),", name)      # (the list form of a row-filtered product: same mode numbers)
     return int(m.group(1)) if m else None
+
+
+def newest(files):
+    """gpurun merges every job's files into the same local directories (the csv names carry the profiled pid): of several passes only the latest"""
+    return [max(files, key=os.path.getmtime)] if files else []
 
 
 def read(tag):
     """{mode: {counter: [values per launch]}}, {mode: [durations us]} over every pass r06_<tag>_*"""
     acc, dur = collections.defaultdict(lambda: collections.defaultdict(list)), collections.defaultdict(list)
     for dd in sorted(glob.glob(os.path.join(PMC, f"r06_{tag}_*"))):
-        for f in glob.glob(dd + "/**/*counter_collection.csv", recursive=True):
+        for f in newest(glob.glob(dd + "/**/*counter_collection.csv", recursive=True)):
             for r in csv.DictReader(open(f)):
                 m = mode_of(r["Kernel_Name"])
                 if m is not None:
                     acc[m][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if dd.endswith("FETCH_SIZE"):
-            for f in glob.glob(dd + "/**/*kernel_trace.csv", recursive=True):
+            for f in newest(glob.glob(dd + "/**/*kernel_trace.csv", recursive=True)):
                 for r in csv.DictReader(open(f)):
                     m = mode_of(r["Kernel_Name"])
                     if m is not None:
