@@ -23,7 +23,8 @@ struct Knobs {
   int spmm_hot = -1;         // overrides every CSR's hot set with rows [0, value) (-1 = the CSR's own, 0 = none)
   int seg_edges = 32;        // entries per SpMM segment (CSR handles created afterwards)
   int spmm_list_blocks = 2048;  // a row-filtered balanced SpMM over at least this many workgroups lists the workgroups that hold a passing row and walks the
-                             // list with persistent workgroups (spmm.hip live_blocks_kernel); 0 = never.  Same bits either way
+                             // list with persistent workgroups (spmm.hip live_blocks_kernel) -- when the caller expects few rows to pass (LiveHint);
+                             // 0 = never, 1 = always.  Same bits either way
   int spmm_giant = 32768;    // balanced SpMM, dense modes: rows with more stored entries than this are cut into chunks of a quarter of it that
                              // other workgroups sum (spmm.hip GiantRows); 0 = never.  CSR handles look at it with their first launch
   int gemm_variant = 2;      // projection tile shape: 2 = by width and row count (default), 3 = 128-node tiles of four waves forced, 5 = of eight waves forced

@@ -67,6 +67,16 @@ int csr_segments(const gss_csr *a, int gpw_log2, const int4 **out, int *n_blocks
 // Two-pass products (a shard's hop overlapped with its halo exchange, plan.hip): the rows' entries are split over two CSRs of the
 // same rows; the first pass is a plain product into `y`, the second pass -- any mode -- takes it as y_in, adds its own sums and
 // runs the epilogue.  y_in may be the buffer the second pass writes.
+// What the caller expects a row-filtered product to compute, in rows (an upper estimate; 0 = unknown): a launch lists its live workgroups
+// (spmm.hip live_blocks_kernel) only when that is a small part of the matrix's rows -- walking a list with persistent workgroups costs ~15 % over
+// the hardware's own dispatch when most workgroups are live (a hub shard's lazy products: every row is a neighbour of some batch row).
+struct LiveHint {
+  int64_t prev;
+  explicit LiveHint(int64_t rows);
+  ~LiveHint();
+  LiveHint(const LiveHint &) = delete;
+  LiveHint &operator=(const LiveHint &) = delete;
+};
 int spmm_fwd(const gss_csr *a, int32_t d, const float *x, float *y, const float *h, float *m, void *stream,
              const int32_t *row_pos = nullptr,    // plain product only: compute rows with row_pos[row] >= 0 only
              const uint32_t *row_bits = nullptr,  // Hadamard-fused product only: compute rows whose bit is set only

@@ -865,6 +865,9 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
           if (int rc = bits_set_list(p->needbits, p->lz.send_list, p->lz.h_cnt[p->P], stream)) return rc;
         p->needbits_valid = p->P == 1 || needed_only;   // own rows: complete (a shard without the request phase does not know its peers' batch rows)
       }
+      // (what the row-filtered products of a lazy top layer are expected to compute: the batch rows and their neighbours / the batch rows)
+      const int64_t deg_a = p->a->n_rows > 0 ? p->a->nnz / p->a->n_rows : 0;
+      LiveHint hint_nb(lazy_l ? (int64_t)lazy_b * (1 + deg_a) : 0);
       {
         const uint32_t *rbits = (lazy_l && p->needbits) ? p->needbits : nullptr;
         auto full = [&]() {
@@ -892,6 +895,7 @@ int plan_forward_impl(gss_plan *p, void *stream, const int32_t *lazy_rows = null
       // AM = A M                      (model.py:169)
       {
         const int32_t *rpos = lazy_l ? p->pos : nullptr;
+        LiveHint hint_b(lazy_l ? (int64_t)lazy_b : 0);   // (A_hat M on the batch rows only)
         auto full = [&]() {
           PROF(GSS_PROF_SPMM_FWD);
           return spmm_fwd(p->a, D.d, m, p->am[l], nullptr, nullptr, stream, rpos);
@@ -1159,6 +1163,7 @@ int plan_backward_impl(gss_plan *p, const BatchView &bv, int32_t b, const float 
       }
       {
         PROF(GSS_PROF_SPMM_BWD1);
+        LiveHint hint((int64_t)b * (1 + (p->at->n_rows > 0 ? p->at->nnz / p->at->n_rows : 0)));
         if (int rc = spmm_bwd1_sparse(p->at, D.d, p->gam_b, p->gax_b, p->pos, pos_row, p->xin[L - 1], p->ax[L - 1], p->u, p->t, stream, p->posbits,
                                       track_nz ? p->nzbits : nullptr, track_nz && p->P == 1, live_rows))
           return rc;

@@ -622,6 +622,11 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
 // (segment blocks) with at least one row the filter lets through -- one pass over the descriptors, any order: every row is still summed
 // by its own lane groups in its own order, the bits do not depend on the list's order -- and spmm_balanced_list_kernel, a fixed grid of
 // persistent workgroups, walks that list.  Used from kListMinBlocks workgroups on (knob spmm_list_blocks).
+static thread_local int64_t t_live_hint = 0;
+}  // namespace gss
+gss::LiveHint::LiveHint(int64_t rows) : prev(gss::t_live_hint) { gss::t_live_hint = rows; }
+gss::LiveHint::~LiveHint() { gss::t_live_hint = prev; }
+namespace gss {
 struct LiveFilter {
   const int32_t *pos;        // live <=> pos[frow] >= 0            (NULL: no row map)
   const uint32_t *bits;      // live <=> bit frow set               (NULL: no bitmap)
@@ -743,7 +748,8 @@ static int launch_balanced_t(const gss_csr *a, int d4_slice, int nslices, bool p
     if (MODE == SPMM_FWD1) f = LiveFilter{nullptr, ep.posbits, nullptr};
     if (MODE == SPMM_BWD1S && ep.skip_zero_rows && ep.nzbits_out) f = LiveFilter{nullptr, ep.rowbits, nullptr};
     const int list_min = K().spmm_list_blocks;
-    if ((f.pos || f.bits) && !prep && list_min > 0 && nblk >= list_min) {
+    const bool sparse_enough = list_min == 1 || t_live_hint <= 0 || t_live_hint * 4 < (int64_t)a->n_rows;   // (LiveHint: mostly-live launches keep the hardware's dispatch; knob value 1 = always: tests)
+    if ((f.pos || f.bits) && !prep && list_min > 0 && nblk >= list_min && sparse_enough) {
       gss_csr *m = const_cast<gss_csr *>(a);   // lazily allocated scratch of the handle (one stream at a time, like the handle's other caches)
       const int k = 6 - LPR_LOG2;
       if (!m->d_live[k]) GSS_HIP(hipMalloc((void **)&m->d_live[k], sizeof(int32_t) * ((size_t)nblk + 1)));
