@@ -460,6 +460,8 @@ int gss_plan_comm_stats(gss_plan *p, int64_t *out3);
 int gss_plan_sync_stats(gss_plan *p, int64_t *out2);
 /* layer activations for parity tests: which 0 AX, 1 AM, 2 P of layer `layer` (0-based) */
 const float *gss_plan_activation(const gss_plan *p, int layer, int which);
+/* bytes of the plan's slab.  Not counted: what a gss_csr handle caches for itself -- its segment descriptors, the chunk scratch of giant rows (one
+ * buffer per stream the handle is used on, grown to the widest d seen), the live-workgroup list of row-filtered products. */
 size_t gss_plan_device_bytes(const gss_plan *p);
 /* every buffer the plan carves from its slab is followed by a 256-byte guard no kernel may touch; this synchronises the device and
  * verifies them all (GSS_EINVAL names the first one that was overwritten).  For tests. */
