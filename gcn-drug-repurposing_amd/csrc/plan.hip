@@ -1518,6 +1518,12 @@ const float *gss_plan_activation(const gss_plan *p, int layer, int which) {
   if (!p || layer < 0 || layer >= p->desc.num_layers) return nullptr;
   // 3 / 4 (round 6, parity tests at full size): the pre-activation gradient buffers as the last backward pass left them -- dP of the bottom
   // layer on all rows [n][d] (L >= 2) / the top layer's dP on the batch rows, in batch order [b][d]; `layer` is ignored for them
+  // 5 / 6: u [rows of A_hat^T's operand][d] and t [n][d] of the top layer's first backward hop; 7: the bitmap (as floats' bytes: uint32 words)
+  // of the rows of u / t that hop wrote -- under it a row whose bit is clear was NOT written (it is zero by contract, its bytes are stale)
+  if (which == 5) return p->u;
+  if (which == 6) return p->t;
+  if (which == 7) return reinterpret_cast<const float *>(p->nzbits);
+  if (which == 8) return p->gab;   // [2 b][d]: the batch rows' input gradients g_ax (first b rows) and g_am, in batch order
   return which == 0 ? p->ax[layer] : which == 1 ? p->am[layer] : which == 2 ? p->p[layer] : which == 3 ? p->dp : which == 4 ? p->dp_b : nullptr;
 }
 size_t gss_plan_device_bytes(const gss_plan *p) { return p ? p->slab_bytes : 0; }

@@ -125,12 +125,26 @@ class GssEngine:
 
     def activation(self, layer: int, which: str) -> torch.Tensor:
         """copy of AX / AM / P of a layer, or of the gradient buffers the last backward pass left: "dP" = the bottom layer's pre-activation
-        gradient [n][d] (L >= 2), "dP_batch" = the top layer's on the batch rows, in batch order [max_batch][d] (parity tests)"""
-        src = self.lib.gss_plan_activation(self.handle, layer, {"AX": 0, "AM": 1, "P": 2, "dP": 3, "dP_batch": 4}[which])
+        gradient [n][d] (L >= 2), "dP_batch" = the top layer's on the batch rows, in batch order [max_batch][d]; "u" / "t" = the results of the top
+        layer's first backward hop, "g_batch" = the batch rows' input gradients [g_ax ; g_am] ([2 max_batch][d]; the first b rows of each half are valid
+        when b < max_batch: the halves then start at rows 0 and b) (parity tests)"""
+        src = self.lib.gss_plan_activation(self.handle, layer, {"AX": 0, "AM": 1, "P": 2, "dP": 3, "dP_batch": 4, "u": 5, "t": 6, "g_batch": 8}[which])
         assert src, (layer, which)
-        out = torch.empty(self.max_batch if which == "dP_batch" else self.n, self.d, dtype=torch.float32, device=self.x.device)
+        rows = {"dP_batch": self.max_batch, "g_batch": 2 * self.max_batch}.get(which, self.n)
+        out = torch.empty(rows, self.d, dtype=torch.float32, device=self.x.device)
         _lib.check(self.lib.gss_memcpy_d2d(out.data_ptr(), src, out.numel() * 4, _lib.current_stream()), "gss_memcpy_d2d")
         return out
+
+    def written_rows_bitmap(self):
+        """bool [n]: the rows of u / t the top layer's first backward hop wrote in the last whole step (plans over huge operands skip the rows
+        that are zero by contract), or None when the plan keeps no such bitmap (every row is written)"""
+        src = self.lib.gss_plan_activation(self.handle, 0, 7)
+        if not src:
+            return None
+        words = torch.empty((self.n + 31) // 32, dtype=torch.int32, device=self.x.device)
+        _lib.check(self.lib.gss_memcpy_d2d(words.data_ptr(), src, words.numel() * 4, _lib.current_stream()), "gss_memcpy_d2d")
+        bits = (words.view(-1, 1) >> torch.arange(32, device=words.device, dtype=torch.int32).view(1, -1)) & 1
+        return bits.reshape(-1)[:self.n].bool()
 
     def profile(self, enable=True):
         _lib.check(self.lib.gss_plan_profile(self.handle, 1 if enable else 0), "gss_plan_profile")

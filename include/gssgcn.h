@@ -458,7 +458,10 @@ int gss_plan_comm_stats(gss_plan *p, int64_t *out3);
  * request stream while the caller's stream keeps running: the request phase of the lazy step's subset exchange}.  An RCCL job with
  * default knobs: {0, 0} per full step, {0, 1} per lazy step from 262,144 nodes on, {0, 0} below.  Zeros on one GPU. */
 int gss_plan_sync_stats(gss_plan *p, int64_t *out2);
-/* layer activations for parity tests: which 0 AX, 1 AM, 2 P of layer `layer` (0-based) */
+/* layer activations for parity tests: which 0 AX, 1 AM, 2 P of layer `layer` (0-based); 3 the bottom layer's dP [n][d] and 4 the top layer's dP on
+ * the batch rows [b][d] as the last backward pass left them; 5 / 6 u and t of the top layer's first backward hop, 7 the uint32 bitmap of the rows of
+ * u / t it wrote (NULL on plans without it: then every row is written), 8 the batch rows' input gradients [g_ax ; g_am] as [2 b][d] -- `layer`
+ * is ignored for 3 .. 8 */
 const float *gss_plan_activation(const gss_plan *p, int layer, int which);
 /* bytes of the plan's slab.  Not counted: what a gss_csr handle caches for itself -- its segment descriptors, the chunk scratch of giant rows (one
  * buffer per stream the handle is used on, grown to the widest d seen), the live-workgroup list of row-filtered products. */
