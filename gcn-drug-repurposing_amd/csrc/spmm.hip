@@ -621,7 +621,7 @@ __global__ __launch_bounds__(kBalThreads) void spmm_balanced_kernel(CsrView a, c
 // batch-sparse hop after its row filter went in, profiles/r06_bench_rmat_10M_200M.json).  So: live_blocks_kernel lists the workgroups
 // (segment blocks) with at least one row the filter lets through -- one pass over the descriptors, any order: every row is still summed
 // by its own lane groups in its own order, the bits do not depend on the list's order -- and spmm_balanced_list_kernel, a fixed grid of
-// persistent workgroups, walks that list.  Used from kListMinBlocks workgroups on (knob spmm_list_blocks).
+// persistent workgroups, walks that list.  Used from 2,048 workgroups on (knob spmm_list_blocks) where the caller expects few rows to pass (LiveHint).
 static thread_local int64_t t_live_hint = 0;
 }  // namespace gss
 gss::LiveHint::LiveHint(int64_t rows) : prev(gss::t_live_hint) { gss::t_live_hint = rows; }
