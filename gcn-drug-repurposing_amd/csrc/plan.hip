@@ -1346,7 +1346,7 @@ void gss_plan_destroy(gss_plan *p) {
 // different addresses); the same plan under alternating settings does not.
 int gss_plan_debug_set_option(gss_plan *p, const char *name, int value) {
   GSS_REQUIRE(p && name, "plan_debug_set_option: null argument");
-  static const char *const kLive[] = {"gemm_variant", "spmm_slices", "spmm_pin", "gemm_ws"};
+  static const char *const kLive[] = {"gemm_variant", "spmm_slices", "spmm_pin", "gemm_ws", "spmm_list_blocks"};
   bool ok = false;
   for (const char *k : kLive) ok = ok || strcmp(k, name) == 0;
   GSS_REQUIRE(ok, "plan_debug_set_option: only kernel-selection knobs can change on a live plan");

@@ -48,7 +48,7 @@ const char *gss_source_hash(const char *file);
  * (gss_dense_fwd) stores its wall-clock stamps {start, loop begin, loop end, end} + {workgroup id, HW_ID} there (6 x 8 bytes per wave).
  * NULL (the default) switches it off; no production path sets it. */
 int gss_debug_set_stamp_buffer(void *device_buffer);
-/* measurement aid (tools/ab_live.py): changes one KERNEL-SELECTION knob ("gemm_variant", "gemm_ws", "spmm_slices", "spmm_pin") in a live
+/* measurement aid (tools/ab_live.py): changes one KERNEL-SELECTION knob ("gemm_variant", "gemm_ws", "spmm_slices", "spmm_pin", "spmm_list_blocks") in a live
  * plan's snapshot, so that one plan -- the same buffers at the same addresses --
  * can be timed under alternating settings; knobs that size a workspace or steer the plan's bookkeeping are refused (GSS_EINVAL).
  * Not thread-safe against gss_debug_set_option on another thread. */
