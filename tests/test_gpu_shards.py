@@ -676,7 +676,7 @@ def test_a_rank_whose_job_wide_knob_differs_is_refused_by_name():
         t0 = threading.Thread(target=create, args=(0,))
         t0.start()
         started.wait(60)
-        time.sleep(3.0)              # rank 0 has taken its snapshot (the first thing plan creation does) and waits for its peers
+        time.sleep(5.0)              # rank 0 has taken its snapshot (the first thing plan creation does) and waits for its peers
     finally:
         assert lib.gss_debug_set_option(b"halo_recompute", -1) == 0
     rest = [threading.Thread(target=create, args=(r,)) for r in (1, 2)]
